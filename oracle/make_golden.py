@@ -1,0 +1,172 @@
+"""Capture golden vectors from the reference's own Python.  CONTAINER-ONLY
+(needs /root/reference); run from the repo root:
+
+    python -m oracle.make_golden            # writes tests/golden/*.npz
+
+The reference modules run as shipped (oracle/ref_import.py lists the five
+stand-ins for absent third-party / CUDA-only pieces).  Weights come from the
+deterministic recipe in graspldm_amd/synthetic.py (seed 0), inputs from the
+same module, noise from torch.manual_seed(1234) in the reference's draw order.
+Fixtures hold inputs and expected outputs only (data, no reference source).
+
+  G2 pvcnn_encoder.npz     PVCNNEncoder (fpc config) on 2 clouds -> z[2,3,64]
+  G3 denoiser.npz          TimeConditionedResNet1D.forward at 6 timesteps
+  G4 decoder.npz           ConditionalGraspPoseDecoder.forward
+  G5 ddim_traj.npz         GaussianDiffusion1D.sample, 100 DDIM steps (5 probes)
+     ddpm_traj.npz         1000 DDPM steps, fixed_large, recorded noise
+  G6 tmrp_to_H.npz         utils/rotations.tmrp_to_H on 64 poses (incl |m|~1)
+  G7 ldm_e2e.npz           GraspLatentDDM.generate_grasps B=2 G=20 N=1024 + epilogue
+     vae_e2e.npz           GraspCVAE.generate_grasps     B=1 G=20 (N=1024 and N=64)
+  schema_*.json            state-dict key -> (shape, dtype) of the reference modules
+  G8 sa_module.npz         PointNetSAModule on one cloud (SSG SA1/SA2 shapes)
+     pointnet2_ssg.npz     PointNet2SSG forward on one cloud (every 8th point kept)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from graspldm_amd import synthetic  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SEED = 1234
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: (_np(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"  {name:22s} {os.path.getsize(path) / 1024:8.1f} KiB")
+
+
+def _schema(name, module):
+    import json
+    sd = module.state_dict()
+    path = os.path.join(OUT, name)
+    with open(path, "w") as f:
+        json.dump({k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()}, f, indent=0)
+    print(f"  {name:22s} {os.path.getsize(path) / 1024:8.1f} KiB  ({len(sd)} entries)")
+
+
+def _cond(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, 3, 64, generator=g)
+
+
+@torch.no_grad()
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref_import.install_shims()
+
+    # ---- full LDM (DDIM flavour for G5/G7; weights are scheduler-independent)
+    ldm = ref_import.build_reference_ldm(noise_scheduler_type="ddim")
+    synthetic.load_synthetic_weights(ldm, seed=0)
+    _schema("schema_fpc_ldm.json", ldm)
+    den = ldm.diffusion_model.model
+    vae = ldm.vae_model
+    pcs, metas = synthetic.synthetic_batch(2, 1024)
+
+    # G2
+    z = vae.encode_pc(pcs)
+    _save("pvcnn_encoder.npz", pc=pcs, z=z)
+
+    # G3
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 1, 4, generator=g)
+    zc = _cond(8, 8)
+    ts = [0, 1, 10, 500, 990, 999]
+    eps = torch.stack([den(x, time=torch.full((8,), t, dtype=torch.long), z_cond=zc) for t in ts])
+    _save("denoiser.npz", x=x, z_cond=zc, t=np.array(ts), eps=eps)
+
+    # G4
+    g = torch.Generator().manual_seed(9)
+    zh = torch.randn(8, 4, generator=g)
+    tmrp, logit = vae.decoder(zh, zc)
+    _save("decoder.npz", z_h=zh, z_cond=zc, tmrp=tmrp, logit=logit)
+
+    # G5 DDIM 100 steps through the reference's own sample() loop
+    ldm.set_inference_timesteps(100)
+    torch.manual_seed(SEED)
+    x_T = torch.randn(8, 1, 4)
+    torch.manual_seed(SEED)
+    x0, trace = ldm.diffusion_model.sample(z_cond=zc, batch_size=8, return_all=True, device="cpu")
+    assert torch.equal(trace[0], x_T)
+    probes = [1, 10, 50, 90, 100]  # trace[i] = x after i steps -> t = 990, 900, 500, 100, 0
+    _save("ddim_traj.npz", x_T=x_T, z_cond=zc, probes=np.array(probes),
+          x=torch.stack([trace[i] for i in probes]), x0=x0)
+
+    # G7 LDM end to end (B=2, G=20) + the inference epilogue from rotations.py
+    from grasp_ldm.utils.rotations import tmrp_to_H
+    torch.manual_seed(SEED)
+    (tm, lg), _ = ldm.generate_grasps(pcs, num_grasps=20, device="cpu")
+    un = tm.view(2, 20, 6) * metas["grasp_std"].unsqueeze(-2) + metas["grasp_mean"].unsqueeze(-2)
+    H = tmrp_to_H(un)
+    _save("ldm_e2e.npz", pc=pcs, grasp_mean=metas["grasp_mean"], grasp_std=metas["grasp_std"],
+          tmrp=tm, logit=lg, H=H, confidence=torch.sigmoid(lg.view(2, 20, 1)), seed=SEED)
+
+    # G7b VAE mode, N=1024
+    torch.manual_seed(SEED)
+    tm_v, lg_v = vae.generate_grasps(pcs[:1], num_grasps=20)
+    _save("vae_e2e.npz", pc=pcs[:1], tmrp=tm_v, logit=lg_v, seed=SEED)
+
+    # G5b DDPM 1000 steps, fixed_large, recorded noise
+    ldm_p = ref_import.build_reference_ldm(noise_scheduler_type="ddpm")
+    synthetic.load_synthetic_weights(ldm_p, seed=0)
+    torch.manual_seed(SEED)
+    noise = [torch.randn(4, 1, 4)]
+    for _ in range(999):
+        noise.append(torch.randn(4, 1, 4))
+    torch.manual_seed(SEED)
+    x0p, trace_p = ldm_p.diffusion_model.sample(z_cond=zc[:4], batch_size=4, return_all=True, device="cpu")
+    assert torch.equal(trace_p[0], noise[0])
+    probes_p = [1, 100, 500, 900, 1000]
+    _save("ddpm_traj.npz", x_T=noise[0], step_noise=torch.stack(noise[1:]), z_cond=zc[:4],
+          probes=np.array(probes_p), x=torch.stack([trace_p[i] for i in probes_p]), x0=x0p)
+
+    # G7c VAE mode with a 64-point encoder (literal BASELINE config 1)
+    ldm64 = ref_import.build_reference_ldm(n_points=64)
+    synthetic.load_synthetic_weights(ldm64, seed=0)
+    _schema("schema_fpc_ldm_n64.json", ldm64)
+    pc64, _ = synthetic.synthetic_batch(1, 64)
+    torch.manual_seed(SEED)
+    tm64, lg64 = ldm64.vae_model.generate_grasps(pc64, num_grasps=20)
+    _save("vae_e2e_n64.npz", pc=pc64, tmrp=tm64, logit=lg64, seed=SEED)
+
+    # G6
+    g = torch.Generator().manual_seed(11)
+    poses = torch.randn(64, 6, generator=g)
+    poses[:8, 3:] = poses[:8, 3:] / poses[:8, 3:].norm(dim=-1, keepdim=True)  # |m| = 1
+    poses[8:12, 3:] = 0
+    _save("tmrp_to_H.npz", tmrp=poses, H=tmrp_to_H(poses))
+
+    # G8 set abstraction
+    from grasp_ldm.models.modules.ext.pvcnn.modules.pointnet import PointNetSAModule
+    from grasp_ldm.models.modules.ext.pvcnn.pointnet2 import PointNet2SSG
+    cloud = pcs[:1].transpose(1, 2).contiguous() * 0.05 / 0.12  # ~unit-scale coords so the radii bite
+    sa1 = PointNetSAModule(num_centers=512, radius=0.2, num_neighbors=64, in_channels=0, out_channels=(64, 64, 128)).eval()
+    synthetic.load_synthetic_weights(sa1, seed=1)
+    _schema("schema_sa1.json", sa1)
+    f1, c1 = sa1((None, cloud))
+    sa2 = PointNetSAModule(num_centers=128, radius=0.4, num_neighbors=64, in_channels=128, out_channels=(128, 128, 256)).eval()
+    synthetic.load_synthetic_weights(sa2, seed=2)
+    _schema("schema_sa2.json", sa2)
+    f2, c2 = sa2((f1, c1))
+    _save("sa_module.npz", coords=cloud, f1=f1[:, :, ::4], c1=c1, f2=f2, c2=c2)
+    ssg = PointNet2SSG(extra_feature_channels=0).eval()
+    synthetic.load_synthetic_weights(ssg, seed=3)
+    _schema("schema_pointnet2_ssg.json", ssg)
+    _save("pointnet2_ssg.npz", coords=cloud, out=ssg(cloud)[:, :, ::8])
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
