@@ -1,0 +1,91 @@
+"""ctypes binding of libgldm_hip.so (C ABI: include/gldm.h).
+
+The HIP library is the product: there is no CPU or eager-PyTorch fallback.  If
+the shared object is missing or a kernel launch fails, callers get an exception.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgldm_hip.so")
+
+ABI_VERSION = 1
+
+
+class GldmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+_SIGNATURES = {
+    # name: argtypes  (all return int)
+    "gldm_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
+    "gldm_grouping_forward": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "gldm_gather_features_forward": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "gldm_furthest_point_sampling": [_vp, _i, _i, _i, _vp, _vp],
+    "gldm_three_nn_interpolate_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "gldm_avg_voxelize_forward": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "gldm_trilinear_devoxelize_forward": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "gldm_voxel_coords": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
+    "gldm_sa_group": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
+}
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into libgldm_hip.so (hipcc cross-compiles
+    without a GPU)."""
+    import subprocess
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc"), "-j4"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise GldmError("building libgldm_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises GldmError loudly when it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GldmError(
+            f"{LIB_PATH} is missing: the gfx950 HIP library is required (no fallback path). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C graspldm_amd/csrc`.")
+    try:
+        h = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise GldmError(f"cannot load {LIB_PATH}: {e}") from e
+    h.gldm_abi_version.restype = _i
+    h.gldm_abi_version.argtypes = []
+    h.gldm_status_string.restype = ctypes.c_char_p
+    h.gldm_status_string.argtypes = [_i]
+    if h.gldm_abi_version() != ABI_VERSION:
+        raise GldmError(f"libgldm_hip.so ABI {h.gldm_abi_version()} != expected {ABI_VERSION}; rebuild it")
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(h, name)
+        fn.argtypes = argtypes
+        fn.restype = _i
+    _lib = h
+    return h
+
+
+def call(name, *args):
+    h = lib()
+    status = getattr(h, name)(*args)
+    if status != 0:
+        raise GldmError(f"{name} failed: {h.gldm_status_string(status).decode()} (status {status})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

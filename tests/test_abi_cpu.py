@@ -1,0 +1,67 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gldm.h declares
+(no compute calls without a GPU), and the oracle's C library builds."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "gldm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gldm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_entry_points():
+    names = _declared()
+    assert "gldm_ball_query" in names and "gldm_sa_group" in names and len(names) >= 11
+
+
+def test_library_exports_every_declared_symbol():
+    from graspldm_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in _declared() if not hasattr(h, n)]
+    assert not missing, f"declared in gldm.h but not exported: {missing}"
+    lib = _lib.lib()
+    assert lib.gldm_abi_version() == _lib.ABI_VERSION
+    assert lib.gldm_status_string(0) == b"ok"
+
+
+def test_python_binding_covers_every_declared_symbol():
+    from graspldm_amd import _lib
+    bound = set(_lib._SIGNATURES) | {"gldm_abi_version", "gldm_status_string"}
+    assert set(_declared()) <= bound, sorted(set(_declared()) - bound)
+
+
+def test_invalid_arguments_return_status_not_exit():
+    from graspldm_amd import _lib
+    h = _lib.lib()
+    # null pointers / non-positive sizes are rejected before any HIP call
+    assert h.gldm_ball_query(None, None, 1, 1, 1, 0.1, 1, None, None) == -1
+    assert h.gldm_grouping_forward(None, None, 0, 0, 0, 0, 0, None, None) == -1
+    with pytest.raises(_lib.GldmError):
+        _lib.call("gldm_furthest_point_sampling", None, 1, 16, 4, None, None)
+
+
+def test_backend_has_the_twelve_reference_names():
+    from graspldm_amd.backend import _backend
+    names = ["gather_features_forward", "gather_features_backward", "furthest_point_sampling", "ball_query",
+             "grouping_forward", "grouping_backward", "three_nearest_neighbors_interpolate_forward",
+             "three_nearest_neighbors_interpolate_backward", "trilinear_devoxelize_forward",
+             "trilinear_devoxelize_backward", "avg_voxelize_forward", "avg_voxelize_backward"]
+    for n in names:
+        assert callable(getattr(_backend, n)), n
+    with pytest.raises(NotImplementedError):
+        _backend.grouping_backward(None, None, 0)
+
+
+def test_backend_rejects_cpu_tensors_like_the_reference():
+    import torch
+    from graspldm_amd.backend import _backend
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        _backend.ball_query(torch.zeros(1, 3, 4), torch.zeros(1, 3, 8), 0.1, 2)
