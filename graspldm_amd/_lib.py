@@ -31,6 +31,10 @@ _SIGNATURES = {
     "gldm_trilinear_devoxelize_forward": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gldm_voxel_coords": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
     "gldm_sa_group": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
+    "gldm_r1d_cond_embed": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "gldm_denoise": [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "gldm_decode": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "gldm_pose_epilogue": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
 }
 
 
@@ -70,6 +74,8 @@ def lib():
         fn = getattr(h, name)
         fn.argtypes = argtypes
         fn.restype = _i
+    h.gldm_r1d_workspace_bytes.argtypes = [_vp, _i]
+    h.gldm_r1d_workspace_bytes.restype = ctypes.c_longlong
     _lib = h
     return h
 

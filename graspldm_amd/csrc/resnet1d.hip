@@ -1,0 +1,712 @@
+// resnet1d.hip -- the fused 1-D ResNet engine of GraspLDM on gfx950:
+//   * gldm_denoise : the whole reverse-diffusion loop (T steps of
+//                    TimeConditionedResNet1D.forward + DDIM/DDPM update) in ONE
+//                    launch; the latent never leaves the chip between steps;
+//   * gldm_decode  : ConditionalGraspPoseDecoder.forward (in_layer, ResNet1D,
+//                    tmrp / class_logits heads);
+//   * gldm_r1d_cond_embed, gldm_pose_epilogue : the small ops either side.
+//
+// Mapping to CDNA4
+//   A workgroup (8 waves) owns a tile of kCols = 64 activation columns =
+//   64/L samples x L positions (L = 4: 16 latents, L = 16: 4 decoder rows) and
+//   walks every layer with activations resident in LDS as [channel][column]
+//   (XOR-swizzled so MFMA B-fragment reads are conflict free).  Every conv /
+//   1x1 is a GEMM  W[Cout x taps*Cin] * im2col(X)[taps*Cin x 64]  on
+//   v_mfma_f32_16x16x4_f32 (exact f32: the parity budget is 1e-4 on poses after
+//   100 steps, and the reference's eps is dtype dependent, so no bf16 here).
+//   A operands (weights, standardised and laid out in fragment order on the
+//   host) stream from L2 straight into VGPRs as 16-byte coalesced loads, one
+//   k-block ahead; B operands are LDS reads with the k=3 halo handled by a lane
+//   mask instead of a materialised im2col.  GroupNorm / LayerNorm / softmax run
+//   with lane = column so rows are read conflict-free and statistics reduce by
+//   wave shuffles plus one small cross-wave exchange.
+//   LinearAttention at n = L is reassociated:  out = V (K^T Q)  (an L x L
+//   matrix per sample and head) instead of (V K^T) Q: 8x fewer FLOPs, same math.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gldm.h"
+
+#define GLDM_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kCols = 64;               // activation columns per workgroup
+constexpr int kHeads = 4, kDimHead = 32, kHidden = kHeads * kDimHead;  // LinearAttention defaults
+constexpr int kMaxC = 256;
+
+// LDS map (floats).  X: block input / residual stream, H: scratch.
+constexpr int kBufX = 0;
+constexpr int kBufH = kMaxC * kCols;            // 16384
+constexpr int kBufY = 128 * kCols;              // 8192  (attention: LayerNorm output, later to_out output)
+constexpr int kBufO = kBufH;                    // 16384 (attention output, 128 rows)
+constexpr int kBufQKV = kBufO + kHidden * kCols;  // 24576 (two heads of q,k,v: 192 rows)
+constexpr int kArena = kBufQKV + 192 * kCols;   // 36864
+constexpr int kMiscLat = kArena;                // [64] current latent row
+constexpr int kMiscEps = kMiscLat + kCols;      // [64]
+constexpr int kMiscG = kMiscEps + kCols;        // [S][E] <= 256
+constexpr int kMiscRed1 = kMiscG + 320;         // [8][64]
+constexpr int kMiscRed2 = kMiscRed1 + kWaves * kCols;
+constexpr int kLdsFloats = kMiscRed2 + kWaves * kCols;  // 38336 floats = 149.75 KiB
+static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ int swz(int row, int col) { return row * kCols + (col ^ ((row & 1) << 4)); }
+
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + fast_exp(-x)); }
+
+struct Ctx {
+  const float *w;   // packed weights
+  float *lds;
+  int tid, wave, lane;
+};
+
+// ---------------------------------------------------------------- GEMM ----
+// acc[mi][ni] += W[16(mt0+mi).., :] * im2col(src)[:, 16(nt0+ni)..]
+template <int L, int MT, int NT>
+__device__ __forceinline__ void gemm_tiles(const Ctx &c, const float *__restrict__ wp, int kblocks, int mt0, int nt0,
+                                           const float *src, int cin, int ktaps, f32x4 (&acc)[MT][NT]) {
+  const int col = c.lane & 15, kq = c.lane >> 4;
+  int n[NT], pos[NT];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    n[ni] = 16 * (nt0 + ni) + col;
+    pos[ni] = n[ni] & (L - 1);
+  }
+  const float4 *wv = reinterpret_cast<const float4 *>(wp);
+  float4 a_cur[MT], a_nxt[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) a_cur[mi] = wv[((size_t)(mt0 + mi) * kblocks) * 64 + c.lane];
+  int dk = 0, cib = 0;
+  const int pad = ktaps == 3 ? 1 : 0;
+  for (int kb = 0; kb < kblocks; ++kb) {
+    if (kb + 1 < kblocks) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) a_nxt[mi] = wv[((size_t)(mt0 + mi) * kblocks + kb + 1) * 64 + c.lane];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ci = cib + kq;
+      const bool kvalid = dk < ktaps;
+      const int shift = dk - pad;
+      float b[NT];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        const int p = pos[ni] + shift;
+        const bool ok = kvalid && (p >= 0) && (p < L);
+        const int row = ok ? ci : 0;
+        const int nn = ok ? n[ni] + shift : 0;
+        const float v = src[swz(row, nn)];
+        b[ni] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const float a = j == 0 ? a_cur[mi].x : (j == 1 ? a_cur[mi].y : (j == 2 ? a_cur[mi].z : a_cur[mi].w));
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[ni], acc[mi][ni], 0, 0, 0);
+      }
+      cib += 4;
+      if (cib >= cin) {
+        cib = 0;
+        ++dk;
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) a_cur[mi] = a_nxt[mi];
+  }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void store_tiles(const Ctx &c, const f32x4 (&acc)[MT][NT], int mt0, int nt0, float *dst,
+                                            int cout, const float *__restrict__ bias) {
+  const int col = c.lane & 15, kq = c.lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * (mt0 + mi) + 4 * kq + r;
+      if (row < cout) {
+        const float bv = bias ? bias[row] : 0.f;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) dst[swz(row, 16 * (nt0 + ni) + col)] = acc[mi][ni][r] + bv;
+      }
+    }
+  }
+}
+
+template <int L, int MT, int NT>
+__device__ __forceinline__ void gemm_fixed(const Ctx &c, const float *wp, int kblocks, int mt0, int nt0, bool active,
+                                           const float *src, int cin, int ktaps, float *dst, int cout,
+                                           const float *bias, bool alias) {
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (active) gemm_tiles<L, MT, NT>(c, wp, kblocks, mt0, nt0, src, cin, ktaps, acc);
+  if (alias) __syncthreads();
+  if (active) store_tiles<MT, NT>(c, acc, mt0, nt0, dst, cout, bias);
+}
+
+// dst[cout][64] = W * im2col(src[cin][64]) + bias.  Ends with a barrier.
+// alias: dst overlaps src -> all reads complete (barrier) before any store.
+template <int L>
+__device__ void conv_gemm(const Ctx &c, int w_off, int b_off, const float *src, int cin, int ktaps, float *dst,
+                          int cout, bool alias) {
+  const float *wp = c.w + w_off;
+  const float *bias = b_off >= 0 ? c.w + b_off : nullptr;
+  const int mtiles = (cout + 15) >> 4;
+  const int kblocks = (ktaps * cin + 15) >> 4;
+  const int w = c.wave;
+  if (mtiles == 16) {
+    gemm_fixed<L, 2, 4>(c, wp, kblocks, 2 * w, 0, true, src, cin, ktaps, dst, cout, bias, alias);
+  } else if (mtiles == 12) {
+    gemm_fixed<L, 3, 2>(c, wp, kblocks, 3 * (w & 3), 2 * (w >> 2), true, src, cin, ktaps, dst, cout, bias, alias);
+  } else if (mtiles == 8) {
+    gemm_fixed<L, 1, 4>(c, wp, kblocks, w, 0, true, src, cin, ktaps, dst, cout, bias, alias);
+  } else if (mtiles == 4) {
+    gemm_fixed<L, 1, 2>(c, wp, kblocks, w & 3, 2 * (w >> 2), true, src, cin, ktaps, dst, cout, bias, alias);
+  } else if (mtiles == 2) {
+    gemm_fixed<L, 1, 1>(c, wp, kblocks, w & 1, w >> 1, true, src, cin, ktaps, dst, cout, bias, alias);
+  } else if (mtiles == 1) {
+    gemm_fixed<L, 1, 1>(c, wp, kblocks, 0, w & 3, w < 4, src, cin, ktaps, dst, cout, bias, alias);
+  } else {
+    // generic widths: every wave walks (m-tile, n-tile) jobs; results are parked
+    // in registers for up to 8 jobs per wave when the output aliases the input.
+    const int jobs = mtiles * 4;
+    if (!alias) {
+      for (int job = w; job < jobs; job += kWaves)
+        gemm_fixed<L, 1, 1>(c, wp, kblocks, job >> 2, job & 3, true, src, cin, ktaps, dst, cout, bias, false);
+    } else {
+      f32x4 acc[8][1][1];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        acc[q][0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int job = w + q * kWaves;
+        if (job < jobs) gemm_tiles<L, 1, 1>(c, wp, kblocks, job >> 2, job & 3, src, cin, ktaps, acc[q]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int job = w + q * kWaves;
+        if (job < jobs) store_tiles<1, 1>(c, acc[q], job >> 2, job & 3, dst, cout, bias);
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ----------------------------------------------------------- GroupNorm ----
+// In place on `buf` (or accumulated into `res` when given):
+//   y = silu( GN(buf) * gamma + beta  [ * scale_sum + shift_sum ] )  [ + res ]
+// lane = column; a group's channels are split over the waves that own it.
+template <int L>
+__device__ void group_norm_pass(const Ctx &c, float *buf, float *res, int C, int groups, int gamma_off, int beta_off,
+                                const float *ss /* [2C][S] or null */, int S) {
+  float *red1 = c.lds + kMiscRed1, *red2 = c.lds + kMiscRed2;
+  const int n = c.lane, s = n / L;
+  const int cpg = C / groups;            // channels per group
+  const int wpg = kWaves / groups;       // waves that share one group
+  const int awpg = cpg < wpg ? cpg : wpg;
+  const int rpw = cpg / awpg;            // rows per active wave
+  const int g = c.wave / wpg, sub = c.wave % wpg;
+  const bool active = g < groups && sub < awpg;
+  const int row0 = g * cpg + sub * rpw;
+  constexpr int kMaxRows = 32;
+  float v[kMaxRows];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    v[i] = 0.f;
+    if (active && i < rpw) {
+      v[i] = buf[swz(row0 + i, n)];
+      sum += v[i];
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < L; off <<= 1) sum += __shfl_xor(sum, off, 64);
+  red1[c.wave * kCols + n] = sum;
+  __syncthreads();
+  const float cnt = (float)(cpg * L);
+  float tot = 0.f;
+  for (int q = 0; q < awpg; ++q) tot += red1[(g * wpg + q) * kCols + n];
+  const float mean = tot / cnt;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i)
+    if (active && i < rpw) {
+      const float d = v[i] - mean;
+      sq += d * d;
+    }
+#pragma unroll
+  for (int off = 1; off < L; off <<= 1) sq += __shfl_xor(sq, off, 64);
+  red2[c.wave * kCols + n] = sq;
+  __syncthreads();
+  float vt = 0.f;
+  for (int q = 0; q < awpg; ++q) vt += red2[(g * wpg + q) * kCols + n];
+  const float rstd = 1.0f / sqrtf(vt / cnt + 1e-5f);
+  const float *gamma = c.w + gamma_off, *beta = c.w + beta_off;
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i)
+    if (active && i < rpw) {
+      const int row = row0 + i;
+      float y = (v[i] - mean) * rstd * gamma[row] + beta[row];
+      if (ss) y = y * ss[row * S + s] + ss[(C + row) * S + s];
+      y = silu(y);
+      if (res) {
+        const int a = swz(row, n);
+        res[a] = res[a] + y;
+      } else {
+        buf[swz(row, n)] = y;
+      }
+    }
+  __syncthreads();
+}
+
+// ----------------------------------------------------------- LayerNorm ----
+// dst = LN_channels(src) * g  (+ res accumulated in place when res != null)
+__device__ void layer_norm_pass(const Ctx &c, const float *src, float *dst, float *res, int C, int g_off) {
+  float *red1 = c.lds + kMiscRed1, *red2 = c.lds + kMiscRed2;
+  const int n = c.lane;
+  constexpr int kMaxRows = 32;
+  float v[kMaxRows];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    const int row = c.wave + i * kWaves;
+    v[i] = 0.f;
+    if (row < C) {
+      v[i] = src[swz(row, n)];
+      sum += v[i];
+    }
+  }
+  red1[c.wave * kCols + n] = sum;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < kWaves; ++q) tot += red1[q * kCols + n];
+  const float mean = tot / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    const int row = c.wave + i * kWaves;
+    if (row < C) {
+      const float d = v[i] - mean;
+      sq += d * d;
+    }
+  }
+  red2[c.wave * kCols + n] = sq;
+  __syncthreads();
+  float vt = 0.f;
+#pragma unroll
+  for (int q = 0; q < kWaves; ++q) vt += red2[q * kCols + n];
+  const float rstd = 1.0f / sqrtf(vt / (float)C + 1e-5f);
+  const float *g = c.w + g_off;
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    const int row = c.wave + i * kWaves;
+    if (row < C) {
+      const float y = (v[i] - mean) * rstd * g[row];
+      const int a = swz(row, n);
+      if (res) res[a] = res[a] + y;
+      else dst[a] = y;
+    }
+  }
+  __syncthreads();
+}
+
+// -------------------------------------------------- linear attention -------
+// qkv: [192][64] = q(2 heads x 32) | k | v for one head pair; writes 64 rows of o.
+// Wave w: head hl = w >> 2 of the pair, output rows e in [8 (w & 3), +8).
+template <int L>
+__device__ void attention_pair(const Ctx &c, const float *qkv, float *o_rows) {
+  const int n = c.lane, sbase = n & ~(L - 1);
+  const int hl = c.wave >> 2, e0 = 8 * (c.wave & 3);
+  const int qrow0 = hl * kDimHead, krow0 = 64 + hl * kDimHead, vrow0 = 128 + hl * kDimHead;
+  // softmax of q over d for this column
+  float qmax = -3.0e38f;
+  for (int d = 0; d < kDimHead; ++d) qmax = fmaxf(qmax, qkv[swz(qrow0 + d, n)]);
+  float qsum = 0.f;
+  for (int d = 0; d < kDimHead; ++d) qsum += fast_exp(qkv[swz(qrow0 + d, n)] - qmax);
+  const float qscale = 0.17677669529663687f / qsum;  // dim_head ** -0.5 / sum
+  // A[n'] = sum_d softmax_n(k)[d, n'] * softmax_d(q)[d, n] * scale
+  float A[L];
+#pragma unroll
+  for (int i = 0; i < L; ++i) A[i] = 0.f;
+  for (int d = 0; d < kDimHead; ++d) {
+    const float qd = fast_exp(qkv[swz(qrow0 + d, n)] - qmax) * qscale;
+    float kv[L];
+    float kmax = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      kv[i] = qkv[swz(krow0 + d, sbase + i)];
+      kmax = fmaxf(kmax, kv[i]);
+    }
+    float ksum = 0.f;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      kv[i] = fast_exp(kv[i] - kmax);
+      ksum += kv[i];
+    }
+    const float f = qd / ksum;
+#pragma unroll
+    for (int i = 0; i < L; ++i) A[i] += kv[i] * f;
+  }
+  // out[e, n] = sum_n' v[e, n'] * A[n']
+  for (int e = e0; e < e0 + 8; ++e) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < L; ++i) acc += qkv[swz(vrow0 + e, sbase + i)] * A[i];
+    o_rows[swz(hl * kDimHead + e, n)] = acc;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------- the network ----
+struct RunArgs {
+  gldm_r1d_desc d;
+  const float *weights;
+  const float *temb;      // [T][E] or null
+  const float *cemb;      // [n_cond][R][E]
+  int samples_per_cond;
+  const float *x_in;      // denoise: [n][L]; decode: z_h [n][D]
+  int n_samples;
+  const int32_t *timesteps;
+  const int32_t *sample_t;
+  int n_steps;
+  int sched_kind, clip_sample;
+  const float *sched_coef;
+  const float *step_noise;
+  float *out0;            // denoise: x_out [n][L]; decode: tmrp [n][6]
+  float *out1;            // decode: logit [n]
+  float *ws;              // [tiles][ss_rows][S]
+};
+
+template <int L>
+__device__ void resnet_block(const Ctx &c, const gldm_r1d_desc &d, const gldm_r1d_resblock &rb, int C,
+                             const float *ss_tile, int S) {
+  float *X = c.lds + kBufX, *H = c.lds + kBufH;
+  conv_gemm<L>(c, rb.c1_w, rb.c1_b, X, C, 3, H, C, false);
+  group_norm_pass<L>(c, H, nullptr, C, d.groups, rb.n1_w, rb.n1_b, ss_tile ? ss_tile + (size_t)rb.ss_row * S : nullptr, S);
+  conv_gemm<L>(c, rb.c2_w, rb.c2_b, H, C, 3, H, C, true);
+  group_norm_pass<L>(c, H, X, C, d.groups, rb.n2_w, rb.n2_b, nullptr, S);
+}
+
+template <int L>
+__device__ void attention_block(const Ctx &c, const gldm_r1d_level &lv, int C) {
+  float *X = c.lds + kBufX, *Y = c.lds + kBufY, *O = c.lds + kBufO, *QKV = c.lds + kBufQKV;
+  layer_norm_pass(c, X, Y, nullptr, C, lv.ln_g);
+  for (int p = 0; p < 2; ++p) {
+    conv_gemm<L>(c, lv.qkv_w[p], -1, Y, C, 1, QKV, 192, false);
+    attention_pair<L>(c, QKV, O + p * 64 * kCols);
+  }
+  conv_gemm<L>(c, lv.out_w, lv.out_b, O, kHidden, 1, Y, C, false);
+  layer_norm_pass(c, Y, nullptr, X, C, lv.ln2_g);
+}
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ float scheduler_update(int kind, int clip, const float *cf, float x, float eps, float noise) {
+  float x0 = (x - cf[0] * eps) / cf[1];
+  if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+  if (kind == GLDM_SCHED_DDIM) {
+    const float a = cf[2] * x0;
+    const float b = cf[3] * eps;
+    return a + b;
+  }
+  const float a = cf[4] * x0;
+  const float b = cf[5] * x;
+  float prev = a + b;
+  if (cf[7] != 0.f) {
+    const float nz = cf[6] * noise;
+    prev = prev + nz;
+  }
+  return prev;
+}
+#pragma clang fp contract(fast)
+
+template <int L>
+__global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
+  extern __shared__ float lds[];
+  const gldm_r1d_desc &d = a.d;
+  constexpr int S = kCols / L;
+  Ctx c{a.weights, lds, (int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63};
+  const int tile = blockIdx.x;
+  const int samp0 = tile * S;
+  const int E = d.emb_dim, R = d.cond_rows;
+  float *lat = lds + kMiscLat, *epsr = lds + kMiscEps, *G = lds + kMiscG;
+  float *X = lds + kBufX;
+  float *ss_tile = a.ws + (size_t)tile * d.ss_rows * S;
+  const bool decode = d.latent_dim > 0;
+
+  // ---- latent row for this tile
+  if (c.tid < kCols) {
+    const int s = c.tid / L, l = c.tid % L;
+    const int gi = min(samp0 + s, a.n_samples - 1);
+    float v;
+    if (decode) {
+      const float *wi = a.weights + d.in_w + l * d.latent_dim;
+      v = a.weights[d.in_b + l];
+      for (int q = 0; q < d.latent_dim; ++q) v += wi[q] * a.x_in[(size_t)gi * d.latent_dim + q];
+    } else {
+      v = a.x_in[(size_t)gi * L + l];
+    }
+    lat[c.tid] = v;
+  }
+  __syncthreads();
+
+  for (int step = 0; step < a.n_steps; ++step) {
+    // ---- G[s][e] = sum_r silu(temb[t][e] + cemb[cond][r][e])
+    for (int i = c.tid; i < S * E; i += kThreads) {
+      const int s = i / E, e = i - s * E;
+      const int gi = min(samp0 + s, a.n_samples - 1);
+      const float *ce = a.cemb + ((size_t)(gi / a.samples_per_cond) * R) * E + e;
+      float te = 0.f;
+      if (a.temb) {
+        const int t = a.sample_t ? a.sample_t[gi] : a.timesteps[step];
+        te = a.temb[(size_t)t * E + e];
+      }
+      float g = 0.f;
+      for (int r = 0; r < R; ++r) g += silu(te + ce[r * E]);
+      G[s * E + e] = g;
+    }
+    __syncthreads();
+    // ---- scale/shift table for every ResnetBlock of this step
+    for (int i = c.tid; i < d.ss_rows * S; i += kThreads) {
+      const int row = i / S, s = i - row * S;
+      const float *wr = a.weights + d.ss_w + (size_t)row * E;
+      float acc = a.weights[d.ss_b + row];
+      for (int e = 0; e < E; ++e) acc += wr[e] * G[s * E + e];
+      ss_tile[i] = acc;
+    }
+    // ---- init conv (k = 7, one input channel)
+    const int C0 = d.dims[0];
+    for (int i = c.tid; i < C0 * kCols; i += kThreads) {
+      const int ch = i / kCols, n = i - ch * kCols;
+      const int l = n & (L - 1), base = n - l;
+      float acc = a.weights[d.init_b + ch];
+      const float *wk = a.weights + d.init_w + ch * 7;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const int p = l + q - 3;
+        if (p >= 0 && p < L) acc += wk[q] * lat[base + p];
+      }
+      X[swz(ch, n)] = acc;
+    }
+    __syncthreads();  // also publishes ss_tile (workgroup-scope: same CU)
+
+    int rbi = 0;
+    for (int lv = 0; lv < d.n_levels; ++lv) {
+      const int C = d.dims[lv], Cn = d.dims[lv + 1];
+      resnet_block<L>(c, d, d.rb[rbi++], C, ss_tile, S);
+      resnet_block<L>(c, d, d.rb[rbi++], C, ss_tile, S);
+      attention_block<L>(c, d.lv[lv], C);
+      conv_gemm<L>(c, d.lv[lv].down_w, d.lv[lv].down_b, X, C, 3, X, Cn, true);
+    }
+    const int CF = d.dims[d.n_levels];
+    resnet_block<L>(c, d, d.rb[rbi], CF, ss_tile, S);
+
+    // ---- final 1x1 conv to one channel: eps[n] = b + sum_c w[c] X[c][n]
+    {
+      float *red1 = lds + kMiscRed1;
+      float part = 0.f;
+      for (int row = c.wave; row < CF; row += kWaves) part += a.weights[d.final_w + row] * X[swz(row, c.lane)];
+      red1[c.wave * kCols + c.lane] = part;
+      __syncthreads();
+      if (c.tid < kCols) {
+        float e = a.weights[d.final_b];
+#pragma unroll
+        for (int q = 0; q < kWaves; ++q) e += red1[q * kCols + c.tid];
+        epsr[c.tid] = e;
+        if (!decode && a.sched_kind != GLDM_SCHED_NONE) {
+          const int s = c.tid / L, l = c.tid % L;
+          const int gi = min(samp0 + s, a.n_samples - 1);
+          const float *cf = a.sched_coef + (size_t)step * GLDM_SCHED_COEF_STRIDE;
+          float nz = 0.f;
+          if (a.sched_kind == GLDM_SCHED_DDPM && cf[7] != 0.f && a.step_noise)
+            nz = a.step_noise[((size_t)step * a.n_samples + gi) * L + l];
+          lat[c.tid] = scheduler_update(a.sched_kind, a.clip_sample, cf, lat[c.tid], e, nz);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- outputs
+  if (!decode) {
+    if (c.tid < kCols) {
+      const int s = c.tid / L, l = c.tid % L;
+      const int gi = samp0 + s;
+      if (gi < a.n_samples) a.out0[(size_t)gi * L + l] = a.sched_kind == GLDM_SCHED_NONE ? epsr[c.tid] : lat[c.tid];
+    }
+  } else {
+    // heads: rows 0..5 tmrp, row 6 class logit; input = the L-vector of each sample
+    const int nh = d.n_head;
+    if (c.tid < S * nh) {
+      const int s = c.tid / nh, r = c.tid - s * nh;
+      const int gi = samp0 + s;
+      if (gi < a.n_samples) {
+        const float *wr = a.weights + d.head_w + r * L;
+        float acc = a.weights[d.head_b + r];
+        for (int l = 0; l < L; ++l) acc += wr[l] * epsr[s * L + l];
+        if (r < 6) a.out0[(size_t)gi * 6 + r] = acc;
+        else a.out1[gi] = acc;
+      }
+    }
+  }
+}
+
+__global__ void cond_embed_kernel(const float *__restrict__ z, const float *__restrict__ w,
+                                  const float *__restrict__ b, int rows_total, int dc, int e, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows_total * e) return;
+  const int row = i / e, col = i - row * e;
+  const float *zr = z + (size_t)row * dc, *wr = w + (size_t)col * dc;
+  float acc = b[col];
+  for (int q = 0; q < dc; ++q) acc += wr[q] * zr[q];
+  out[i] = acc / (1.0f + expf(-acc));
+}
+
+#pragma clang fp contract(off)
+__global__ void pose_epilogue_kernel(const float *__restrict__ tmrp, const float *__restrict__ logit,
+                                     const float *__restrict__ mean, const float *__restrict__ stdv, int n, int gpc,
+                                     float *__restrict__ H, float *__restrict__ un, float *__restrict__ conf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cl = i / gpc;
+  float v[6];
+  for (int q = 0; q < 6; ++q) {
+    v[q] = tmrp[(size_t)i * 6 + q] * stdv[cl * 6 + q] + mean[cl * 6 + q];
+    un[(size_t)i * 6 + q] = v[q];
+  }
+  // rotations.py:218-252 (mrp -> quat) and :171-215 (quat -> rotmat, SciPy convention)
+  const float magsq = v[3] * v[3] + v[4] * v[4] + v[5] * v[5];
+  const float den = 1.0f + magsq;
+  const float x = (2.0f * v[3]) / den, y = (2.0f * v[4]) / den, z = (2.0f * v[5]) / den;
+  const float w = (1.0f - magsq) / den;
+  const float x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+  const float xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+  float *h = H + (size_t)i * 16;
+  h[0] = x2 - y2 - z2 + w2;  h[1] = 2.0f * (xy - zw);     h[2] = 2.0f * (xz + yw);      h[3] = v[0];
+  h[4] = 2.0f * (xy + zw);   h[5] = -x2 + y2 - z2 + w2;   h[6] = 2.0f * (yz - xw);      h[7] = v[1];
+  h[8] = 2.0f * (xz - yw);   h[9] = 2.0f * (yz + xw);     h[10] = -x2 - y2 + z2 + w2;   h[11] = v[2];
+  h[12] = 0.f; h[13] = 0.f; h[14] = 0.f; h[15] = 1.0f;
+  if (conf) conf[i] = 1.0f / (1.0f + expf(-logit[i]));
+}
+#pragma clang fp contract(fast)
+
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int validate(const gldm_r1d_desc *d) {
+  if (!d) return GLDM_ERR_INVALID_ARG;
+  if (d->seq_len != 4 && d->seq_len != 16) return GLDM_ERR_UNSUPPORTED;
+  if (d->n_levels < 1 || d->n_levels > GLDM_R1D_MAX_LEVELS) return GLDM_ERR_UNSUPPORTED;
+  const int S = kCols / d->seq_len;
+  if (d->emb_dim <= 0 || S * d->emb_dim > 320) return GLDM_ERR_UNSUPPORTED;
+  if (d->groups <= 0 || kWaves % d->groups != 0) return GLDM_ERR_UNSUPPORTED;
+  for (int i = 0; i <= d->n_levels; ++i) {
+    const int C = d->dims[i];
+    if (C < d->groups || C > kMaxC || C % 4 != 0 || C % d->groups != 0) return GLDM_ERR_UNSUPPORTED;
+    const int cpg = C / d->groups, wpg = kWaves / d->groups;
+    const int awpg = cpg < wpg ? cpg : wpg;
+    if (cpg % awpg != 0 || cpg / awpg > 32) return GLDM_ERR_UNSUPPORTED;
+    if (i < d->n_levels && C > 128) return GLDM_ERR_UNSUPPORTED;  // attention levels keep 4 regions in LDS
+  }
+  (void)pow2;
+  return GLDM_OK;
+}
+
+int launch_r1d(const RunArgs &a, hipStream_t s) {
+  const int L = a.d.seq_len, S = kCols / L;
+  const int tiles = (a.n_samples + S - 1) / S;
+  const size_t lds_bytes = (size_t)kLdsFloats * sizeof(float);
+  if (L == 4) {
+    static bool attr4 = false;
+    if (!attr4) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&r1d_kernel<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      attr4 = true;
+    }
+    hipLaunchKernelGGL(r1d_kernel<4>, dim3(tiles), dim3(kThreads), lds_bytes, s, a);
+  } else {
+    static bool attr16 = false;
+    if (!attr16) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&r1d_kernel<16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      attr16 = true;
+    }
+    hipLaunchKernelGGL(r1d_kernel<16>, dim3(tiles), dim3(kThreads), lds_bytes, s, a);
+  }
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+}  // namespace
+
+GLDM_API int gldm_r1d_cond_embed(const float *z_cond, const float *w, const float *b, int n_cond, int rows, int dc,
+                                 int e, float *cemb, gldm_stream_t stream) {
+  if (!z_cond || !w || !b || !cemb || n_cond <= 0 || rows <= 0 || dc <= 0 || e <= 0) return GLDM_ERR_INVALID_ARG;
+  const int total = n_cond * rows * e;
+  hipLaunchKernelGGL(cond_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     z_cond, w, b, n_cond * rows, dc, e, cemb);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples) {
+  if (validate(desc) != GLDM_OK || n_samples <= 0) return -1;
+  const int S = kCols / desc->seq_len;
+  const long long tiles = (n_samples + S - 1) / S;
+  return tiles * desc->ss_rows * S * (long long)sizeof(float);
+}
+
+GLDM_API int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,
+                          int samples_per_cond, const float *x_in, int n_samples, const int32_t *timesteps,
+                          const int32_t *sample_t, int n_steps, int sched_kind, int clip_sample,
+                          const float *sched_coef, const float *step_noise, float *x_out, void *workspace,
+                          gldm_stream_t stream) {
+  int st = validate(desc);
+  if (st != GLDM_OK) return st;
+  if (!weights || !cemb || !x_in || !x_out || !workspace || n_samples <= 0 || n_steps <= 0 || samples_per_cond <= 0)
+    return GLDM_ERR_INVALID_ARG;
+  if (desc->latent_dim != 0) return GLDM_ERR_INVALID_ARG;
+  if (temb && !timesteps && !sample_t) return GLDM_ERR_INVALID_ARG;
+  if (sched_kind != GLDM_SCHED_NONE && !sched_coef) return GLDM_ERR_INVALID_ARG;
+  if (sched_kind == GLDM_SCHED_NONE && n_steps != 1) return GLDM_ERR_INVALID_ARG;
+  RunArgs a{};
+  a.d = *desc;
+  a.weights = weights; a.temb = temb; a.cemb = cemb; a.samples_per_cond = samples_per_cond;
+  a.x_in = x_in; a.n_samples = n_samples; a.timesteps = timesteps; a.sample_t = sample_t; a.n_steps = n_steps;
+  a.sched_kind = sched_kind; a.clip_sample = clip_sample; a.sched_coef = sched_coef; a.step_noise = step_noise;
+  a.out0 = x_out; a.out1 = nullptr; a.ws = reinterpret_cast<float *>(workspace);
+  return launch_r1d(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+GLDM_API int gldm_decode(const gldm_r1d_desc *desc, const float *weights, const float *cemb, int samples_per_cond,
+                         const float *z_h, int n_samples, float *tmrp, float *logit, void *workspace,
+                         gldm_stream_t stream) {
+  int st = validate(desc);
+  if (st != GLDM_OK) return st;
+  if (!weights || !cemb || !z_h || !tmrp || !logit || !workspace || n_samples <= 0 || samples_per_cond <= 0)
+    return GLDM_ERR_INVALID_ARG;
+  if (desc->latent_dim <= 0 || desc->n_head != 7) return GLDM_ERR_INVALID_ARG;
+  RunArgs a{};
+  a.d = *desc;
+  a.weights = weights; a.temb = nullptr; a.cemb = cemb; a.samples_per_cond = samples_per_cond;
+  a.x_in = z_h; a.n_samples = n_samples; a.n_steps = 1; a.sched_kind = GLDM_SCHED_NONE;
+  a.out0 = tmrp; a.out1 = logit; a.ws = reinterpret_cast<float *>(workspace);
+  return launch_r1d(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+GLDM_API int gldm_pose_epilogue(const float *tmrp, const float *logit, const float *grasp_mean,
+                                const float *grasp_std, int n, int grasps_per_cloud, float *H, float *tmrp_unnorm,
+                                float *confidence, gldm_stream_t stream) {
+  if (!tmrp || !grasp_mean || !grasp_std || !H || !tmrp_unnorm || n <= 0 || grasps_per_cloud <= 0)
+    return GLDM_ERR_INVALID_ARG;
+  if (confidence && !logit) return GLDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(pose_epilogue_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     tmrp, logit, grasp_mean, grasp_std, n, grasps_per_cloud, H, tmrp_unnorm, confidence);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}

@@ -1,0 +1,85 @@
+"""Device-side handle of one packed 1-D ResNet (denoiser or pose decoder):
+owns the packed weight buffer on the GPU and calls the fused HIP engine through
+the C ABI (gldm_r1d_cond_embed / gldm_denoise / gldm_decode)."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from .r1d_pack import SCHED_DDIM, SCHED_DDPM, SCHED_NONE, SCHED_COEF_STRIDE, pack_resnet1d  # noqa: F401
+
+
+class R1dEngine:
+    def __init__(self, packed, device):
+        self.device = torch.device(device)
+        self.desc = packed["desc"]
+        self.weights = packed["weights"].to(self.device)
+        self.temb = packed["temb"].to(self.device) if packed["temb"] is not None else None
+        self.cond_w = packed["cond_w"].to(self.device)
+        self.cond_b = packed["cond_b"].to(self.device)
+        self.seq_len = int(self.desc.seq_len)
+        self._ws = None
+
+    # -- helpers
+    def _desc_ptr(self):
+        return ctypes.cast(ctypes.pointer(self.desc), ctypes.c_void_p)
+
+    def _workspace(self, n):
+        need = L.lib().gldm_r1d_workspace_bytes(self._desc_ptr(), int(n))
+        if need < 0:
+            raise L.GldmError("gldm_r1d_workspace_bytes: this ResNet1D configuration is not supported by the HIP engine")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def cond_embed(self, z_cond):
+        """input_emb_layers (Linear + SiLU) on [n, R, Dc] (or [n, Dc]) -> [n, R, E]."""
+        z = z_cond if z_cond.ndim == 3 else z_cond.unsqueeze(1)
+        z = z.contiguous().float()
+        n, r, dc = z.shape
+        e = self.cond_w.shape[0]
+        out = torch.empty((n, r, e), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.call("gldm_r1d_cond_embed", L.ptr(z), L.ptr(self.cond_w), L.ptr(self.cond_b), n, r, dc, e, L.ptr(out),
+                   L.current_stream(self.device))
+        return out
+
+    def denoise(self, x_in, cemb, samples_per_cond, timesteps=None, sample_t=None, sched_kind=SCHED_NONE,
+                clip_sample=True, coef=None, step_noise=None):
+        """x_in [n, 1, L] -> x after all steps (or eps when sched_kind == NONE)."""
+        n = x_in.shape[0]
+        x_in = x_in.contiguous().float()
+        out = torch.empty_like(x_in)
+        n_steps = 1 if timesteps is None else int(timesteps.numel())
+        ws = self._workspace(n)
+        with torch.cuda.device(self.device):
+            L.call("gldm_denoise", self._desc_ptr(), L.ptr(self.weights), L.ptr(self.temb), L.ptr(cemb),
+                   int(samples_per_cond), L.ptr(x_in), n, L.ptr(timesteps), L.ptr(sample_t), n_steps, int(sched_kind),
+                   1 if clip_sample else 0, L.ptr(coef), L.ptr(step_noise), L.ptr(out), L.ptr(ws),
+                   L.current_stream(self.device))
+        return out
+
+    def decode(self, z_h, cemb, samples_per_cond):
+        n = z_h.shape[0]
+        z_h = z_h.contiguous().float()
+        tmrp = torch.empty((n, 6), dtype=torch.float32, device=self.device)
+        logit = torch.empty((n, 1), dtype=torch.float32, device=self.device)
+        ws = self._workspace(n)
+        with torch.cuda.device(self.device):
+            L.call("gldm_decode", self._desc_ptr(), L.ptr(self.weights), L.ptr(cemb), int(samples_per_cond), L.ptr(z_h),
+                   n, L.ptr(tmrp), L.ptr(logit), L.ptr(ws), L.current_stream(self.device))
+        return tmrp, logit
+
+
+def pose_epilogue(tmrp, logit, grasp_mean, grasp_std, grasps_per_cloud):
+    """unnormalise + tmrp_to_H + sigmoid in one launch (tools/inference.py:628-647)."""
+    n = tmrp.shape[0]
+    dev = tmrp.device
+    H = torch.empty((n, 4, 4), dtype=torch.float32, device=dev)
+    un = torch.empty((n, 6), dtype=torch.float32, device=dev)
+    conf = torch.empty((n, 1), dtype=torch.float32, device=dev) if logit is not None else None
+    with torch.cuda.device(dev):
+        L.call("gldm_pose_epilogue", L.ptr(tmrp.contiguous()), L.ptr(logit.contiguous()) if logit is not None else None,
+               L.ptr(grasp_mean.contiguous().float()), L.ptr(grasp_std.contiguous().float()), n, int(grasps_per_cloud),
+               L.ptr(H), L.ptr(un), L.ptr(conf), L.current_stream(dev))
+    return H, un, conf

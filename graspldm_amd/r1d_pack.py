@@ -1,0 +1,194 @@
+"""Host-side weight preparation for the fused 1-D ResNet engine
+(csrc/resnet1d.hip, C ABI `gldm_r1d_desc` in include/gldm.h).
+
+Runs once at model-load time (step-invariant work hoisted out of the denoise
+loop): weight standardisation of every `Block.proj` (resnets.py:85-101, fp32
+eps 1e-5), re-layout of every conv / 1x1 weight into v_mfma_f32_16x16x4_f32
+A-fragment order, the combined scale/shift bias, and the time_mlp table
+[T, E] (resnets.py:44-56,517-522), evaluated with the same torch CPU ops the
+reference module uses so that large-argument sin/cos are identical.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn.functional as F
+
+MAX_LEVELS = 6
+MAX_RESBLOCKS = 2 * MAX_LEVELS + 1
+SCHED_NONE, SCHED_DDIM, SCHED_DDPM = 0, 1, 2
+SCHED_COEF_STRIDE = 8
+
+
+class R1dResblock(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("c1_w", "c1_b", "n1_w", "n1_b", "c2_w", "c2_b", "n2_w", "n2_b", "ss_row")]
+
+
+class R1dLevel(ctypes.Structure):
+    _fields_ = [("ln_g", ctypes.c_int32), ("qkv_w", ctypes.c_int32 * 2), ("out_w", ctypes.c_int32),
+                ("out_b", ctypes.c_int32), ("ln2_g", ctypes.c_int32), ("down_w", ctypes.c_int32),
+                ("down_b", ctypes.c_int32)]
+
+
+class R1dDesc(ctypes.Structure):
+    """Mirror of `gldm_r1d_desc` (include/gldm.h)."""
+    _fields_ = [("seq_len", ctypes.c_int32), ("n_levels", ctypes.c_int32),
+                ("dims", ctypes.c_int32 * (MAX_LEVELS + 1)),
+                ("emb_dim", ctypes.c_int32), ("cond_rows", ctypes.c_int32), ("groups", ctypes.c_int32),
+                ("init_w", ctypes.c_int32), ("init_b", ctypes.c_int32),
+                ("ss_w", ctypes.c_int32), ("ss_b", ctypes.c_int32), ("ss_rows", ctypes.c_int32),
+                ("rb", R1dResblock * MAX_RESBLOCKS), ("lv", R1dLevel * MAX_LEVELS),
+                ("final_w", ctypes.c_int32), ("final_b", ctypes.c_int32),
+                ("latent_dim", ctypes.c_int32), ("in_w", ctypes.c_int32), ("in_b", ctypes.c_int32),
+                ("head_w", ctypes.c_int32), ("head_b", ctypes.c_int32), ("n_head", ctypes.c_int32)]
+
+
+def mfma_a_fragments(w2d):
+    """[M, K] -> flat buffer in fragment order [M/16][K/16][lane 64][4]: lane l of
+    k-step j inside block kb holds W[16 mt + (l & 15)][16 kb + 4 j + (l >> 4)]."""
+    m, k = w2d.shape
+    mt, kb = (m + 15) // 16, (k + 15) // 16
+    wp = torch.zeros(mt * 16, kb * 16, dtype=torch.float32)
+    wp[:m, :k] = w2d
+    wp = wp.view(mt, 16, kb, 4, 4)            # (mt, i, kb, j, kq):  k = 16 kb + 4 j + kq
+    return wp.permute(0, 2, 4, 1, 3).contiguous().reshape(-1)   # (mt, kb, kq, i, j): lane = 16 kq + i
+
+
+def conv_as_gemm(w):
+    """Conv1d weight [Cout, Cin, taps] -> [Cout, taps*Cin] with k = tap*Cin + ci."""
+    return w.permute(0, 2, 1).reshape(w.shape[0], -1)
+
+
+def weight_standardize(w):
+    mean = w.mean(dim=(1, 2), keepdim=True)
+    var = w.var(dim=(1, 2), unbiased=False, keepdim=True)
+    return (w - mean) * (var + 1e-5).rsqrt()
+
+
+class _Buf:
+    def __init__(self):
+        self.parts, self.n = [], 0
+
+    def add(self, t):
+        t = t.detach().to(torch.float32).reshape(-1)
+        off = self.n
+        pad = (-t.numel()) % 4          # keep every section 16-byte aligned
+        self.parts.append(t)
+        if pad:
+            self.parts.append(torch.zeros(pad))
+        self.n += t.numel() + pad
+        return off
+
+    def tensor(self):
+        return torch.cat(self.parts) if self.parts else torch.zeros(0)
+
+
+def time_embedding_table(sd, p, num_steps):
+    """time_mlp evaluated for t = 0..T-1 exactly like the module (int64 time,
+    f = ((t*w)*2)*pi in f32, cat(t, sin, cos), Linear, GELU(erf), Linear)."""
+    t = torch.arange(num_steps, dtype=torch.long).reshape(-1, 1)
+    freqs = t * sd[p + "time_mlp.0.weights"].reshape(1, -1) * 2 * math.pi
+    four = torch.cat((t, freqs.sin(), freqs.cos()), dim=-1)
+    h = F.linear(four, sd[p + "time_mlp.1.weight"], sd[p + "time_mlp.1.bias"])
+    return F.linear(F.gelu(h), sd[p + "time_mlp.3.weight"], sd[p + "time_mlp.3.bias"]).contiguous()
+
+
+def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=None):
+    """sd: flat state dict (CPU f32), p: prefix of the ResNet1D / TimeConditionedResNet1D.
+    decoder: None or dict(in_w, in_b, tmrp_w, tmrp_b, cls_w, cls_b) for the pose decoder.
+    Returns dict(desc=R1dDesc, weights=f32 tensor, temb=[T,E] or None,
+                 cond_w=[E,Dc], cond_b=[E])."""
+    sd = {k: v.detach().float().cpu() for k, v in sd.items() if k.startswith(p)}
+    d = R1dDesc()
+    buf = _Buf()
+    init_w = sd[p + "init_conv.weight"]
+    if init_w.shape[1] != 1 or init_w.shape[2] != 7:
+        raise ValueError("init_conv must be Conv1d(1 -> C0, k=7) (self-conditioning is off on the hot path)")
+    n_levels = 0
+    while (p + f"blocks.{n_levels}.3.weight") in sd:
+        n_levels += 1
+    if n_levels > MAX_LEVELS:
+        raise ValueError("too many levels")
+    dims = [init_w.shape[0]] + [sd[p + f"blocks.{i}.3.weight"].shape[0] for i in range(n_levels)]
+    emb = sd[p + "input_emb_layers.0.weight"].shape[0]
+    d.n_levels, d.emb_dim, d.cond_rows, d.groups = n_levels, emb, cond_rows, groups
+    for i, c in enumerate(dims):
+        d.dims[i] = c
+    d.init_w = buf.add(init_w.reshape(dims[0], 7))
+    d.init_b = buf.add(sd[p + "init_conv.bias"])
+
+    ss_w, ss_b, ss_row = [], [], 0
+
+    def resblock(q, c, slot):
+        nonlocal ss_row
+        rb = d.rb[slot]
+        mw, mb = sd[q + "mlp.1.weight"], sd[q + "mlp.1.bias"]          # [2C, E], [2C]
+        ss_w.append(mw)
+        comb = cond_rows * mb
+        comb[:c] = comb[:c] + cond_rows                                 # sum_r (scale_r + 1)
+        ss_b.append(comb)
+        rb.ss_row = ss_row
+        ss_row += 2 * c
+        rb.c1_w = buf.add(mfma_a_fragments(conv_as_gemm(weight_standardize(sd[q + "block1.proj.weight"]))))
+        rb.c1_b = buf.add(sd[q + "block1.proj.bias"])
+        rb.n1_w = buf.add(sd[q + "block1.norm.weight"])
+        rb.n1_b = buf.add(sd[q + "block1.norm.bias"])
+        rb.c2_w = buf.add(mfma_a_fragments(conv_as_gemm(weight_standardize(sd[q + "block2.proj.weight"]))))
+        rb.c2_b = buf.add(sd[q + "block2.proj.bias"])
+        rb.n2_w = buf.add(sd[q + "block2.norm.weight"])
+        rb.n2_b = buf.add(sd[q + "block2.norm.bias"])
+        if (q + "res_conv.weight") in sd:
+            raise ValueError("res_conv (dim != dim_out) does not occur in ResNet1D")
+
+    slot = 0
+    for i in range(n_levels):
+        c = dims[i]
+        q = p + f"blocks.{i}."
+        resblock(q + "0.", c, slot)
+        resblock(q + "1.", c, slot + 1)
+        slot += 2
+        lv = d.lv[i]
+        lv.ln_g = buf.add(sd[q + "2.fn.norm.g"])
+        wqkv = sd[q + "2.fn.fn.to_qkv.weight"][:, :, 0]                 # [384, C]
+        hid = wqkv.shape[0] // 3
+        if hid != 128:
+            raise ValueError("LinearAttention with heads=4, dim_head=32 expected")
+        for pr in range(2):
+            rows = torch.cat([wqkv[o + 64 * pr:o + 64 * pr + 64] for o in (0, hid, 2 * hid)])
+            lv.qkv_w[pr] = buf.add(mfma_a_fragments(rows))
+        lv.out_w = buf.add(mfma_a_fragments(sd[q + "2.fn.fn.to_out.0.weight"][:, :, 0]))
+        lv.out_b = buf.add(sd[q + "2.fn.fn.to_out.0.bias"])
+        lv.ln2_g = buf.add(sd[q + "2.fn.fn.to_out.1.g"])
+        lv.down_w = buf.add(mfma_a_fragments(conv_as_gemm(sd[q + "3.weight"])))
+        lv.down_b = buf.add(sd[q + "3.bias"])
+    resblock(p + "final_res_block.", dims[-1], slot)
+    fw = sd[p + "final_conv.weight"]
+    if fw.shape[0] != 1:
+        raise ValueError("final_conv with one output channel expected (learned variance is off)")
+    d.final_w = buf.add(fw.reshape(-1))
+    d.final_b = buf.add(sd[p + "final_conv.bias"])
+    d.ss_w = buf.add(torch.cat(ss_w))
+    d.ss_b = buf.add(torch.cat(ss_b))
+    d.ss_rows = ss_row
+
+    if decoder is not None:
+        if decoder["in_w"].shape[0] != seq_len:
+            raise ValueError("in_layer must map the latent to seq_len features")
+        d.latent_dim = decoder["in_w"].shape[1]
+        d.in_w = buf.add(decoder["in_w"])
+        d.in_b = buf.add(decoder["in_b"])
+        d.head_w = buf.add(torch.cat([decoder["tmrp_w"], decoder["cls_w"]]))
+        d.head_b = buf.add(torch.cat([decoder["tmrp_b"], decoder["cls_b"]]))
+        d.n_head = 7
+    else:
+        d.latent_dim = 0
+    d.seq_len = seq_len
+    temb = None
+    if (p + "time_mlp.1.weight") in sd:
+        if num_steps is None:
+            raise ValueError("num_steps needed for the time-embedding table")
+        temb = time_embedding_table(sd, p, num_steps)
+    return dict(desc=d, weights=buf.tensor(), temb=temb,
+                cond_w=sd[p + "input_emb_layers.0.weight"].contiguous(),
+                cond_b=sd[p + "input_emb_layers.0.bias"].contiguous())

@@ -110,6 +110,99 @@ int gldm_sa_group(const float *points /*[b,3,n]*/, const float *centers /*[b,3,m
                   int b, int c, int n, int m, float radius, int u,
                   float *out /*[b,3+c,m,u]*/, int32_t *idx_out, gldm_stream_t stream);
 
+
+/* ------------------------------------- 1-D ResNet engine (denoiser, decoder) */
+
+/* Architecture descriptor of one ResNet1D / TimeConditionedResNet1D instance
+ * (ref: grasp_ldm/models/modules/resnets.py:263-424,427-616) plus offsets, in
+ * floats, into ONE packed weight buffer prepared on the host at load time
+ * (graspldm_amd/r1d_pack.py): weight-standardised conv weights, MFMA
+ * A-fragment order, combined scale/shift biases.  Plain C struct, filled by the
+ * host side; the kernels never parse checkpoints. */
+#define GLDM_R1D_MAX_LEVELS 6
+#define GLDM_R1D_MAX_RESBLOCKS (2 * GLDM_R1D_MAX_LEVELS + 1)
+
+typedef struct gldm_r1d_resblock {
+  int32_t c1_w, c1_b;   /* block1.proj  (packed A fragments), bias [C]            */
+  int32_t n1_w, n1_b;   /* block1.norm  gamma/beta [C]                            */
+  int32_t c2_w, c2_b;   /* block2.proj                                            */
+  int32_t n2_w, n2_b;   /* block2.norm                                            */
+  int32_t ss_row;       /* first row of this block in the scale/shift table       */
+} gldm_r1d_resblock;
+
+typedef struct gldm_r1d_level {
+  int32_t ln_g;         /* PreNorm LayerNorm gain [C]                             */
+  int32_t qkv_w[2];     /* to_qkv rows for heads {0,1} and {2,3}: 192 x C packed  */
+  int32_t out_w, out_b; /* to_out.0 [C x 128] packed, bias [C]                    */
+  int32_t ln2_g;        /* to_out.1 LayerNorm gain [C]                            */
+  int32_t down_w, down_b; /* Conv1d(C -> C', k=3) packed, bias [C']               */
+} gldm_r1d_level;
+
+typedef struct gldm_r1d_desc {
+  int32_t seq_len;      /* L: 4 (latent denoiser) or 16 (pose decoder)            */
+  int32_t n_levels;
+  int32_t dims[GLDM_R1D_MAX_LEVELS + 1]; /* channel widths; dims[0] = init_dim    */
+  int32_t emb_dim;      /* E = 4 * dim                                            */
+  int32_t cond_rows;    /* R: rows of the conditioning latent (3), 1 if 2-D       */
+  int32_t groups;       /* GroupNorm groups (resnet_block_groups)                 */
+  int32_t init_w, init_b; /* init_conv [C0][7], [C0]                              */
+  int32_t ss_w, ss_b;   /* all ResnetBlock.mlp.1 stacked: [ss_rows][E]; combined
+                           bias R*b (+R on scale rows): [ss_rows]                 */
+  int32_t ss_rows;
+  gldm_r1d_resblock rb[GLDM_R1D_MAX_RESBLOCKS]; /* 2 per level, then final        */
+  gldm_r1d_level lv[GLDM_R1D_MAX_LEVELS];
+  int32_t final_w, final_b; /* final_conv [dims[n_levels]], [1]                   */
+  /* decoder only (ref: grasp_ldm/models/grasp_vae.py:358-436) */
+  int32_t latent_dim;   /* D of z_h; 0 for the denoiser                           */
+  int32_t in_w, in_b;   /* in_layer [L][D], [L]                                   */
+  int32_t head_w, head_b; /* rows tmrp(6) then class_logits(1): [7][L], [7]       */
+  int32_t n_head;       /* 7                                                      */
+} gldm_r1d_desc;
+
+enum gldm_sched_kind { GLDM_SCHED_NONE = 0, GLDM_SCHED_DDIM = 1, GLDM_SCHED_DDPM = 2 };
+#define GLDM_SCHED_COEF_STRIDE 8
+/* per-step coefficient row (f32, computed on the host exactly like the
+ * scheduler library does on 0-dim f32 tensors):
+ *   [0] sqrt(1-abar_t) [1] sqrt(abar_t)
+ *   DDIM: [2] sqrt(abar_prev) [3] sqrt(1-abar_prev-sigma^2)
+ *   DDPM: [4] coef_x0 [5] coef_xt [6] sqrt(variance) [7] 1 if noise is added (t>0) */
+
+/* ref: resnets.py:484-494,587-594 (input_emb_layers = Linear + SiLU on z_cond).
+ * cemb[i,r,:] = silu(W z_cond[i,r,:] + b). */
+int gldm_r1d_cond_embed(const float *z_cond /*[n_cond,R,Dc]*/, const float *w /*[E,Dc]*/, const float *b /*[E]*/,
+                        int n_cond, int rows, int dc, int e, float *cemb /*[n_cond,R,E]*/, gldm_stream_t stream);
+
+/* Bytes of scratch gldm_denoise / gldm_decode need for n_samples. */
+long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples);
+
+/* ref: grasp_ldm/models/diffusion/gaussian_diffusion.py:232-277 (sample loop:
+ * eps = model(x, t, z_cond); x = scheduler.step(eps, t, x)) and
+ * resnets.py:558-616 (TimeConditionedResNet1D.forward), fused: ONE launch runs
+ * all n_steps for every latent; x stays on chip between steps.
+ *  - sched_kind NONE with n_steps = 1 returns eps (= the module's forward);
+ *    sample_t (optional, [n]) then gives a per-sample timestep.
+ *  - temb is the host-precomputed time_mlp table [T, E] (resnets.py:517-522).
+ *  - sample i is conditioned on cemb[i / samples_per_cond].
+ *  - step_noise [n_steps, n, D] is read by DDPM steps with coef[7] != 0. */
+int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,
+                 int samples_per_cond, const float *x_in /*[n,1,L]*/, int n_samples,
+                 const int32_t *timesteps /*[n_steps]*/, const int32_t *sample_t, int n_steps,
+                 int sched_kind, int clip_sample, const float *sched_coef /*[n_steps,8]*/,
+                 const float *step_noise, float *x_out /*[n,1,L]*/, void *workspace, gldm_stream_t stream);
+
+/* ref: grasp_ldm/models/grasp_vae.py:401-436 (ConditionalGraspPoseDecoder.forward:
+ * in_layer -> ResNet1D -> tmrp / class_logits heads). */
+int gldm_decode(const gldm_r1d_desc *desc, const float *weights, const float *cemb, int samples_per_cond,
+                const float *z_h /*[n,D]*/, int n_samples, float *tmrp /*[n,6]*/, float *logit /*[n,1]*/,
+                void *workspace, gldm_stream_t stream);
+
+/* ref: tools/inference.py:64-94,628-647 + grasp_ldm/utils/rotations.py:171-302:
+ * un = tmrp*std+mean; H = tmrp_to_H(un); conf = sigmoid(logit).  mean/std are
+ * per cloud [n_clouds,6]; grasp i belongs to cloud i / grasps_per_cloud. */
+int gldm_pose_epilogue(const float *tmrp /*[n,6]*/, const float *logit /*[n]*/, const float *grasp_mean,
+                       const float *grasp_std, int n, int grasps_per_cloud, float *H /*[n,4,4]*/,
+                       float *tmrp_unnorm /*[n,6]*/, float *confidence /*[n]*/, gldm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,123 @@
+"""GPU (MI355X): the fused 1-D ResNet engine (gldm_denoise / gldm_decode /
+gldm_pose_epilogue through the C ABI) against the golden vectors captured from
+the reference and against the torch-CPU oracle on fresh seeded inputs.
+fp32 tolerances: single forward 2e-5 abs (values are O(1)); 100-step DDIM and
+1000-step DDPM trajectories 1e-4 (the north-star pose bound)."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines(fpc_state_dict):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from graspldm_amd.r1d import R1dEngine, pack_resnet1d
+    sd = fpc_state_dict
+    den = R1dEngine(pack_resnet1d(sd, "diffusion_model.model.", groups=4, seq_len=4, num_steps=1000), "cuda:0")
+    p = "vae_model.decoder."
+    dec = R1dEngine(pack_resnet1d(sd, p + "net.", groups=4, seq_len=16, decoder=dict(
+        in_w=sd[p + "in_layer.weight"], in_b=sd[p + "in_layer.bias"], tmrp_w=sd[p + "tmrp.weight"],
+        tmrp_b=sd[p + "tmrp.bias"], cls_w=sd[p + "class_logits.weight"], cls_b=sd[p + "class_logits.bias"])), "cuda:0")
+    return den, dec
+
+
+def _err(a, b):
+    return (a.cpu() - b).abs().max().item()
+
+
+def test_cond_embed_matches_oracle(engines, fpc_state_dict):
+    import torch.nn.functional as F
+    den, _ = engines
+    z = torch.randn(5, 3, 64, generator=torch.Generator().manual_seed(1))
+    exp = F.silu(F.linear(z, fpc_state_dict["diffusion_model.model.input_emb_layers.0.weight"],
+                          fpc_state_dict["diffusion_model.model.input_emb_layers.0.bias"]))
+    assert _err(den.cond_embed(z.cuda()), exp) < 2e-6
+
+
+def test_g3_denoiser_forward_golden(engines):
+    den, _ = engines
+    g = load_golden("denoiser.npz")
+    cemb = den.cond_embed(g["z_cond"].cuda())
+    for i, t in enumerate(g["t"].tolist()):
+        ts = torch.tensor([t], dtype=torch.int32, device="cuda")
+        eps = den.denoise(g["x"].cuda(), cemb, 1, timesteps=ts)
+        assert _err(eps, g["eps"][i]) < 2e-5, (t, _err(eps, g["eps"][i]))
+
+
+def test_denoiser_per_sample_times_and_ragged_batch(engines, fpc_state_dict):
+    from oracle import torch_ref as R
+    den, _ = engines
+    g = torch.Generator().manual_seed(3)
+    n = 37  # not a multiple of the 16-sample tile
+    x = torch.randn(n, 1, 4, generator=g)
+    z = torch.randn(n, 3, 64, generator=g)
+    t = torch.randint(0, 1000, (n,), generator=g)
+    exp = R.resnet1d_forward(fpc_state_dict, "diffusion_model.model.", x, z_cond=z, time=t)
+    eps = den.denoise(x.cuda(), den.cond_embed(z.cuda()), 1, sample_t=t.int().cuda())
+    assert _err(eps, exp) < 2e-5
+
+
+def test_g4_decoder_golden(engines):
+    _, dec = engines
+    g = load_golden("decoder.npz")
+    tmrp, logit = dec.decode(g["z_h"].cuda(), dec.cond_embed(g["z_cond"].cuda()), 1)
+    assert _err(tmrp, g["tmrp"]) < 2e-5 and _err(logit, g["logit"]) < 2e-5
+
+
+def _ddim_tables(n_inf=100):
+    from graspldm_amd.diffusion import make_schedule_tables
+    return make_schedule_tables("ddim", 1000, 5e-5, 1e-3, "linear", "fixed_large", n_inf)
+
+
+def test_g5_ddim_trajectory_golden(engines):
+    from graspldm_amd.r1d import SCHED_DDIM
+    den, _ = engines
+    g = load_golden("ddim_traj.npz")
+    ts, coef = _ddim_tables(100)
+    cemb = den.cond_embed(g["z_cond"].cuda())
+    x_T = g["x_T"].cuda()
+    for j, i in enumerate(g["probes"].tolist()):
+        x = den.denoise(x_T, cemb, 1, timesteps=ts[:i].cuda(), sched_kind=SCHED_DDIM, coef=coef[:i].cuda())
+        assert _err(x, g["x"][j]) < 1e-4, (i, _err(x, g["x"][j]))
+    x0 = den.denoise(x_T, cemb, 1, timesteps=ts.cuda(), sched_kind=SCHED_DDIM, coef=coef.cuda())
+    assert _err(x0, g["x0"]) < 1e-4
+
+
+def test_g5_ddpm_trajectory_golden(engines):
+    from graspldm_amd.diffusion import make_schedule_tables
+    from graspldm_amd.r1d import SCHED_DDPM
+    den, _ = engines
+    g = load_golden("ddpm_traj.npz")
+    ts, coef = make_schedule_tables("ddpm", 1000, 5e-5, 1e-3, "linear", "fixed_large", None)
+    noise = torch.cat([g["step_noise"], torch.zeros(1, 4, 1, 4)]).cuda()  # t = 999..1 then unused t = 0
+    cemb = den.cond_embed(g["z_cond"].cuda())
+    x0 = den.denoise(g["x_T"].cuda(), cemb, 1, timesteps=ts.cuda(), sched_kind=SCHED_DDPM, coef=coef.cuda(),
+                     step_noise=noise)
+    assert _err(x0, g["x0"]) < 1e-4, _err(x0, g["x0"])
+
+
+def test_g6_pose_epilogue_golden():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from graspldm_amd.r1d import pose_epilogue
+    g = load_golden("tmrp_to_H.npz")
+    mean, std = torch.zeros(1, 6).cuda(), torch.ones(1, 6).cuda()
+    H, un, conf = pose_epilogue(g["tmrp"].cuda(), torch.zeros(64, 1).cuda(), mean, std, 64)
+    assert _err(H, g["H"]) < 1e-6 and _err(un, g["tmrp"]) == 0 and _err(conf, torch.full((64, 1), 0.5)) == 0
+
+
+def test_shared_conditioning_index(engines, fpc_state_dict):
+    """samples_per_cond = G: sample i uses cloud i // G (repeat_interleave in grasp_ldm.py:204)."""
+    from oracle import torch_ref as R
+    den, _ = engines
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(3, 3, 64, generator=g)
+    x = torch.randn(60, 1, 4, generator=g)
+    t = torch.full((60,), 500)
+    exp = R.resnet1d_forward(fpc_state_dict, "diffusion_model.model.", x, z_cond=z.repeat_interleave(20, 0), time=t)
+    eps = den.denoise(x.cuda(), den.cond_embed(z.cuda()), 20, timesteps=torch.tensor([500], dtype=torch.int32).cuda())
+    assert _err(eps, exp) < 2e-5
