@@ -441,14 +441,14 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
   float *lat = lds + kMiscLat, *epsr = lds + kMiscEps, *G = lds + kMiscG;
   float *X = lds + kBufX;
   float *ss_tile = a.ws + (size_t)tile * d.ss_rows * S;
-  const bool decode = d.latent_dim > 0;
+  const bool has_in = d.latent_dim > 0, has_head = d.n_head > 0;
 
   // ---- latent row for this tile
   if (c.tid < kCols) {
     const int s = c.tid / L, l = c.tid % L;
     const int gi = min(samp0 + s, a.n_samples - 1);
     float v;
-    if (decode) {
+    if (has_in) {
       const float *wi = a.weights + d.in_w + l * d.latent_dim;
       v = a.weights[d.in_b + l];
       for (int q = 0; q < d.latent_dim; ++q) v += wi[q] * a.x_in[(size_t)gi * d.latent_dim + q];
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
 #pragma unroll
         for (int q = 0; q < kWaves; ++q) e += red1[q * kCols + c.tid];
         epsr[c.tid] = e;
-        if (!decode && a.sched_kind != GLDM_SCHED_NONE) {
+        if (a.sched_kind != GLDM_SCHED_NONE) {
           const int s = c.tid / L, l = c.tid % L;
           const int gi = min(samp0 + s, a.n_samples - 1);
           const float *cf = a.sched_coef + (size_t)step * GLDM_SCHED_COEF_STRIDE;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
   }
 
   // ---- outputs
-  if (!decode) {
+  if (!has_head) {
     if (c.tid < kCols) {
       const int s = c.tid / L, l = c.tid % L;
       const int gi = samp0 + s;

@@ -68,3 +68,89 @@ def make_schedule_tables(kind, num_train_steps, beta_start, beta_end, beta_sched
         else:
             raise NotImplementedError(kind)
     return torch.tensor(ts, dtype=torch.int32), coef
+
+
+class GaussianDiffusion1D(nn.Module):
+    """Sampling half of gaussian_diffusion.py:10-277 with the same constructor arguments
+    and attributes (`model`, `n_dims`, `beta_start/end`, `num_steps`,
+    `num_inference_steps`, `set_inference_timesteps`, `sample`)."""
+    NOISE_SCHEDULERS = ["ddpm", "ddim"]
+    BETA_SCHEDULES = ["linear", "scaled_linear", "squaredcos_cap_v2", "cosine"]
+    VARIANCE_TYPES = ["fixed_small", "fixed_small_log", "fixed_large", "fixed_large_log", "learned", "learned_range"]
+
+    def __init__(self, model, n_dims, noise_scheduler_type="ddpm", beta_schedule="linear",
+                 variance_type="fixed_small", pred_type="epsilon", beta_start=0.0001, beta_end=0.02, num_steps=1000,
+                 loss_type="l1", clip_sample=True):
+        super().__init__()
+        assert noise_scheduler_type in self.NOISE_SCHEDULERS, f"{noise_scheduler_type} Not supported"
+        assert beta_schedule in self.BETA_SCHEDULES, f"{beta_schedule} not supported"
+        assert variance_type in self.VARIANCE_TYPES, f"{variance_type} not supported"
+        if pred_type != "epsilon":
+            raise NotImplementedError("only epsilon prediction is on the generation hot path")
+        if variance_type in ("learned", "learned_range"):
+            raise NotImplementedError("learned variance is not on the generation hot path")
+        assert model.out_channels == 1, (
+            f"For pre-defined variance type {variance_type}, the score model should have only one output channel")
+        self.num_train_timesteps = self.num_steps = num_steps
+        self.beta_start, self.beta_end = beta_start, beta_end
+        self.beta_schedule = beta_schedule if beta_schedule != "cosine" else "squaredcos_cap_v2"
+        self.variance_type, self.pred_type, self.clip_sample = variance_type, pred_type, clip_sample
+        self.model, self.n_dims, self.channels = model, n_dims, 1
+        self.loss_type = loss_type
+        self._noise_scheduler_type = noise_scheduler_type
+        self._num_inference_steps = None
+        self._tables = {}
+        if hasattr(model, "max_timesteps"):
+            model.max_timesteps = max(model.max_timesteps, num_steps)
+
+    @property
+    def num_inference_steps(self):
+        return self._num_inference_steps if self._num_inference_steps is not None else self.num_steps
+
+    def set_inference_timesteps(self, num_steps):
+        self._num_inference_steps = int(num_steps)
+
+    def _schedule(self, device):
+        key = (str(device), self._noise_scheduler_type, self._num_inference_steps)
+        if key not in self._tables:
+            ts, coef = make_schedule_tables(self._noise_scheduler_type, self.num_steps, self.beta_start, self.beta_end,
+                                            self.beta_schedule, self.variance_type, self._num_inference_steps)
+            self._tables[key] = (ts.to(device), coef.to(device))
+        return self._tables[key]
+
+    @torch.no_grad()
+    def sample(self, z_cond=None, batch_size=1, return_all=False, device=None, samples_per_cond=1, x_T=None,
+               step_noise=None, **kwargs):
+        """Reverse diffusion (gaussian_diffusion.py:232-277).  x_T is drawn on the CPU
+        generator then moved, exactly like the reference (:253); DDPM per-step noise is
+        drawn on the device ([steps, B, 1, D]) unless `step_noise` is given.  One HIP launch
+        runs every step.  `z_cond` is [B/samples_per_cond, R, Dc] (the reference passes the
+        repeat_interleaved tensor: samples_per_cond = 1)."""
+        device = torch.device(device if device is not None else z_cond.device)
+        if device.type != "cuda":
+            raise RuntimeError("sampling runs on the GPU only (graspldm_amd has no CPU path)")
+        if x_T is None:
+            x_T = torch.randn((batch_size, self.channels, self.n_dims))
+        x_T = x_T.to(device)
+        ts, coef = self._schedule(device)
+        kind = SCHED_DDIM if self._noise_scheduler_type == "ddim" else SCHED_DDPM
+        if kind == SCHED_DDPM and step_noise is None:
+            step_noise = torch.randn((ts.numel(), batch_size, self.channels, self.n_dims), device=device)
+        model = self.model
+        model._cond_rows_of(z_cond)
+        eng = model.engine(device)
+        cemb = eng.cond_embed(z_cond.to(device))
+        if not return_all:
+            x = eng.denoise(x_T, cemb, samples_per_cond, timesteps=ts, sched_kind=kind, clip_sample=self.clip_sample,
+                            coef=coef, step_noise=step_noise)
+            return x, []
+        trace, x = [x_T], x_T
+        for i in range(ts.numel()):
+            x = eng.denoise(x, cemb, samples_per_cond, timesteps=ts[i:i + 1], sched_kind=kind,
+                            clip_sample=self.clip_sample, coef=coef[i:i + 1],
+                            step_noise=None if step_noise is None else step_noise[i:i + 1])
+            trace.append(x)
+        return x, trace
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("training (denoising loss) is out of scope: graspldm_amd is the generation path")

@@ -1,0 +1,66 @@
+"""Point-cloud encoder heads: mirror of `grasp_ldm/models/modules/pc_encoders.py`
+(PVCNNEncoder :8-136, PVCNN2Encoder :139-197) with the same constructor arguments and
+state_dict keys."""
+import torch
+from torch import nn
+
+from . import dense
+from .pvcnn import PVCNN, PVCNN2
+
+
+class PVCNNEncoder(nn.Module):
+    def __init__(self, in_features=3, out_features=32, n_points=1024, extra_feature_channels=0, scale_channels=0.25,
+                 scale_voxel_resolution=0.75, num_blocks=(1, 1, 1, 1), is_conditioned=False, cond_dims=None,
+                 extra_block_channels=None, use_global_attention=False, out_channels=1, load_from_ckpt_path=None):
+        super().__init__()
+        if use_global_attention:
+            raise NotImplementedError("global attention is off in the shipped configs and not on the hot path")
+        self.pvcnn_modules = PVCNN(extra_feature_channels=extra_feature_channels, scale_channels=scale_channels,
+                                   scale_voxel_resolution=scale_voxel_resolution, num_blocks=num_blocks,
+                                   is_conditioned=is_conditioned, cond_dims=cond_dims,
+                                   extra_block_channels=extra_block_channels)
+        self._finish(in_features, out_features, n_points, out_channels)
+        if load_from_ckpt_path is not None:
+            self.load_ckpt_and_freeze(load_from_ckpt_path)
+
+    def _finish(self, in_features, out_features, n_points, out_channels):
+        self.in_features, self.out_features = in_features, out_features
+        mid = int(self.pvcnn_modules.out_channels / 2)
+        self.conv_downscale = nn.Conv1d(self.pvcnn_modules.out_channels, mid, kernel_size=1)
+        self.global_attention = None
+        self.out_layer = nn.Sequential(nn.Conv1d(mid, out_channels, kernel_size=1),
+                                       nn.Linear(n_points, self.out_features))
+
+    @torch.no_grad()
+    def forward(self, out, cond=None):
+        """pc [B, N, 3] -> latent [B, C_out, out_features] (pc_encoders.py:87-115)."""
+        if not out.is_cuda:
+            raise RuntimeError("pointcloud must be a CUDA tensor (graspldm_amd has no CPU path)")
+        x = torch.transpose(out, 1, 2).contiguous()
+        x = self.pvcnn_modules(x, cond=cond)
+        x = dense.pointwise_conv(x, self.conv_downscale)
+        x = dense.pointwise_conv(x, self.out_layer[0])
+        x = dense.linear(x, self.out_layer[1])
+        return x.squeeze(1) if x.shape[-2] == 1 else x
+
+    def load_ckpt_and_freeze(self, ckpt_path, fine_tune=False):
+        ckpt = torch.load(ckpt_path, map_location="cpu")
+        self.load_state_dict(ckpt["state_dict"] if "state_dict" in ckpt else ckpt)
+        for p in self.parameters():
+            p.requires_grad = False
+
+
+class PVCNN2Encoder(PVCNNEncoder):
+    """The reference's PVCNN2Encoder cannot be constructed (it forwards scale_channels /
+    num_blocks / ... to PVCNN2.__init__, which does not accept them: pc_encoders.py:188-197 vs
+    pvcnn_base.py:204-212).  This is the repaired form: same head, PVCNN2 (set-abstraction +
+    feature-propagation) backbone built from the arguments PVCNN2 does take."""
+
+    def __init__(self, in_features=3, out_features=32, n_points=1024, extra_feature_channels=0, scale_channels=0.25,
+                 scale_voxel_resolution=0.75, num_blocks=(1, 1, 1, 1), is_conditioned=False, cond_dims=None,
+                 extra_block_channels=None, use_global_attention=False, use_local_attention=False, out_channels=1):
+        nn.Module.__init__(self)
+        if use_global_attention or use_local_attention:
+            raise NotImplementedError("attention variants are not on the hot path")
+        self.pvcnn_modules = PVCNN2(extra_feature_channels=extra_feature_channels, use_attention=False)
+        self._finish(in_features, out_features, n_points, out_channels)

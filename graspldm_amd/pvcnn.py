@@ -1,0 +1,518 @@
+"""Point-cloud backbones of the GraspLDM encoder on MI355X: host-side mirror of
+`grasp_ldm/models/modules/ext/pvcnn/**` (functional wrappers, nn.Modules and the
+three backbones PVCNN / PVCNN2 / PointNet2SSG) with the reference's class names,
+constructor arguments and state_dict keys, so reference checkpoints load with
+`strict=True`.
+
+Inference only.  Every point operator runs in libgldm_hip.so through the C ABI
+(`backend._backend` / `_lib.call`); there is no CPU or autograd path: calling a
+module on a CPU tensor raises like the reference's CHECK_CUDA does.
+"""
+import functools
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from . import _lib as L
+from . import dense
+from .backend import _backend
+
+# ------------------------------------------------------------------ functional
+# (functional/{ball_query,grouping,sampling,interpolatation,voxelization,devoxelization}.py)
+
+
+def ball_query(centers_coords, points_coords, radius, num_neighbors):
+    return _backend.ball_query(centers_coords.contiguous(), points_coords.contiguous(), radius, num_neighbors)
+
+
+def grouping(features, indices):
+    return _backend.grouping_forward(features.contiguous(), indices.contiguous())
+
+
+def gather(features, indices):
+    return _backend.gather_features_forward(features.contiguous(), indices.int().contiguous())
+
+
+def furthest_point_sample(coords, num_samples):
+    coords = coords.contiguous()
+    return gather(coords, _backend.furthest_point_sampling(coords, num_samples))
+
+
+def nearest_neighbor_interpolate(points_coords, centers_coords, centers_features):
+    return _backend.three_nearest_neighbors_interpolate_forward(
+        points_coords.contiguous(), centers_coords.contiguous(), centers_features.contiguous())[0]
+
+
+def avg_voxelize(features, coords, resolution):
+    b, c, _ = features.shape
+    out, _, _ = _backend.avg_voxelize_forward(features.contiguous(), coords.int().contiguous(), resolution)
+    return out.view(b, c, resolution, resolution, resolution)
+
+
+def trilinear_devoxelize(features, coords, resolution, is_training=False):
+    b, c = features.shape[:2]
+    return _backend.trilinear_devoxelize_forward(resolution, bool(is_training), coords.contiguous(),
+                                                 features.contiguous().view(b, c, -1))[0]
+
+
+def sa_group(points_coords, centers_coords, points_features, radius, num_neighbors):
+    """BallQuery.forward with include_coordinates=True as one launch (gldm_sa_group)."""
+    pts, ctr = points_coords.contiguous(), centers_coords.contiguous()
+    feat = points_features.contiguous() if points_features is not None and points_features.shape[1] > 0 else None
+    for t, nm in ((pts, "points_coords"), (ctr, "centers_coords")) + (((feat, "points_features"),) if feat is not None else ()):
+        if not t.is_cuda:
+            raise RuntimeError(f"{nm} must be a CUDA tensor")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{nm} must be a float tensor")
+    b, _, n = pts.shape
+    m = ctr.shape[2]
+    c = 0 if feat is None else feat.shape[1]
+    out = torch.empty((b, 3 + c, m, int(num_neighbors)), dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        L.call("gldm_sa_group", L.ptr(pts), L.ptr(ctr), L.ptr(feat), b, c, n, m, float(radius), int(num_neighbors),
+               L.ptr(out), None, L.current_stream(pts.device))
+    return out
+
+
+# --------------------------------------------------------------------- modules
+
+
+class Swish(nn.Module):
+    def forward(self, x):
+        return dense.swish(x)
+
+
+class SharedMLP(nn.Module):
+    """(Conv k=1 + BatchNorm + ReLU)*  -- shared_mlp.py:6-35.  Eval mode: BatchNorm is
+    folded into the GEMM epilogue (dense.pointwise_conv_bn_relu)."""
+
+    def __init__(self, in_channels, out_channels, dim=1):
+        super().__init__()
+        if dim == 1:
+            conv, bn = nn.Conv1d, nn.BatchNorm1d
+        elif dim == 2:
+            conv, bn = nn.Conv2d, nn.BatchNorm2d
+        else:
+            raise ValueError
+        if not isinstance(out_channels, (list, tuple)):
+            out_channels = [out_channels]
+        layers = []
+        for oc in out_channels:
+            layers.extend([conv(in_channels, oc, 1), bn(oc), nn.ReLU(True)])
+            in_channels = oc
+        self.layers = nn.Sequential(*layers)
+
+    def _run(self, x):
+        for i in range(0, len(self.layers), 3):
+            x = dense.pointwise_conv_bn_relu(x, self.layers[i], self.layers[i + 1])
+        return x
+
+    def forward(self, inputs):
+        if isinstance(inputs, (list, tuple)):
+            return (self._run(inputs[0]), *inputs[1:])
+        return self._run(inputs)
+
+
+class BallQuery(nn.Module):
+    """ball_query.py:9-34"""
+
+    def __init__(self, radius, num_neighbors, include_coordinates=True):
+        super().__init__()
+        self.radius, self.num_neighbors, self.include_coordinates = radius, num_neighbors, include_coordinates
+
+    def forward(self, points_coords, centers_coords, points_features=None):
+        if self.include_coordinates:
+            return sa_group(points_coords, centers_coords, points_features, self.radius, self.num_neighbors)
+        assert points_features is not None, "No Features For Grouping"
+        idx = ball_query(centers_coords, points_coords, self.radius, self.num_neighbors)
+        return grouping(points_features, idx)
+
+    def extra_repr(self):
+        return "radius={}, num_neighbors={}{}".format(
+            self.radius, self.num_neighbors, ", include coordinates" if self.include_coordinates else "")
+
+
+def _as_nested(out_channels, n):
+    if not isinstance(out_channels, (list, tuple)):
+        return [[out_channels]] * n
+    if not isinstance(out_channels[0], (list, tuple)):
+        return [out_channels] * n
+    return out_channels
+
+
+class PointNetAModule(nn.Module):
+    """pointnet.py:11-46"""
+
+    def __init__(self, in_channels, out_channels, include_coordinates=True):
+        super().__init__()
+        out_channels = _as_nested(out_channels, 1)
+        mlps, total = [], 0
+        for oc in out_channels:
+            mlps.append(SharedMLP(in_channels + (3 if include_coordinates else 0), oc, dim=1))
+            total += oc[-1]
+        self.include_coordinates = include_coordinates
+        self.out_channels = total
+        self.mlps = nn.ModuleList(mlps)
+
+    def forward(self, inputs):
+        features, coords = inputs
+        if self.include_coordinates:
+            features = torch.cat([features, coords], dim=1)
+        coords = torch.zeros((coords.size(0), 3, 1), device=coords.device)
+        outs = [mlp(features).max(dim=-1, keepdim=True).values for mlp in self.mlps]
+        return (torch.cat(outs, dim=1) if len(outs) > 1 else outs[0]), coords
+
+
+class PointNetSAModule(nn.Module):
+    """pointnet.py:49-114: FPS -> ball query -> group -> SharedMLP2d -> max over neighbours."""
+
+    def __init__(self, num_centers, radius, num_neighbors, in_channels, out_channels, include_coordinates=True):
+        super().__init__()
+        if not isinstance(radius, (list, tuple)):
+            radius = [radius]
+        if not isinstance(num_neighbors, (list, tuple)):
+            num_neighbors = [num_neighbors] * len(radius)
+        assert len(radius) == len(num_neighbors)
+        out_channels = _as_nested(out_channels, len(radius))
+        assert len(radius) == len(out_channels)
+        groupers, mlps, total = [], [], 0
+        for r, oc, k in zip(radius, out_channels, num_neighbors):
+            groupers.append(BallQuery(radius=r, num_neighbors=k, include_coordinates=include_coordinates))
+            mlps.append(SharedMLP(in_channels + (3 if include_coordinates else 0), oc, dim=2))
+            total += oc[-1]
+        self.num_centers = num_centers
+        self.out_channels = total
+        self.groupers = nn.ModuleList(groupers)
+        self.mlps = nn.ModuleList(mlps)
+
+    def forward(self, inputs):
+        features, coords = inputs
+        centers = furthest_point_sample(coords, self.num_centers)
+        outs = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            outs.append(mlp(grouper(coords, centers, features)).max(dim=-1).values)
+        return (torch.cat(outs, dim=1) if len(outs) > 1 else outs[0]), centers
+
+    def extra_repr(self):
+        return f"num_centers={self.num_centers}, out_channels={self.out_channels}"
+
+
+class PointNetFPModule(nn.Module):
+    """pointnet.py:117-135"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.mlp = SharedMLP(in_channels=in_channels, out_channels=out_channels, dim=1)
+
+    def forward(self, inputs):
+        if len(inputs) == 3:
+            points_coords, centers_coords, centers_features = inputs
+            points_features = None
+        else:
+            points_coords, centers_coords, centers_features, points_features = inputs
+        interp = nearest_neighbor_interpolate(points_coords, centers_coords, centers_features)
+        if points_features is not None:
+            interp = torch.cat([interp, points_features], dim=1)
+        return self.mlp(interp), points_coords
+
+
+class Voxelization(nn.Module):
+    """voxelization.py:9-35; the coordinate front end is one kernel (gldm_voxel_coords)."""
+
+    def __init__(self, resolution, normalize=True, eps=0):
+        super().__init__()
+        self.r, self.normalize, self.eps = int(resolution), normalize, eps
+
+    def forward(self, features, coords):
+        coords = coords.detach().contiguous()
+        if not coords.is_cuda:
+            raise RuntimeError("coords must be a CUDA tensor")
+        b, _, n = coords.shape
+        norm_coords = torch.empty_like(coords)
+        vox = torch.empty(coords.shape, dtype=torch.int32, device=coords.device)
+        with torch.cuda.device(coords.device):
+            L.call("gldm_voxel_coords", L.ptr(coords), b, n, self.r, 1 if self.normalize else 0, float(self.eps),
+                   L.ptr(norm_coords), L.ptr(vox), L.current_stream(coords.device))
+        return avg_voxelize(features, vox, self.r), norm_coords
+
+    def extra_repr(self):
+        return "resolution={}{}".format(self.r, ", normalized eps = {}".format(self.eps) if self.normalize else "")
+
+
+class SE3d(nn.Module):
+    """se.py:12-25"""
+
+    def __init__(self, channel, reduction=8, use_relu=False):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(channel, channel // reduction, bias=False),
+                                nn.ReLU(True) if use_relu else Swish(),
+                                nn.Linear(channel // reduction, channel, bias=False), nn.Sigmoid())
+        self.use_relu = use_relu
+
+    def gate(self, mean):
+        h = TF.linear(mean, self.fc[0].weight)
+        h = torch.relu(h) if self.use_relu else h * torch.sigmoid(h)
+        return torch.sigmoid(TF.linear(h, self.fc[2].weight))
+
+    def forward(self, inputs):
+        return inputs * self.gate(inputs.mean(dim=(2, 3, 4))).view(inputs.shape[0], inputs.shape[1], 1, 1, 1)
+
+
+class PVConv(nn.Module):
+    """pvconv.py:13-84 (inference; `use_attention` voxel attention is off in every shipped config)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, resolution, use_attention=False, dropout=0.1,
+                 with_se=False, with_se_relu=False, normalize=True, eps=0):
+        super().__init__()
+        if use_attention:
+            raise NotImplementedError("voxel attention is not on the generation hot path")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.resolution = kernel_size, resolution
+        self.voxelization = Voxelization(resolution, normalize=normalize, eps=eps)
+        layers = [nn.Conv3d(in_channels, out_channels, kernel_size, stride=1, padding=kernel_size // 2),
+                  nn.GroupNorm(num_groups=8, num_channels=out_channels), Swish()]
+        layers += [nn.Dropout(dropout)] if dropout is not None else []
+        layers += [nn.Conv3d(out_channels, out_channels, kernel_size, stride=1, padding=kernel_size // 2),
+                   nn.GroupNorm(num_groups=8, num_channels=out_channels), Swish()]
+        if with_se:
+            layers.append(SE3d(out_channels, use_relu=with_se_relu))
+        self.voxel_layers = nn.Sequential(*layers)
+        self.point_features = SharedMLP(in_channels, out_channels)
+
+    def forward(self, inputs):
+        features, coords = inputs
+        vox, norm_coords = self.voxelization(features, coords)
+        mods = list(self.voxel_layers)
+        convs = [m for m in mods if isinstance(m, nn.Conv3d)]
+        norms = [m for m in mods if isinstance(m, nn.GroupNorm)]
+        se = mods[-1] if isinstance(mods[-1], SE3d) else None
+        h = dense.conv3d_gn_swish(vox, convs[0], norms[0])
+        h = dense.conv3d_gn_swish(h, convs[1], norms[1])
+        if se is not None:
+            h = se(h)
+        out = trilinear_devoxelize(h, norm_coords, self.resolution, False)
+        return out + self.point_features(features), coords
+
+
+# --------------------------------------------------------------------- builders
+# (ext/pvcnn/utils.py:65-247, restated)
+
+
+def create_pointnet_components(blocks, in_channels, with_se=False, normalize=True, eps=0, width_multiplier=1,
+                               voxel_resolution_multiplier=1):
+    r, vr = width_multiplier, voxel_resolution_multiplier
+    layers, concat = [], 0
+    for out_channels, num_blocks, voxel_resolution in blocks:
+        out_channels = int(r * out_channels)
+        if voxel_resolution is None:
+            make = SharedMLP
+        else:
+            make = functools.partial(PVConv, kernel_size=3, resolution=int(vr * voxel_resolution), with_se=with_se,
+                                     normalize=normalize, eps=eps)
+        for _ in range(num_blocks):
+            layers.append(make(in_channels, out_channels))
+            in_channels = out_channels
+            concat += out_channels
+    return layers, in_channels, concat
+
+
+def create_pointnet2_sa_components(sa_blocks, extra_feature_channels, embed_dim=0, use_attention=False, dropout=0.1,
+                                   with_se=False, voxelization_normalize=True, eps=0, width_multiplier=1,
+                                   voxel_resolution_multiplier=1):
+    """utils.py:97-182.  Keeps the reference's quirk that, after the first stage, only the
+    first PVConv of a multi-block stage is instantiated (the `elif k == 0` at :142)."""
+    r, vr = width_multiplier, voxel_resolution_multiplier
+    in_channels = extra_feature_channels + 3
+    sa_layers, sa_in_channels = [], []
+    stage = 0
+    num_centers = None
+    for conv_cfg, sa_cfg in sa_blocks:
+        k = 0
+        sa_in_channels.append(in_channels)
+        blocks = []
+        if conv_cfg is not None:
+            oc, num_blocks, vres = conv_cfg
+            oc = int(r * oc)
+            for p in range(num_blocks):
+                attention = (stage + 1) % 2 == 0 and use_attention and p == 0
+                if vres is None:
+                    make = SharedMLP
+                else:
+                    make = functools.partial(PVConv, kernel_size=3, resolution=int(vr * vres),
+                                             use_attention=attention, dropout=dropout, with_se=with_se,
+                                             with_se_relu=True, normalize=voxelization_normalize, eps=eps)
+                if stage == 0:
+                    blocks.append(make(in_channels, oc))
+                elif k == 0:
+                    blocks.append(make(in_channels + embed_dim, oc))
+                in_channels = oc
+                k += 1
+            extra_feature_channels = in_channels
+        num_centers, radius, num_neighbors, ocs = sa_cfg
+        ocs = [[int(r * o) for o in oc] if isinstance(oc, (list, tuple)) else int(r * oc) for oc in ocs]
+        if num_centers is None:
+            make = PointNetAModule
+        else:
+            make = functools.partial(PointNetSAModule, num_centers=num_centers, radius=radius,
+                                     num_neighbors=num_neighbors)
+        blocks.append(make(in_channels=extra_feature_channels + (embed_dim if k == 0 else 0), out_channels=ocs,
+                           include_coordinates=True))
+        stage += 1
+        in_channels = extra_feature_channels = blocks[-1].out_channels
+        sa_layers.append(blocks[0] if len(blocks) == 1 else nn.Sequential(*blocks))
+    return sa_layers, sa_in_channels, in_channels, 1 if num_centers is None else num_centers
+
+
+def create_pointnet2_fp_modules(fp_blocks, in_channels, sa_in_channels, embed_dim=0, use_attention=False, dropout=0.1,
+                                with_se=False, normalize=True, eps=0, width_multiplier=1,
+                                voxel_resolution_multiplier=1):
+    """utils.py:185-247"""
+    r, vr = width_multiplier, voxel_resolution_multiplier
+    fp_layers = []
+    for fp_idx, (fp_cfg, conv_cfg) in enumerate(fp_blocks):
+        blocks = []
+        ocs = tuple(int(r * oc) for oc in fp_cfg)
+        blocks.append(PointNetFPModule(in_channels=in_channels + sa_in_channels[-1 - fp_idx] + embed_dim,
+                                       out_channels=ocs))
+        in_channels = ocs[-1]
+        if conv_cfg is not None:
+            oc, num_blocks, vres = conv_cfg
+            oc = int(r * oc)
+            for _ in range(num_blocks):
+                if vres is None:
+                    make = SharedMLP
+                else:
+                    make = functools.partial(PVConv, kernel_size=3, resolution=int(vr * vres), use_attention=False,
+                                             dropout=dropout, with_se=with_se, with_se_relu=True,
+                                             normalize=normalize, eps=eps)
+                blocks.append(make(in_channels, oc))
+                in_channels = oc
+        fp_layers.append(blocks[0] if len(blocks) == 1 else nn.Sequential(*blocks))
+    return fp_layers, in_channels
+
+
+# -------------------------------------------------------------------- backbones
+
+
+class PVCNN(nn.Module):
+    """pvcnn_base.py:15-177 (the shipped encoder backbone; FiLM conditioning is off in
+    every shipped config and not implemented)."""
+
+    def __init__(self, in_channels=3, extra_feature_channels=0, scale_channels=0.25, scale_voxel_resolution=0.75,
+                 num_blocks=(1, 2, 1, 1), is_conditioned=False, cond_dims=None, extra_block_channels=None):
+        super().__init__()
+        assert extra_feature_channels >= 0
+        if not isinstance(num_blocks, (list, tuple)):
+            raise TypeError("num_blocks must be of type List or Tuple")
+        if len(num_blocks) != 4:
+            raise ValueError("PVCNN is configured with 4 PVConv modules. The num_blocks sequence must of length 4.")
+        if is_conditioned:
+            raise NotImplementedError("conditioned PVCNN (FiLM) is not on the generation hot path")
+        self.in_channels = in_channels + extra_feature_channels
+        self.block_spec = self.get_blocks_spec(scale_channels, scale_voxel_resolution, num_blocks, extra_block_channels)
+        self.out_channels = self.block_spec[-1][0]
+        layers, _, _ = create_pointnet_components(blocks=self.block_spec, in_channels=self.in_channels, with_se=True,
+                                                  normalize=False, width_multiplier=1, voxel_resolution_multiplier=1)
+        self.point_features = nn.ModuleList(layers)
+        self.is_conditioned = False
+
+    @staticmethod
+    def get_blocks_spec(c_mul, r_mul, num_blocks, extra_block_channels=None):
+        c = [int(64 * c_mul), int(128 * c_mul), int(1024 * c_mul), int(2048 * c_mul)]
+        r = [int(32 * r_mul), int(16 * r_mul), None, None]
+        assert all(v % 2 == 0 for v in c) and r[0] % 2 == 0 and r[1] % 2 == 0
+        blocks = tuple((c[i], num_blocks[i], r[i]) for i in range(4))
+        if extra_block_channels is not None:
+            blocks = blocks + tuple((ch, 1, None) for ch in extra_block_channels)
+        return blocks
+
+    def forward(self, inputs, *, cond=None):
+        features = inputs[:, : self.in_channels, :]
+        coords = features[:, :3, :].contiguous()
+        for layer in self.point_features:
+            features, _ = layer((features, coords))
+        return features
+
+
+class PVCNN2(nn.Module):
+    """pvcnn_base.py:180-279"""
+    sa_blocks = [((32, 1, 32), (1024, 0.1, 32, (32, 64))), ((64, 2, 16), (256, 0.2, 32, (64, 128))),
+                 ((128, 1, 8), (64, 0.4, 32, (128, 256))), (None, (16, 0.8, 32, (256, 256, 512)))]
+    fp_blocks = [((256, 256), (256, 1, 8)), ((256, 256), (256, 1, 8)), ((256, 128), (128, 2, 16)),
+                 ((128, 128, 64), (64, 1, 32))]
+
+    def __init__(self, in_channels=3, extra_feature_channels=0, width_multiplier=1, voxel_resolution_multiplier=1,
+                 use_attention=False, dropout=0.1):
+        super().__init__()
+        self.in_channels = in_channels + extra_feature_channels
+        sa_layers, sa_in, ch_sa, _ = create_pointnet2_sa_components(
+            sa_blocks=self.sa_blocks, embed_dim=0, extra_feature_channels=extra_feature_channels, with_se=True,
+            voxelization_normalize=True, use_attention=use_attention, dropout=dropout,
+            width_multiplier=width_multiplier, voxel_resolution_multiplier=voxel_resolution_multiplier)
+        self.sa_layers = nn.ModuleList(sa_layers)
+        sa_in[0] = extra_feature_channels
+        fp_layers, _ = create_pointnet2_fp_modules(
+            fp_blocks=self.fp_blocks, in_channels=ch_sa, sa_in_channels=sa_in, with_se=True,
+            width_multiplier=width_multiplier, voxel_resolution_multiplier=voxel_resolution_multiplier)
+        self.fp_layers = nn.ModuleList(fp_layers)
+        self.out_channels = self.fp_layers[-1][-1].out_channels
+
+    def forward(self, inputs, cond=None):
+        if isinstance(inputs, dict):
+            inputs = inputs["features"]
+        coords, features = inputs[:, :3, :].contiguous(), inputs
+        coords_list, feats_list = [], []
+        for sa in self.sa_layers:
+            feats_list.append(features)
+            coords_list.append(coords)
+            features, coords = sa((features, coords))
+        feats_list[0] = inputs[:, 3:, :].contiguous()
+        for i, fp in enumerate(self.fp_layers):
+            features, coords = fp((coords_list[-1 - i], coords, features, feats_list[-1 - i]))
+        return features
+
+
+class PointNet2(nn.Module):
+    """pointnet2.py:13-95"""
+
+    def __init__(self, sa_blocks, fp_blocks, with_one_hot_shape_id=False, num_shapes=0, extra_feature_channels=3,
+                 width_multiplier=1, voxel_resolution_multiplier=1):
+        super().__init__()
+        assert extra_feature_channels >= 0
+        self.in_channels = extra_feature_channels + 3
+        self.num_shapes, self.with_one_hot_shape_id = num_shapes, with_one_hot_shape_id
+        sa_layers, sa_in, ch_sa, _ = create_pointnet2_sa_components(
+            sa_blocks=sa_blocks, extra_feature_channels=extra_feature_channels, width_multiplier=width_multiplier)
+        self.sa_layers = nn.ModuleList(sa_layers)
+        sa_in[0] += num_shapes if with_one_hot_shape_id else 0
+        fp_layers, _ = create_pointnet2_fp_modules(
+            fp_blocks=fp_blocks, in_channels=ch_sa, sa_in_channels=sa_in, width_multiplier=width_multiplier,
+            voxel_resolution_multiplier=voxel_resolution_multiplier)
+        self.fp_layers = nn.ModuleList(fp_layers)
+
+    def forward(self, inputs):
+        features = inputs[:, : self.in_channels, :]
+        skip0 = inputs if self.with_one_hot_shape_id else features
+        coords, features = features[:, :3, :].contiguous(), features[:, 3:, :].contiguous()
+        coords_list, feats_list = [], []
+        for sa in self.sa_layers:
+            feats_list.append(features)
+            coords_list.append(coords)
+            features, coords = sa((features, coords))
+        feats_list[0] = skip0.contiguous()
+        for i, fp in enumerate(self.fp_layers):
+            features, coords = fp((coords_list[-1 - i], coords, features, feats_list[-1 - i]))
+        return features
+
+
+class PointNet2SSG(PointNet2):
+    """pointnet2.py:98-123"""
+    sa_blocks = [(None, (512, 0.2, 64, (64, 64, 128))), (None, (128, 0.4, 64, (128, 128, 256))),
+                 (None, (None, None, None, (256, 512, 1024)))]
+    fp_blocks = [((256, 256), None), ((256, 128), None), ((128, 128, 128), None)]
+
+    def __init__(self, num_shapes=0, extra_feature_channels=3, width_multiplier=1, voxel_resolution_multiplier=1):
+        super().__init__(num_shapes=num_shapes, sa_blocks=self.sa_blocks, fp_blocks=self.fp_blocks,
+                         with_one_hot_shape_id=False, extra_feature_channels=extra_feature_channels,
+                         width_multiplier=width_multiplier, voxel_resolution_multiplier=voxel_resolution_multiplier)
