@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- grasps/sec of the GraspLDM generation hot path on MI355X.
+
+One "step" = one full pass of the hot path over one batch of synthetic clouds that are
+already resident in HBM: PVCNN encoder -> 100 DDIM steps of the latent denoiser (one fused
+launch) -> pose decoder -> pose epilogue (-> all-gather of the result rows when N > 1).
+Workload per GPU: 256 synthetic 1024-point clouds x 20 grasps (BASELINE.json configs[2];
+configs[3] = the same 256 clouds per GPU on 8 GPUs => weak scaling).
+
+Prints ONE JSON line (rank 0) with the driver's keys plus
+  roofline      dominant kernel (the fused denoise loop, f32 MFMA bound), timed with HIP
+                events on the launch stream inside this run
+  cpu_baseline  the CPU oracle (a torch-CPU port of the reference graph) timed on this
+                box's host cores on a bounded sample (rank 0, N = 1 only)
+  kernels       extra per-kernel roofline records (set-abstraction gather: HBM bound, ...)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix), spec
+PEAK_HBM_GBS = 8000.0          # HBM3E peak, spec
+DENOISER_FLOP_PER_LATENT_STEP = 7_589_120   # SURVEY.md Appendix B (matches torch flop counter)
+DECODER_FLOP_PER_GRASP = 30.7e6
+ENCODER_FLOP_PER_CLOUD = 8.115e9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clouds-per-gpu", type=int, default=256)
+    ap.add_argument("--grasps", type=int, default=20)
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--ddim-steps", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def event_time(fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from graspldm_amd import _lib
+    _lib.lib()  # fail loudly here if the HIP library is missing
+    from graspldm_amd.distributed import gather_results
+    from graspldm_amd.pipeline import build_fpc_ldm
+    from graspldm_amd.r1d import pose_epilogue
+    from graspldm_amd.synthetic import synthetic_batch
+
+    B, G, N, S = args.clouds_per_gpu, args.grasps, args.points, args.ddim_steps
+    ldm = build_fpc_ldm(n_points=N, scheduler="ddim", device=dev)
+    ldm.set_inference_timesteps(S)
+    uniq = min(B, 32)   # 32 distinct synthetic objects per rank, tiled to B (resident in HBM)
+    pcs_u, metas_u = synthetic_batch(uniq, N, first_index=rank * uniq)
+    reps = (B + uniq - 1) // uniq
+    pcs = pcs_u.repeat(reps, 1, 1)[:B].contiguous().to(dev)
+    gmean = metas_u["grasp_mean"].repeat(reps, 1)[:B].contiguous().to(dev)
+    gstd = metas_u["grasp_std"].repeat(reps, 1)[:B].contiguous().to(dev)
+    x_T = torch.randn(B * G, 1, 4, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+
+    def step():
+        (tm, lg), _ = ldm.generate_grasps(pcs, num_grasps=G, x_T=x_T)
+        rows = torch.cat([tm, lg], dim=1)
+        if world > 1:
+            rows = gather_results(rows, B * G, world * B * G)
+            H, un, conf = pose_epilogue(rows[:, :6].contiguous(), rows[:, 6:7].contiguous(),
+                                        gmean.repeat(world, 1), gstd.repeat(world, 1), G)
+        else:
+            H, un, conf = pose_epilogue(tm, lg, gmean, gstd, G)
+        return H
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    grasps_per_s = world * B * G * args.steps / dt
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the fused denoise loop (r1d_kernel<4>)
+        den = ldm.diffusion_model.model
+        eng = den.engine(dev)
+        z = ldm.vae_model.encode_pc(pcs)
+        cemb = eng.cond_embed(z)
+        ts, coef = ldm.diffusion_model._schedule(dev)
+        from graspldm_amd.r1d_pack import SCHED_DDIM
+        dn = lambda: eng.denoise(x_T, cemb, G, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
+        dn()
+        t_den = event_time(dn, 3)
+        flop = B * G * S * DENOISER_FLOP_PER_LATENT_STEP
+        roof = dict(kernel="r1d_kernel<4> (gldm_denoise: %d DDIM steps fused)" % S, bound="mfma",
+                    achieved=flop / t_den / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=flop / t_den / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                    algorithmic_flop_per_launch=flop, avg_launch_ms=t_den * 1e3)
+        # ---- stage split and the set-abstraction gather (north-star HBM kernel), same run
+        t_enc = event_time(lambda: ldm.vae_model.encode_pc(pcs), 3)
+        dec = ldm.vae_model.decoder
+        lat = dn().squeeze(-2)
+        t_dec = event_time(lambda: dec(lat, z, samples_per_cond=G), 3)
+        kernels = [dict(kernel="PVCNNEncoder.forward (all launches)", bound="mfma", avg_ms=t_enc * 1e3,
+                        achieved=B * ENCODER_FLOP_PER_CLOUD / t_enc / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=B * ENCODER_FLOP_PER_CLOUD / t_enc / 1e12 / PEAK_F32_MFMA_TFLOPS),
+                   dict(kernel="r1d_kernel<16> (gldm_decode)", bound="mfma", avg_ms=t_dec * 1e3,
+                        achieved=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12 / PEAK_F32_MFMA_TFLOPS)]
+        from graspldm_amd import _lib as L
+        from graspldm_amd.pvcnn import furthest_point_sample
+        pts = (pcs.transpose(1, 2) * (0.05 / 0.12)).contiguous()
+        c1 = furthest_point_sample(pts, 512)
+        c2 = furthest_point_sample(c1, 128)
+        f1 = torch.randn(B, 128, 512, device=dev)
+        Ns, Ms, Us, Cs = 512, 128, 64, 128
+        grouped = torch.empty(B, 3 + Cs, Ms, Us, device=dev)
+        st = L.current_stream(dev)
+        sa = lambda: L.call("gldm_sa_group", L.ptr(c1), L.ptr(c2), L.ptr(f1), B, Cs, Ns, Ms, 0.4, Us, L.ptr(grouped),
+                            None, st)
+        sa()
+        t_sa = event_time(sa, 10)
+        by = B * (12 * Ns + 4 * Cs * Ns + 12 * Ms + 4 * (Cs + 3) * Ms * Us)
+        kernels.append(dict(kernel="sa_group_kernel (PointNet2SSG SA2 gather: N=512 M=128 U=64 C=128)", bound="hbm",
+                            avg_ms=t_sa * 1e3, achieved=by / t_sa / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=by / t_sa / 1e9 / PEAK_HBM_GBS, algorithmic_bytes_per_launch=by))
+        # ---- CPU baseline: the torch-CPU oracle on this box's host cores, bounded sample
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            # separate CPU-only process (bounded: 8 clouds x G grasps, full S steps, <= 16 threads:
+            # the oracle's ~110 small ops per step do not scale past a few cores)
+            import subprocess
+            threads = min(os.cpu_count() or 1, 16)
+            cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--clouds", "8", "--grasps", str(G), "--points", str(N),
+                   "--ddim-steps", str(S), "--threads", str(threads)]
+            try:
+                r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
+                rec = json.loads(r.stdout.strip().splitlines()[-1])
+                cpu = dict(value=rec["grasps"] / rec["seconds"], unit="grasps/s", cores=rec["threads"], kind="port",
+                           sample=f"8 clouds x {G} grasps, N={N}, {S} DDIM steps, torch-CPU oracle "
+                                  f"(oracle/torch_ref.py + oracle/point_ops.c), {rec['seconds']:.1f} s of "
+                                  f"{os.cpu_count()} host cores' box")
+            except Exception as e:  # noqa: BLE001
+                cpu = dict(value=None, unit="grasps/s", cores=threads, kind="port", sample=f"failed: {e!r}"[:200])
+        out = dict(metric="grasps/sec whole-node (1024-pt cloud, 100 DDIM steps)", value=grasps_per_s,
+                   unit="grasps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=f"LDM mode, {B} synthetic {N}-pt clouds per GPU x {G} grasps, {S} DDIM steps "
+                                        "(BASELINE.json configs[2]; configs[3] at 8 GPUs)",
+                               clouds_per_gpu=B, grasps_per_cloud=G, points=N, ddim_steps=S,
+                               encoder="PVCNNEncoder (shipped fpc config)", parallelism=f"cloud-sharded x{world}",
+                               weights="synthetic recipe seed 0"),
+                   roofline=roof, cpu_baseline=cpu, kernels=kernels)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

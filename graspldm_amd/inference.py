@@ -1,0 +1,197 @@
+"""Inference harness: mirror of `tools/inference.py` (Experiment :97-158, InferenceLDM
+:401-666, InferenceVAE :669-815, unnormalize_* :31-94) for the generation path.
+
+Differences, all additive or documented:
+  * a model can be injected directly (`model=`) so the path runs without an experiment
+    directory (no ACRONYM data / checkpoints exist offline); datasets are out of scope,
+    inputs follow the dataset item contract produced by graspldm_amd.synthetic;
+  * `num_inference_steps` is honoured (the reference's CLI ignores `--inference_steps`
+    because it passes use_fast_sampler=False: tools/generate_grasps.py:69-79);
+  * unnormalise + tmrp_to_H + sigmoid are one HIP launch (gldm_pose_epilogue).
+"""
+import glob
+import os
+import warnings
+from enum import Enum
+
+import torch
+
+from .builder import build_model_from_cfg
+from .config import Config
+from .r1d import pose_epilogue
+
+PC_STD, MRP_STD = 0.05, 0.5
+
+
+class Conditioning(Enum):
+    UNCONDITIONAL = "NORMAL"
+    CLASS_CONDITIONED = "CLASS_CONDITIONED"
+    REGION_CONDITIONED = "REGION_CONDITIONED"
+
+
+class ModelType(Enum):
+    LDM = "LDM"
+    VAE = "VAE"
+
+
+def fix_state_dict_prefix(state_dict, prefix="model", ignore_all_others=False):
+    """grasp_ldm/utils/torch_utils.py:4-37: strip `model.` / `ema_model.online_model.`."""
+    items = [(k, v) for k, v in state_dict.items() if not ignore_all_others or k.startswith(prefix)]
+    return type(state_dict)((k.partition(f"{prefix}.")[2], v) for k, v in items)
+
+
+def unnormalize_pc(pc, metas):
+    if pc.ndim == 2:
+        return pc * metas["pc_std"].to(pc.device) + metas["pc_mean"].to(pc.device)
+    return pc * metas["pc_std"].unsqueeze(-2).to(pc.device) + metas["pc_mean"].unsqueeze(-2).to(pc.device)
+
+
+class Experiment:
+    """Experiment directory layout: {root}/{name}/{mode}/*.py + {mode}/checkpoints/last.ckpt."""
+
+    def __init__(self, exp_name, exp_out_root="output", modes=("vae", "ddm"), vae_ckpt_path=None,
+                 ddm_ckpt_path=None, **_):
+        self.exp_name = exp_name
+        self.exp_dir = os.path.join(exp_out_root, exp_name)
+        self._modes = list(modes)
+        if not os.path.isdir(self.exp_dir):
+            raise FileNotFoundError(f"No experiment directory `{exp_name}` found in `{exp_out_root}/`")
+        self._config_paths = {m: glob.glob(f"{self.exp_dir}/{m}/*.py") for m in self._modes}
+        manual = dict(vae=vae_ckpt_path, ddm=ddm_ckpt_path)
+        self._ckpt_paths = {}
+        for m in self._modes:
+            path = manual.get(m) if manual.get(m) and os.path.isfile(manual[m]) else f"{self.exp_dir}/{m}/checkpoints/last.ckpt"
+            if not os.path.isfile(path):
+                raise FileNotFoundError(f"For given mode ({m}) in `modes`:Could not find any checkpoint in ckpt path: {path}")
+            self._ckpt_paths[m] = path
+
+    def get_config(self, mode):
+        assert mode in self._modes, f"Could not find mode ({mode}) in experiment modes "
+        return Config.fromfile(self._config_paths[mode][0])
+
+    def get_ckpt_path(self, mode):
+        return self._ckpt_paths[mode]
+
+
+def _load_weights(model, ckpt_path, use_ema_model):
+    sd = torch.load(ckpt_path, map_location="cpu")["state_dict"]
+    prefix = "model" if not use_ema_model else "ema_model.online_model"
+    sd = fix_state_dict_prefix(sd, prefix, ignore_all_others=True)
+    try:
+        model.load_state_dict(sd, strict=True)
+    except Exception as e:
+        msg = "Error while loading state dict: You might be using an incompatible state dict. \n"
+        if use_ema_model:
+            msg += "EMA model is requested but may not be available. Check and set the `use_ema_model` flag appropriately. \n"
+        raise RuntimeError(msg + f"Error: {e}")
+    return model
+
+
+class _InferenceBase:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("graspldm_amd runs on the GPU only (no CPU path)")
+        self.model = None
+        self.dataset = None
+
+    def _results(self, pc, metas, tmrp, cls_logit, num_pcs, num_grasps, all_steps=()):
+        metas = {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in metas.items()}
+        mean, std = metas["grasp_mean"].reshape(-1, 6), metas["grasp_std"].reshape(-1, 6)
+        if mean.shape[0] == 1 and num_pcs > 1:
+            mean, std = mean.expand(num_pcs, 6), std.expand(num_pcs, 6)
+        H, un, conf = pose_epilogue(tmrp, cls_logit, mean, std, num_grasps)
+        return dict(grasps=H.view(num_pcs, num_grasps, 4, 4), grasp_tmrp=un.view(num_pcs, num_grasps, 6),
+                    confidence=conf.view(num_pcs, num_grasps, 1), qualities=None, pc=unnormalize_pc(pc, metas),
+                    all_steps_grasps=list(all_steps))
+
+    def infer(self, data_idx=None, num_grasps=10, visualize=False, condition_type=Conditioning.UNCONDITIONAL,
+              conditioning=None, **kwargs):
+        if self.dataset is None:
+            raise RuntimeError("no dataset attached: ACRONYM loading is out of scope; call generate_grasps(pc, metas) "
+                               "with a dataset-contract item (graspldm_amd.synthetic.normalize_cloud)")
+        if condition_type != Conditioning.UNCONDITIONAL:
+            raise NotImplementedError("class / region conditioned denoisers are not shipped (out of scope)")
+        item = self.dataset[data_idx if data_idx is not None else 0]
+        res = self.generate_grasps(item["pc"], item["metas"], num_grasps=num_grasps, **kwargs)
+        res["inputs"] = dict(item)
+        return res
+
+
+class InferenceLDM(_InferenceBase):
+    def __init__(self, exp_name=None, exp_out_root=None, data_root=None, data_split="test", use_ema_model=True,
+                 ddm_ckpt_path=None, vae_ckpt_path=None, elucidated_ckpt_path=None, use_elucidated=False,
+                 use_fast_sampler=True, num_inference_steps=None, augment_pc=False, load_dataset=False,
+                 device="cuda:0", model=None):
+        super().__init__(device)
+        if use_elucidated:
+            raise NotImplementedError("ElucidatedDiffusion / DPM++ is not enabled by any shipped config")
+        self.use_ema_model = use_ema_model
+        self.fast_sampler = "DDIM" if use_fast_sampler else None
+        self.num_inference_steps = (100 if num_inference_steps is None else num_inference_steps) if use_fast_sampler \
+            else num_inference_steps
+        if model is not None:
+            self.model = model.to(self.device).eval()
+        else:
+            self.experiment = Experiment(exp_name, exp_out_root, modes=["ddm"], ddm_ckpt_path=ddm_ckpt_path)
+            self.config = self.experiment.get_config("ddm")
+            key = "model" if "model" in self.config else "models"  # old configs use `models`
+            if use_fast_sampler:
+                self.config[key]["ddm"]["model"]["args"]["noise_scheduler_type"] = "ddim"
+            m = build_model_from_cfg(self.config[key]["ddm"])
+            m.set_vae_model(build_model_from_cfg(self.config[key]["vae"]))
+            self.model = _load_weights(m, self.experiment.get_ckpt_path("ddm"), use_ema_model).to(self.device).eval()
+        if load_dataset:
+            warnings.warn("ACRONYM dataset loading is out of scope; use generate_grasps(pc, metas)")
+
+    PC_MEAN = torch.zeros(3)
+
+    def normalize_input(self, pc):
+        """tools/inference.py:570-591: centre on the mean, divide by 0.05, build metas."""
+        assert pc.ndim in (2, 3)
+        pc = pc.clone()
+        mean = pc.mean(dim=-2)
+        pc = (pc - (mean.unsqueeze(1) if pc.ndim == 3 else mean)) / PC_STD
+        gm = torch.zeros(mean.reshape(-1, 3).shape[0], 6, device=pc.device)
+        gm[:, :3] = mean.reshape(-1, 3)
+        std = torch.tensor([PC_STD] * 3 + [MRP_STD] * 3, device=pc.device).unsqueeze(0)
+        metas = dict(pc_mean=mean.reshape(-1, 3), pc_std=torch.full((1, 3), PC_STD, device=pc.device),
+                     grasp_mean=gm, grasp_std=std, dataset_normalized=True)
+        return pc, metas
+
+    @torch.no_grad()
+    def generate_grasps(self, pc, metas, num_grasps=10, return_intermediate=False, x_T=None, **kwargs):
+        batch = (pc.unsqueeze(0) if pc.ndim == 2 else pc).to(self.device)
+        if self.num_inference_steps is not None:
+            self.model.set_inference_timesteps(self.num_inference_steps)
+        (tmrp, logit), steps = self.model.generate_grasps(batch, num_grasps=num_grasps,
+                                                          return_intermediate=return_intermediate, x_T=x_T)
+        return self._results(batch, metas, tmrp, logit, batch.shape[0], num_grasps)
+
+    def infer_on_pointcloud(self, pc, num_grasps=10, return_intermediate=False):
+        pcn, metas = self.normalize_input(pc.to(self.device))
+        return self.generate_grasps(pcn, metas, num_grasps=num_grasps, return_intermediate=return_intermediate)
+
+
+class InferenceVAE(_InferenceBase):
+    def __init__(self, exp_name=None, exp_out_root=None, use_ema_model=True, data_root=None, data_split="test",
+                 ddm_ckpt_path=None, vae_ckpt_path=None, augment_pc=False, load_dataset=False, device="cuda:0",
+                 model=None):
+        super().__init__(device)
+        self.use_ema_model = use_ema_model
+        if model is not None:
+            self.model = model.to(self.device).eval()
+        else:
+            self.experiment = Experiment(exp_name, exp_out_root, modes=["vae"], vae_ckpt_path=vae_ckpt_path)
+            self.config = self.experiment.get_config("vae")
+            key = "model" if "model" in self.config else "models"
+            m = build_model_from_cfg(self.config[key]["vae"])
+            self.model = _load_weights(m, self.experiment.get_ckpt_path("vae"), use_ema_model).to(self.device).eval()
+
+    @torch.no_grad()
+    def generate_grasps(self, pc, metas, num_grasps=10, z_h=None, **kwargs):
+        batch = (pc.unsqueeze(0) if pc.ndim == 2 else pc).to(self.device)
+        tmrp, logit = self.model.generate_grasps(batch, num_grasps, z_h=z_h)
+        out = self._results(batch, metas, tmrp, logit, batch.shape[0], num_grasps)
+        out.pop("all_steps_grasps")
+        return out

@@ -1,0 +1,64 @@
+"""CPU, world_size 2 over gloo: shard / gather bookkeeping of the multi-GPU path
+(graspldm_amd/distributed.py).  The per-shard generator is a stand-in pure function of
+(cloud, noise) -- the HIP path itself needs a GPU -- so this checks that results are
+identical to the single-process run and independent of the world size."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from graspldm_amd.distributed import gather_results, generate_sharded, shard_bounds
+
+
+def _fake_generate(pc, x_T):
+    g = x_T.shape[0] // pc.shape[0]
+    feat = pc.mean(dim=1).repeat_interleave(g, 0)                     # [n, 3]
+    tm = torch.cat([feat + x_T[:, 0, :3], feat * x_T[:, 0, 1:4]], dim=1)
+    return tm, x_T[:, 0, :1] - feat[:, :1]
+
+
+def _worker(rank, world, port, B, G, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    pcs = torch.randn(B, 32, 3, generator=g)
+    x_T = torch.randn(B * G, 1, 4, generator=g)
+    tm, lg = generate_sharded(_fake_generate, pcs, G, x_T)
+    q.put((rank, tm, lg))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [5, 4, 1])
+def test_two_ranks_match_single_process(B):
+    G = 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, G, q)) for r in range(2)]
+    [p.start() for p in procs]
+    outs = [q.get(timeout=120) for _ in range(2)]
+    [p.join(timeout=60) for p in procs]
+    g = torch.Generator().manual_seed(0)
+    pcs = torch.randn(B, 32, 3, generator=g)
+    x_T = torch.randn(B * G, 1, 4, generator=g)
+    tm_ref, lg_ref = _fake_generate(pcs, x_T)
+    for _, tm, lg in outs:
+        assert torch.equal(tm, tm_ref) and torch.equal(lg, lg_ref)
+
+
+def test_shard_bounds_cover_everything():
+    for B in (1, 7, 8, 2048):
+        for W in (1, 2, 4, 8):
+            spans = [shard_bounds(B, W, r) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(hi - lo <= per for lo, hi, per in spans)
+
+
+def test_gather_single_process_is_identity():
+    rows = torch.arange(21.).view(3, 7)
+    assert torch.equal(gather_results(rows, 4, 3), rows)
