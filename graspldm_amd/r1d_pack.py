@@ -22,7 +22,7 @@ SCHED_COEF_STRIDE = 8
 
 class R1dResblock(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("c1_w", "c1_b", "n1_w", "n1_b", "c2_w", "c2_b", "n2_w", "n2_b", "ss_row")]
+                ("c1_w", "c1_b", "n1_w", "n1_b", "c2_w", "c2_b", "n2_w", "n2_b", "ss_w", "ss_b")]
 
 
 class R1dLevel(ctypes.Structure):
@@ -37,7 +37,7 @@ class R1dDesc(ctypes.Structure):
                 ("dims", ctypes.c_int32 * (MAX_LEVELS + 1)),
                 ("emb_dim", ctypes.c_int32), ("cond_rows", ctypes.c_int32), ("groups", ctypes.c_int32),
                 ("init_w", ctypes.c_int32), ("init_b", ctypes.c_int32),
-                ("ss_w", ctypes.c_int32), ("ss_b", ctypes.c_int32), ("ss_rows", ctypes.c_int32),
+                ("ss_rows", ctypes.c_int32),
                 ("rb", R1dResblock * MAX_RESBLOCKS), ("lv", R1dLevel * MAX_LEVELS),
                 ("final_w", ctypes.c_int32), ("final_b", ctypes.c_int32),
                 ("latent_dim", ctypes.c_int32), ("in_w", ctypes.c_int32), ("in_b", ctypes.c_int32),
@@ -118,18 +118,13 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
     d.init_w = buf.add(init_w.reshape(dims[0], 7))
     d.init_b = buf.add(sd[p + "init_conv.bias"])
 
-    ss_w, ss_b, ss_row = [], [], 0
-
     def resblock(q, c, slot):
-        nonlocal ss_row
         rb = d.rb[slot]
         mw, mb = sd[q + "mlp.1.weight"], sd[q + "mlp.1.bias"]          # [2C, E], [2C]
-        ss_w.append(mw)
         comb = cond_rows * mb
         comb[:c] = comb[:c] + cond_rows                                 # sum_r (scale_r + 1)
-        ss_b.append(comb)
-        rb.ss_row = ss_row
-        ss_row += 2 * c
+        rb.ss_w = buf.add(mfma_a_fragments(mw))
+        rb.ss_b = buf.add(comb)
         rb.c1_w = buf.add(mfma_a_fragments(conv_as_gemm(weight_standardize(sd[q + "block1.proj.weight"]))))
         rb.c1_b = buf.add(sd[q + "block1.proj.bias"])
         rb.n1_w = buf.add(sd[q + "block1.norm.weight"])
@@ -168,9 +163,7 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
         raise ValueError("final_conv with one output channel expected (learned variance is off)")
     d.final_w = buf.add(fw.reshape(-1))
     d.final_b = buf.add(sd[p + "final_conv.bias"])
-    d.ss_w = buf.add(torch.cat(ss_w))
-    d.ss_b = buf.add(torch.cat(ss_b))
-    d.ss_rows = ss_row
+    d.ss_rows = 2 * max(dims)
 
     if decoder is not None:
         if decoder["in_w"].shape[0] != seq_len:

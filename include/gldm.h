@@ -127,7 +127,8 @@ typedef struct gldm_r1d_resblock {
   int32_t n1_w, n1_b;   /* block1.norm  gamma/beta [C]                            */
   int32_t c2_w, c2_b;   /* block2.proj                                            */
   int32_t n2_w, n2_b;   /* block2.norm                                            */
-  int32_t ss_row;       /* first row of this block in the scale/shift table       */
+  int32_t ss_w, ss_b;   /* mlp.1 as a [2C x E] GEMM (packed A fragments) and the
+                           combined bias R*b (+R on the C scale rows): [2C]       */
 } gldm_r1d_resblock;
 
 typedef struct gldm_r1d_level {
@@ -146,9 +147,8 @@ typedef struct gldm_r1d_desc {
   int32_t cond_rows;    /* R: rows of the conditioning latent (3), 1 if 2-D       */
   int32_t groups;       /* GroupNorm groups (resnet_block_groups)                 */
   int32_t init_w, init_b; /* init_conv [C0][7], [C0]                              */
-  int32_t ss_w, ss_b;   /* all ResnetBlock.mlp.1 stacked: [ss_rows][E]; combined
-                           bias R*b (+R on scale rows): [ss_rows]                 */
-  int32_t ss_rows;
+  int32_t ss_rows;      /* 2 * max(dims): rows of the per-workgroup scale/shift
+                           scratch                                                */
   gldm_r1d_resblock rb[GLDM_R1D_MAX_RESBLOCKS]; /* 2 per level, then final        */
   gldm_r1d_level lv[GLDM_R1D_MAX_LEVELS];
   int32_t final_w, final_b; /* final_conv [dims[n_levels]], [1]                   */
