@@ -199,7 +199,7 @@ __device__ __forceinline__ void gemm_small(const Ctx &c, const float *__restrict
 
 template <int MT, int NT>
 __device__ __forceinline__ void store_tiles(const Ctx &c, const f32x4 (&acc)[MT][NT], int mt0, int nt0, float *dst,
-                                            int cout, const float *__restrict__ bias) {
+                                            int cout, const float *__restrict__ bias, int act) {
   const int col = c.lane & 15, kq = c.lane >> 4;
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
@@ -209,7 +209,10 @@ __device__ __forceinline__ void store_tiles(const Ctx &c, const f32x4 (&acc)[MT]
       const float bv = bias ? bias[row < cout ? row : cout - 1] : 0.f;
       if (row < cout) {
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) dst[swz(row, 16 * (nt0 + ni) + col)] = acc[mi][ni][r] + bv;
+        for (int ni = 0; ni < NT; ++ni) {
+          const float v = acc[mi][ni][r] + bv;
+          dst[swz(row, 16 * (nt0 + ni) + col)] = act ? fmaxf(v, 0.f) : v;
+        }
       }
     }
   }
@@ -218,7 +221,7 @@ __device__ __forceinline__ void store_tiles(const Ctx &c, const f32x4 (&acc)[MT]
 template <int L, int MT, int NT>
 __device__ __forceinline__ void gemm_fixed(const Ctx &c, const float *wp, int mt0, int nt0, bool active,
                                            const float *src, int cin, int ktaps, float *dst, int cout,
-                                           const float *bias, bool alias) {
+                                           const float *bias, bool alias, int act) {
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi)
@@ -233,7 +236,7 @@ __device__ __forceinline__ void gemm_fixed(const Ctx &c, const float *wp, int mt
     }
   }
   if (alias) __syncthreads();
-  if (active) store_tiles<MT, NT>(c, acc, mt0, nt0, dst, cout, bias);
+  if (active) store_tiles<MT, NT>(c, acc, mt0, nt0, dst, cout, bias, act);
 }
 
 // dst[cout][64] = W * im2col(src[cin][64]) + bias.  Ends with a barrier.
@@ -241,24 +244,24 @@ __device__ __forceinline__ void gemm_fixed(const Ctx &c, const float *wp, int mt
 // Output widths are 16 x {1, 2, 4, 8, 12, 16} rows (validate() enforces it).
 template <int L>
 __device__ __noinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, const float *src, int cin, int ktaps,
-                                       float *dst, int cout, bool alias) {
+                                       float *dst, int cout, bool alias, int act = 0) {
   if (c.skip & 8) return;
   const float *wp = c.w + w_off;
   const float *bias = b_off >= 0 ? c.w + b_off : nullptr;
   const int mtiles = (cout + 15) >> 4;
   const int w = c.wave;
   if (mtiles == 16) {
-    gemm_fixed<L, 2, 4>(c, wp, 2 * w, 0, true, src, cin, ktaps, dst, cout, bias, alias);
+    gemm_fixed<L, 2, 4>(c, wp, 2 * w, 0, true, src, cin, ktaps, dst, cout, bias, alias, act);
   } else if (mtiles == 12) {
-    gemm_fixed<L, 3, 2>(c, wp, 3 * (w & 3), 2 * (w >> 2), true, src, cin, ktaps, dst, cout, bias, alias);
+    gemm_fixed<L, 3, 2>(c, wp, 3 * (w & 3), 2 * (w >> 2), true, src, cin, ktaps, dst, cout, bias, alias, act);
   } else if (mtiles == 8) {
-    gemm_fixed<L, 1, 4>(c, wp, w, 0, true, src, cin, ktaps, dst, cout, bias, alias);
+    gemm_fixed<L, 1, 4>(c, wp, w, 0, true, src, cin, ktaps, dst, cout, bias, alias, act);
   } else if (mtiles == 4) {
-    gemm_fixed<L, 1, 2>(c, wp, w & 3, 2 * (w >> 2), true, src, cin, ktaps, dst, cout, bias, alias);
+    gemm_fixed<L, 1, 2>(c, wp, w & 3, 2 * (w >> 2), true, src, cin, ktaps, dst, cout, bias, alias, act);
   } else if (mtiles == 2) {
-    gemm_fixed<L, 1, 1>(c, wp, w & 1, w >> 1, true, src, cin, ktaps, dst, cout, bias, alias);
+    gemm_fixed<L, 1, 1>(c, wp, w & 1, w >> 1, true, src, cin, ktaps, dst, cout, bias, alias, act);
   } else {
-    gemm_fixed<L, 1, 1>(c, wp, 0, w & 3, w < 4, src, cin, ktaps, dst, cout, bias, alias);
+    gemm_fixed<L, 1, 1>(c, wp, 0, w & 3, w < 4, src, cin, ktaps, dst, cout, bias, alias, act);
   }
   __syncthreads();
 }
@@ -771,6 +774,71 @@ __global__ void pose_epilogue_kernel(const float *__restrict__ tmrp, const float
 }
 #pragma clang fp contract(fast)
 
+
+// ====================================================================== fused SA ==
+// PointNetSAModule core (ext/pvcnn/modules/pointnet.py:100-111 without the FPS):
+//   grouped = cat(p[idx] - centre, f[idx])          (BallQuery.forward)
+//   out[b, :, j] = max_k  SharedMLP2d(grouped)[b, :, j, k]
+// One workgroup = one 64-column tile = 64/U centres x U neighbours.  The grouped tensor
+// ([B, 3+C, M, U], 4.3 MB per cloud at SSG-SA2) never exists in HBM: the neighbour tile is
+// gathered straight into LDS, the MLP layers (BatchNorm folded, ReLU) run on the same
+// f32-MFMA GEMM core as the ResNet1D engine with weights streamed from L2, and the max
+// over the U neighbours is taken on chip.  HBM traffic: 12N + 4CN + 12M + 4MU (idx)
+// in, 4 Cout M out per cloud.
+struct SaArgs {
+  const float *points, *centers, *feat;
+  const int32_t *idx;
+  const float *weights;
+  float *out;
+  int c, n, m, u, n_layers;
+  int cin_pad[4], cout[4], w_off[4], b_off[4];
+};
+
+__global__ __launch_bounds__(kThreads, 2) void sa_mlp_kernel(const SaArgs a) {
+  extern __shared__ float lds[];
+  Ctx c{a.weights, lds, (int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, 0};
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const int cpt = kCols / a.u;                 // centres per tile
+  const int j0 = tile * cpt;
+  const float *pts = a.points + (size_t)b * 3 * a.n;
+  const float *ctr = a.centers + (size_t)b * 3 * a.m;
+  const float *feat = a.feat ? a.feat + (size_t)b * a.c * a.n : nullptr;
+  const int32_t *idx = a.idx + ((size_t)b * a.m + j0) * a.u;
+  float *X = lds + kBufX, *H = lds + kBufH;
+  // ---- gather the neighbour tile: rows 0..2 relative coords, 3..3+C features, zero pad
+  {
+    const int col = c.lane, jj = col / a.u;
+    const bool live = j0 + jj < a.m;
+    const int id = live ? idx[col] : 0;
+    const int rows = a.cin_pad[0];
+    for (int r = c.wave; r < rows; r += kWaves) {
+      float v = 0.f;
+      if (live) {
+        if (r < 3) v = pts[r * a.n + id] - ctr[r * a.m + j0 + jj];
+        else if (r < 3 + a.c) v = feat[(size_t)(r - 3) * a.n + id];
+      }
+      X[swz(r, col)] = v;
+    }
+  }
+  __syncthreads();
+  // ---- grouped MLP (1x1 convs + folded BN + ReLU), ping-pong X <-> H
+  float *src = X, *dst = H;
+  for (int l = 0; l < a.n_layers; ++l) {
+    conv_gemm<16>(c, a.w_off[l], a.b_off[l], src, a.cin_pad[l], 1, dst, a.cout[l], false, 1);
+    float *t = src; src = dst; dst = t;
+  }
+  // ---- max over the U neighbours of each centre
+  const int cout = a.cout[a.n_layers - 1];
+  float *out = a.out + (size_t)b * cout * a.m;
+  for (int i = c.tid; i < cout * cpt; i += kThreads) {
+    const int row = i / cpt, jj = i - row * cpt;
+    if (j0 + jj >= a.m) continue;
+    float mx = -3.0e38f;
+    for (int k = 0; k < a.u; ++k) mx = fmaxf(mx, src[swz(row, jj * a.u + k)]);
+    out[(size_t)row * a.m + j0 + jj] = mx;
+  }
+}
+
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 int validate(const gldm_r1d_desc *d) {
@@ -884,5 +952,40 @@ GLDM_API int gldm_pose_epilogue(const float *tmrp, const float *logit, const flo
   if (confidence && !logit) return GLDM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(pose_epilogue_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      tmrp, logit, grasp_mean, grasp_std, n, grasps_per_cloud, H, tmrp_unnorm, confidence);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_sa_mlp_forward(const float *points, const float *centers, const float *features,
+                                 const int32_t *idx, const float *weights, int b, int c, int n, int m, int u,
+                                 int n_layers, const int32_t *cin_pad, const int32_t *cout, const int32_t *w_off,
+                                 const int32_t *b_off, float *out, gldm_stream_t stream) {
+  if (!points || !centers || !idx || !weights || !out || !cin_pad || !cout || !w_off || !b_off || b <= 0 || c < 0 ||
+      n <= 0 || m <= 0 || u <= 0)
+    return GLDM_ERR_INVALID_ARG;
+  if (c > 0 && !features) return GLDM_ERR_INVALID_ARG;
+  if (n_layers < 1 || n_layers > 4) return GLDM_ERR_UNSUPPORTED;
+  if (u > kCols || (kCols % u) != 0) return GLDM_ERR_UNSUPPORTED;
+  SaArgs a{};
+  a.points = points; a.centers = centers; a.feat = c > 0 ? features : nullptr; a.idx = idx; a.weights = weights;
+  a.out = out; a.c = c; a.n = n; a.m = m; a.u = u; a.n_layers = n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    const int mt = (cout[l] + 15) >> 4;
+    if (cin_pad[l] <= 0 || (cin_pad[l] & 15) || cin_pad[l] > kMaxC || cout[l] > kMaxC ||
+        !(mt == 1 || mt == 2 || mt == 4 || mt == 8 || mt == 12 || mt == 16) || (cout[l] & 15))
+      return GLDM_ERR_UNSUPPORTED;
+    if (l > 0 && cin_pad[l] != cout[l - 1]) return GLDM_ERR_INVALID_ARG;
+    a.cin_pad[l] = cin_pad[l]; a.cout[l] = cout[l]; a.w_off[l] = w_off[l]; a.b_off[l] = b_off[l];
+  }
+  if (cin_pad[0] < 3 + c) return GLDM_ERR_INVALID_ARG;
+  const size_t lds_bytes = (size_t)(kBufH + kMaxC * kCols) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes);
+    attr = true;
+  }
+  const int cpt = kCols / u;
+  hipLaunchKernelGGL(sa_mlp_kernel, dim3((m + cpt - 1) / cpt, b), dim3(kThreads), lds_bytes,
+                     reinterpret_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }

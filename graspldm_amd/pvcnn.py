@@ -186,12 +186,31 @@ class PointNetSAModule(nn.Module):
         self.groupers = nn.ModuleList(groupers)
         self.mlps = nn.ModuleList(mlps)
 
+    def _fused(self, g, grouper, mlp, coords, centers, features):
+        """ball query -> ONE fused launch (gather + grouped MLP on MFMA + max): the grouped
+        [B, 3+C, M, U] tensor is never materialised."""
+        from .sa_pack import SaMlpPlan
+        plans = self.__dict__.setdefault("_plans", {})
+        key = tuple((p.data_ptr(), p._version) for p in mlp.state_dict(keep_vars=True).values()) + (str(coords.device),)
+        plan = plans.get(g)
+        if plan is None or plan.key_dev != key:
+            plan = SaMlpPlan(mlp, coords.device)
+            plan.key_dev = key
+            plans[g] = plan
+        feats = features.contiguous() if features is not None and features.shape[1] > 0 else None
+        idx = ball_query(centers, coords, grouper.radius, grouper.num_neighbors)
+        return plan.run(coords.contiguous(), centers.contiguous(), feats, idx)
+
     def forward(self, inputs):
+        from .sa_pack import fusable
         features, coords = inputs
         centers = furthest_point_sample(coords, self.num_centers)
         outs = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
-            outs.append(mlp(grouper(coords, centers, features)).max(dim=-1).values)
+        for g, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            if grouper.include_coordinates and not self.training and fusable(mlp, grouper.num_neighbors):
+                outs.append(self._fused(g, grouper, mlp, coords, centers, features))
+            else:  # wide (> 256 channel) or U > 64 stages: gather kernel + GEMMs + max
+                outs.append(mlp(grouper(coords, centers, features)).max(dim=-1).values)
         return (torch.cat(outs, dim=1) if len(outs) > 1 else outs[0]), centers
 
     def extra_repr(self):

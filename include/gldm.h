@@ -203,6 +203,18 @@ int gldm_pose_epilogue(const float *tmrp /*[n,6]*/, const float *logit /*[n]*/, 
                        const float *grasp_std, int n, int grasps_per_cloud, float *H /*[n,4,4]*/,
                        float *tmrp_unnorm /*[n,6]*/, float *confidence /*[n]*/, gldm_stream_t stream);
 
+/* ref: grasp_ldm/models/modules/ext/pvcnn/modules/pointnet.py:100-111 (PointNetSAModule.forward
+ * after FPS + ball query): neighbour gather + grouped SharedMLP2d (Conv2d k1 + eval BatchNorm
+ * folded + ReLU, shared_mlp.py:6-35) + max over the U neighbours, fused; the grouped tensor
+ * never reaches HBM.  `weights` holds, per layer l, the folded weight [cout x cin_pad] in MFMA
+ * A-fragment order at w_off[l] and the folded bias at b_off[l] (graspldm_amd/sa_pack.py);
+ * cin_pad[0] = roundup(3 + c, 16), u must divide 64, cout <= 256. */
+int gldm_sa_mlp_forward(const float *points /*[b,3,n]*/, const float *centers /*[b,3,m]*/,
+                        const float *features /*[b,c,n] or NULL*/, const int32_t *idx /*[b,m,u]*/,
+                        const float *weights, int b, int c, int n, int m, int u, int n_layers,
+                        const int32_t *cin_pad, const int32_t *cout, const int32_t *w_off, const int32_t *b_off,
+                        float *out /*[b,cout_last,m]*/, gldm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,3 +143,27 @@ def test_ddpm_sampler_runs_and_is_seed_reproducible(ldm):
     torch.manual_seed(3); torch.cuda.manual_seed(3)
     b, _ = m.diffusion_model.sample(z_cond=z, batch_size=6, samples_per_cond=3, device="cuda")
     assert torch.equal(a, b) and torch.isfinite(a).all() and a.abs().max() < 10
+
+
+@pytest.mark.parametrize("b,c,n,m,u,chans", [(2, 128, 512, 128, 64, (128, 128, 256)), (3, 0, 1024, 512, 64, (64, 64, 128)),
+                                             (2, 32, 1024, 1024, 32, (32, 64)), (1, 5, 300, 37, 16, (16, 32, 32, 64))])
+def test_fused_sa_mlp_equals_unfused_oracle(b, c, n, m, u, chans):
+    """gldm_sa_mlp_forward (gather + grouped MLP + max, fused) vs the oracle's
+    ball_group -> shared_mlp -> max on the same weights; includes ragged tiles (m*u % 64 != 0)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from graspldm_amd.pvcnn import PointNetSAModule
+    from graspldm_amd.synthetic import load_synthetic_weights
+    from oracle import torch_ref as R
+    mod = PointNetSAModule(num_centers=m, radius=0.35, num_neighbors=u, in_channels=c, out_channels=chans).eval()
+    load_synthetic_weights(mod, seed=11)
+    g = torch.Generator().manual_seed(2)
+    coords = (torch.rand(b, 3, n, generator=g) * 2 - 1).contiguous()
+    feats = torch.randn(b, c, n, generator=g) if c else None
+    sd = {k: v.detach() for k, v in mod.state_dict().items()}
+    exp, ectr = R.sa_module(sd, "", feats, coords, m, [0.35], [u])
+    mod = mod.cuda()
+    with torch.no_grad():
+        got, ctr = mod((feats.cuda() if c else None, coords.cuda()))
+    assert torch.equal(ctr.cpu(), ectr)
+    assert _err(got, exp) < 2e-5, _err(got, exp)
