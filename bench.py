@@ -164,20 +164,36 @@ def main():
         kernels.append(dict(kernel="sa_group_kernel (PointNet2SSG SA2 gather: N=512 M=128 U=64 C=128)", bound="hbm",
                             avg_ms=t_sa * 1e3, achieved=by / t_sa / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
                             frac=by / t_sa / 1e9 / PEAK_HBM_GBS, algorithmic_bytes_per_launch=by))
+        # fused SA module core (gather + grouped MLP + max; the grouped tensor never reaches HBM)
+        from graspldm_amd.pvcnn import PointNetSAModule, ball_query
+        from graspldm_amd.sa_pack import SaMlpPlan
+        from graspldm_amd.synthetic import load_synthetic_weights
+        sa2 = load_synthetic_weights(PointNetSAModule(num_centers=Ms, radius=0.4, num_neighbors=Us, in_channels=Cs,
+                                                      out_channels=(128, 128, 256)).eval(), seed=2).to(dev)
+        plan = SaMlpPlan(sa2.mlps[0], dev)
+        idx = ball_query(c2, c1, 0.4, Us)
+        fsa = lambda: plan.run(c1, c2, f1, idx)
+        fsa()
+        t_fsa = event_time(fsa, 10)
+        sa_flop = B * 2 * Ms * Us * (131 * 128 + 128 * 128 + 128 * 256)
+        kernels.append(dict(kernel="sa_mlp_kernel (SSG SA2 fused gather + MLP 131-128-128-256 + max)", bound="mfma",
+                            avg_ms=t_fsa * 1e3, achieved=sa_flop / t_fsa / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
+                            unit="TFLOP/s", frac=sa_flop / t_fsa / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                            hbm_bytes_avoided=B * 4 * (Cs + 3) * Ms * Us))
         # ---- CPU baseline: the torch-CPU oracle on this box's host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            # separate CPU-only process (bounded: 8 clouds x G grasps, full S steps, <= 16 threads:
+            # separate CPU-only process (bounded: 32 clouds x G grasps, full S steps, <= 16 threads:
             # the oracle's ~110 small ops per step do not scale past a few cores)
             import subprocess
             threads = min(os.cpu_count() or 1, 16)
-            cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--clouds", "8", "--grasps", str(G), "--points", str(N),
+            cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--clouds", "32", "--grasps", str(G), "--points", str(N),
                    "--ddim-steps", str(S), "--threads", str(threads)]
             try:
                 r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
                 rec = json.loads(r.stdout.strip().splitlines()[-1])
                 cpu = dict(value=rec["grasps"] / rec["seconds"], unit="grasps/s", cores=rec["threads"], kind="port",
-                           sample=f"8 clouds x {G} grasps, N={N}, {S} DDIM steps, torch-CPU oracle "
+                           sample=f"32 clouds x {G} grasps, N={N}, {S} DDIM steps, torch-CPU oracle "
                                   f"(oracle/torch_ref.py + oracle/point_ops.c), {rec['seconds']:.1f} s of "
                                   f"{os.cpu_count()} host cores' box")
             except Exception as e:  # noqa: BLE001

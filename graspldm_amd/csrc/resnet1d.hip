@@ -24,6 +24,7 @@
 //   matrix per sample and head) instead of (V K^T) Q: 8x fewer FLOPs, same math.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "gldm.h"
@@ -33,6 +34,8 @@
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef __attribute__((address_space(3))) float lds_f;   // explicit LDS pointers: 32-bit ds_* addressing
+typedef __attribute__((address_space(3))) f32x4 lds_f4;
 
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
@@ -65,6 +68,9 @@ struct Ctx {
   float *lds;
   int tid, wave, lane;
   int skip;
+  long long *dbg;   // diagnostic stamps (GLDM_R1D_STAMP), null in production
+  int *call;
+  int nta;          // active 16-column tiles of this workgroup (4 = full, 1 = tail tile)
 };
 
 // ---------------------------------------------------------------- GEMM ----
@@ -93,68 +99,101 @@ __device__ __forceinline__ float f4_get(const f32x4 &v, int j) { return v[j]; }
 template <int L, int TAPS, int MT, int NT>
 __device__ __forceinline__ void gemm_fast(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0, int nt0,
                                           const float *src, f32x4 (&acc)[MT][NT]) {
+  // k = 3 convs keep one accumulator set per tap: Y_t = W_t X on UNSHIFTED columns, and the
+  // halo shift is applied once to the 16x16 result tiles (out[n] = Y0[n-1] + Y1[n] + Y2[n+1],
+  // lane shifts inside the 16-lane rows of the C/D layout) -- the k-loop is loads + MFMA only.
+  constexpr int PF = (MT * TAPS >= 6) ? 2 : 4;  // weight blocks in flight (register budget)
   const int col = c.lane & 15, kq = c.lane >> 4;
-  const bool keepL = (col & (L - 1)) != 0, keepR = (col & (L - 1)) != (L - 1);
   const int kblocks = TAPS * cblocks;
-  // weights are read through an explicit global-address-space pointer: plain global_load
-  // (vmcnt only) instead of flat_load, so LDS waits and weight prefetch stay independent
-  typedef const __attribute__((address_space(1))) f32x4 *gf4p;
+  typedef const __attribute__((address_space(1))) f32x4 *gf4p;  // plain global_load (vmcnt only)
   gf4p wv = (gf4p)(reinterpret_cast<const f32x4 *>(wp) + c.lane);
-  // LDS address of (row = 4 j + kq, col) inside channel block 0; rows advance by 16 per block
   int boff[4][NT];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) boff[j][ni] = swz(4 * j + kq, 16 * (nt0 + ni) + col);
-  f32x4 a[2][TAPS][MT];
+  f32x4 a[PF][TAPS][MT];
   float b[2][4][NT];
-  auto load = [&](int buf, int cb) {
+  f32x4 side[TAPS > 1 ? 2 : 1][MT][NT];  // tap 0 and tap 2 partial results (tap 1 goes to acc)
+  if (TAPS == 3) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) side[t][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto load_a = [&](int buf, int cb) {
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) a[buf][t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks + cb) * 64];
-    const float *s = src + cb * 16 * kCols;
+  };
+  const lds_f *src3 = (const lds_f *)src;
+  auto load_b = [&](int buf, int cb) {
+    const lds_f *s = src3 + cb * 16 * kCols;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) b[buf][j][ni] = s[boff[j][ni]];
   };
-  auto compute = [&](int buf) {
+  auto compute = [&](int abuf, int bbuf) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      if (TAPS == 3) {
 #pragma unroll
-      for (int ni = 0; ni < NT; ++ni) {
-        const float bc = b[buf][j][ni];
-        if (TAPS == 3) {
-          const float bl = tap_left<L>(bc, keepL), br = tap_right<L>(bc, keepR);
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int mi = 0; mi < MT; ++mi) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(a[buf][0][mi], j), bl, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(a[buf][TAPS > 1 ? 1 : 0][mi], j), bc, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(a[buf][TAPS > 2 ? 2 : 0][mi], j), br, acc[mi][ni], 0, 0, 0);
-          }
-        } else {
+          for (int ni = 0; ni < NT; ++ni)
+            side[0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][0][mi][j], b[bbuf][j][ni], side[0][mi][ni], 0, 0, 0);
 #pragma unroll
-          for (int mi = 0; mi < MT; ++mi)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(a[buf][0][mi], j), bc, acc[mi][ni], 0, 0, 0);
-        }
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][TAPS > 1 ? 1 : 0][mi][j], b[bbuf][j][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni)
+            side[TAPS > 1 ? 1 : 0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][TAPS > 2 ? 2 : 0][mi][j], b[bbuf][j][ni], side[TAPS > 1 ? 1 : 0][mi][ni], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][0][mi][j], b[bbuf][j][ni], acc[mi][ni], 0, 0, 0);
       }
     }
   };
-  // two-deep software pipeline; sched_barrier pins "issue next block's loads, then compute"
-  load(0, 0);
-  int cb = 0;
-  for (; cb + 2 <= cblocks; cb += 2) {
-    load(1, cb + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (cb + 2 < cblocks) load(0, cb + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(1);
-    __builtin_amdgcn_sched_barrier(0);
+  // loads are UNCONDITIONAL (block index clamped, a redundant re-load at the tail is harmless):
+  // a branch around a load forces s_waitcnt 0 at the join and serialises the pipeline
+  const int last = cblocks - 1;
+#pragma unroll
+  for (int u = 0; u < PF - 1; ++u) load_a(u, u < last ? u : last);
+  load_b(0, 0);
+  for (int cb0 = 0; cb0 < cblocks; cb0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int cb = cb0 + u;
+      if (cb < cblocks) {
+        load_a((u + PF - 1) % PF, cb + PF - 1 < last ? cb + PF - 1 : last);
+        load_b((u + 1) & 1, cb + 1 < last ? cb + 1 : last);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(u, u & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
-  if (cb < cblocks) compute(0);
+  if (TAPS == 3) {
+    const bool keepL = (col & (L - 1)) != 0, keepR = (col & (L - 1)) != (L - 1);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[mi][ni][r] += tap_left<L>(side[0][mi][ni][r], keepL) + tap_right<L>(side[TAPS > 1 ? 1 : 0][mi][ni][r], keepR);
+  }
 }
 
 // Generic path (Cin % 16 != 0: the 4-channel level of the latent denoiser): masked reads.
@@ -206,12 +245,11 @@ __device__ __forceinline__ void store_tiles(const Ctx &c, const f32x4 (&acc)[MT]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * (mt0 + mi) + 4 * kq + r;
-      const float bv = bias ? bias[row < cout ? row : cout - 1] : 0.f;
       if (row < cout) {
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
-          const float v = acc[mi][ni][r] + bv;
-          dst[swz(row, 16 * (nt0 + ni) + col)] = act ? fmaxf(v, 0.f) : v;
+          const float v = acc[mi][ni][r];
+          ((lds_f *)dst)[swz(row, 16 * (nt0 + ni) + col)] = act ? fmaxf(v, 0.f) : v;
         }
       }
     }
@@ -222,11 +260,24 @@ template <int L, int MT, int NT>
 __device__ __forceinline__ void gemm_fixed(const Ctx &c, const float *wp, int mt0, int nt0, bool active,
                                            const float *src, int cin, int ktaps, float *dst, int cout,
                                            const float *bias, bool alias, int act) {
+  // the bias is folded into the accumulator start value (its L2 load overlaps the GEMM)
   f32x4 acc[MT][NT];
+  {
+    const int kq = c.lane >> 4;
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi)
+    for (int mi = 0; mi < MT; ++mi) {
+      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (bias) {
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * (mt0 + mi) + 4 * kq + r;
+          bv[r] = bias[row < cout ? row : cout - 1];
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = bv;
+    }
+  }
   if (active) {
     if ((cin & 15) == 0) {
       if (ktaps == 3) gemm_fast<L, 3, MT, NT>(c, wp, cin >> 4, mt0, nt0, src, acc);
@@ -235,6 +286,7 @@ __device__ __forceinline__ void gemm_fixed(const Ctx &c, const float *wp, int mt
       gemm_small<L, MT, NT>(c, wp, (ktaps * cin + 15) >> 4, mt0, nt0, src, cin, ktaps, acc);
     }
   }
+  if (c.dbg && c.lane == 0) c.dbg[(*c.call * 8 + c.wave) * 4 + 1] = (long long)__builtin_readcyclecounter();
   if (alias) __syncthreads();
   if (active) store_tiles<MT, NT>(c, acc, mt0, nt0, dst, cout, bias, act);
 }
@@ -246,11 +298,33 @@ template <int L>
 __device__ __noinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, const float *src, int cin, int ktaps,
                                        float *dst, int cout, bool alias, int act = 0) {
   if (c.skip & 8) return;
+  // arguments of a non-inlined device function arrive in VGPRs: make the wave-uniform ones
+  // scalar again so loop bounds and address bases stay on the SALU
+  w_off = __builtin_amdgcn_readfirstlane(w_off);
+  b_off = __builtin_amdgcn_readfirstlane(b_off);
+  cin = __builtin_amdgcn_readfirstlane(cin);
+  ktaps = __builtin_amdgcn_readfirstlane(ktaps);
+  cout = __builtin_amdgcn_readfirstlane(cout);
+  act = __builtin_amdgcn_readfirstlane(act);
+  {
+    const int so = __builtin_amdgcn_readfirstlane((int)(src - c.lds)), dd = __builtin_amdgcn_readfirstlane((int)(dst - c.lds));
+    src = c.lds + so;
+    dst = c.lds + dd;
+  }
   const float *wp = c.w + w_off;
   const float *bias = b_off >= 0 ? c.w + b_off : nullptr;
   const int mtiles = (cout + 15) >> 4;
   const int w = c.wave;
-  if (mtiles == 16) {
+  if (c.dbg && c.lane == 0) {
+    c.dbg[(*c.call * 8 + c.wave) * 4 + 0] = (long long)__builtin_readcyclecounter();
+    c.dbg[(*c.call * 8 + c.wave) * 4 + 3] = ((long long)cout << 32) | ((long long)cin << 8) | ktaps;
+  }
+  if (c.nta == 1) {
+    // tail workgroup: only columns 0..15 are live -> one n-tile, m-tiles spread over the waves
+    if (mtiles == 16) gemm_fixed<L, 2, 1>(c, wp, 2 * w, 0, true, src, cin, ktaps, dst, cout, bias, alias, act);
+    else if (mtiles == 12) gemm_fixed<L, 2, 1>(c, wp, 2 * (w < 6 ? w : 0), 0, w < 6, src, cin, ktaps, dst, cout, bias, alias, act);
+    else gemm_fixed<L, 1, 1>(c, wp, w < mtiles ? w : 0, 0, w < mtiles, src, cin, ktaps, dst, cout, bias, alias, act);
+  } else if (mtiles == 16) {
     gemm_fixed<L, 2, 4>(c, wp, 2 * w, 0, true, src, cin, ktaps, dst, cout, bias, alias, act);
   } else if (mtiles == 12) {
     gemm_fixed<L, 3, 2>(c, wp, 3 * (w & 3), 2 * (w >> 2), true, src, cin, ktaps, dst, cout, bias, alias, act);
@@ -264,6 +338,8 @@ __device__ __noinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, const
     gemm_fixed<L, 1, 1>(c, wp, 0, w & 3, w < 4, src, cin, ktaps, dst, cout, bias, alias, act);
   }
   __syncthreads();
+  if (c.dbg && c.lane == 0) c.dbg[(*c.call * 8 + c.wave) * 4 + 2] = (long long)__builtin_readcyclecounter();
+  if (c.dbg) ++*c.call;
 }
 
 // ----------------------------------------------------------- GroupNorm ----
@@ -528,6 +604,8 @@ struct RunArgs {
   float *out1;            // decode: logit [n]
   float *ws;              // [tiles][ss_rows][S]
   int skip;               // diagnostic phase-skip mask (GLDM_R1D_SKIP env; 0 in production)
+  long long *dbg;         // diagnostic per-GEMM stamps (GLDM_R1D_STAMP env)
+  int full_tiles, tail_tiles, tail_samples;
 };
 
 // scale/shift rows of one ResnetBlock: ss[row][s] = Wmlp[row,:] . G[s,:] + (R b + R on scale rows),
@@ -617,19 +695,29 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
   extern __shared__ float lds[];
   const gldm_r1d_desc &d = a.d;
   constexpr int S = kCols / L;
-  Ctx c{a.weights, lds, (int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, a.skip};
+  int call_idx = 0;
+  Ctx c{a.weights, lds, (int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, a.skip,
+        blockIdx.x == 0 ? a.dbg : nullptr, &call_idx, 4};
+  // Tiles: the first `full_tiles` workgroups own S samples each; the remainder of the batch is
+  // spread over `tail_tiles` workgroups of `tail_samples` (one 16-column n-tile when it fits)
+  // so that the last wave of workgroups is not 64-column tiles on a quarter of the CUs.
   const int tile = blockIdx.x;
-  const int samp0 = tile * S;
+  const bool is_tail = tile >= a.full_tiles;
+  const int samp0 = is_tail ? a.full_tiles * S + (tile - a.full_tiles) * a.tail_samples : tile * S;
+  c.nta = (is_tail && a.tail_samples * L <= 16) ? 1 : 4;
+  const int nsamp = is_tail ? a.tail_samples : S;  // samples this workgroup owns
   const int E = d.emb_dim, R = d.cond_rows;
   float *lat = lds + kMiscLat, *epsr = lds + kMiscEps, *G = lds + kMiscG;
   float *X = lds + kBufX;
   float *ss_tile = a.ws + (size_t)tile * d.ss_rows * S;  // [2 Cmax][S], reused by every ResnetBlock
   const bool has_in = d.latent_dim > 0, has_head = d.n_head > 0;
 
+  for (int i = c.tid; i < kLdsFloats; i += kThreads) lds[i] = 0.f;  // dead columns must stay finite
+  __syncthreads();
   // ---- latent row for this tile
   if (c.tid < kCols) {
     const int s = c.tid / L, l = c.tid % L;
-    const int gi = min(samp0 + s, a.n_samples - 1);
+    const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
     float v;
     if (has_in) {
       const float *wi = a.weights + d.in_w + l * d.latent_dim;
@@ -643,10 +731,11 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
   __syncthreads();
 
   for (int step = 0; step < a.n_steps; ++step) {
+    call_idx = 0;
     // ---- G[s][e] = sum_r silu(temb[t][e] + cemb[cond][r][e])
     for (int i = c.tid; i < S * E; i += kThreads) {
       const int s = i / E, e = i - s * E;
-      const int gi = min(samp0 + s, a.n_samples - 1);
+      const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
       const float *ce = a.cemb + ((size_t)(gi / a.samples_per_cond) * R) * E + e;
       float te = 0.f;
       if (a.temb) {
@@ -699,7 +788,7 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
         epsr[c.tid] = e;
         if (a.sched_kind != GLDM_SCHED_NONE) {
           const int s = c.tid / L, l = c.tid % L;
-          const int gi = min(samp0 + s, a.n_samples - 1);
+          const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
           const float *cf = a.sched_coef + (size_t)step * GLDM_SCHED_COEF_STRIDE;
           float nz = 0.f;
           if (a.sched_kind == GLDM_SCHED_DDPM && cf[7] != 0.f && a.step_noise)
@@ -716,7 +805,7 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
     if (c.tid < kCols) {
       const int s = c.tid / L, l = c.tid % L;
       const int gi = samp0 + s;
-      if (gi < a.n_samples) a.out0[(size_t)gi * L + l] = a.sched_kind == GLDM_SCHED_NONE ? epsr[c.tid] : lat[c.tid];
+      if (s < nsamp && gi < a.n_samples) a.out0[(size_t)gi * L + l] = a.sched_kind == GLDM_SCHED_NONE ? epsr[c.tid] : lat[c.tid];
     }
   } else {
     // heads: rows 0..5 tmrp, row 6 class logit; input = the L-vector of each sample
@@ -724,7 +813,7 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
     if (c.tid < S * nh) {
       const int s = c.tid / nh, r = c.tid - s * nh;
       const int gi = samp0 + s;
-      if (gi < a.n_samples) {
+      if (s < nsamp && gi < a.n_samples) {
         const float *wr = a.weights + d.head_w + r * L;
         float acc = a.weights[d.head_b + r];
         for (int l = 0; l < L; ++l) acc += wr[l] * epsr[s * L + l];
@@ -796,7 +885,7 @@ struct SaArgs {
 
 __global__ __launch_bounds__(kThreads, 2) void sa_mlp_kernel(const SaArgs a) {
   extern __shared__ float lds[];
-  Ctx c{a.weights, lds, (int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, 0};
+  Ctx c{a.weights, lds, (int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, 0, nullptr, nullptr, 4};
   const int b = blockIdx.y, tile = blockIdx.x;
   const int cpt = kCols / a.u;                 // centres per tile
   const int j0 = tile * cpt;
@@ -859,15 +948,47 @@ int validate(const gldm_r1d_desc *d) {
   return GLDM_OK;
 }
 
+struct Tiling { int full_tiles, tail_tiles, tail_samples; };
+
+Tiling make_tiling(int n_samples, int L) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const int S = kCols / L, unit = 16 / L;  // samples per 64-column tile / per 16-column n-tile
+  const int tiles = (n_samples + S - 1) / S;
+  Tiling t{tiles, 0, 0};
+  if (tiles <= cus || tiles % cus == 0) return t;
+  const int full = (tiles / cus) * cus;
+  const int left = n_samples - full * S;          // < cus * S samples for the last wave of workgroups
+  const int units = (left + unit - 1) / unit;
+  const int upt = (units + cus - 1) / cus;        // n-tiles per tail workgroup (1..4)
+  if (upt >= 4) return t;
+  t.full_tiles = full;
+  t.tail_samples = upt * unit;
+  t.tail_tiles = (left + t.tail_samples - 1) / t.tail_samples;
+  return t;
+}
+
 int launch_r1d(const RunArgs &a_in, hipStream_t s) {
-  const int L = a_in.d.seq_len, S = kCols / L;
-  const int tiles = (a_in.n_samples + S - 1) / S;
+  const int L = a_in.d.seq_len;
+  const Tiling tl = make_tiling(a_in.n_samples, L);
+  const int tiles = tl.full_tiles + tl.tail_tiles;
   const size_t lds_bytes = (size_t)kLdsFloats * sizeof(float);
   RunArgs a = a_in;
+  a.full_tiles = tl.full_tiles; a.tail_tiles = tl.tail_tiles; a.tail_samples = tl.tail_samples;
   {
     const char *e = getenv("GLDM_R1D_SKIP");
     a.skip = e ? atoi(e) : 0;
   }
+  const bool stamp = getenv("GLDM_R1D_STAMP") != nullptr;  // diagnostic: blocks, copies and prints
+  static long long *dbg = nullptr;
+  if (stamp && !dbg) (void)hipMalloc(&dbg, 64 * 8 * 4 * sizeof(long long));
+  a.dbg = stamp ? dbg : nullptr;
+  if (stamp) (void)hipMemset(dbg, 0, 64 * 8 * 4 * sizeof(long long));
   if (L == 4) {
     static bool attr4 = false;
     if (!attr4) {
@@ -884,6 +1005,23 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
       attr16 = true;
     }
     hipLaunchKernelGGL(r1d_kernel<16>, dim3(tiles), dim3(kThreads), lds_bytes, s, a);
+  }
+  if (stamp) {
+    static long long host[64 * 8 * 4];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
+    for (int cidx = 0; cidx < 64 && host[cidx * 32 + 3]; ++cidx) {
+      const long long meta = host[cidx * 32 + 3];
+      long long t0 = host[cidx * 32], lo = 1ll << 62, hi = 0, end = 0;
+      for (int w = 0; w < 8; ++w) {
+        t0 = host[(cidx * 8 + w) * 4] < t0 ? host[(cidx * 8 + w) * 4] : t0;
+        const long long d = host[(cidx * 8 + w) * 4 + 1];
+        if (d) { lo = d < lo ? d : lo; hi = d > hi ? d : hi; }
+        end = host[(cidx * 8 + w) * 4 + 2] > end ? host[(cidx * 8 + w) * 4 + 2] : end;
+      }
+      printf("gemm %2d cout=%3d cin=%3d taps=%d  first wave done %6lld  last wave done %6lld  end %6lld\n", cidx,
+             (int)(meta >> 32), (int)((meta >> 8) & 0xffffff), (int)(meta & 0xff), lo - t0, hi - t0, end - t0);
+    }
   }
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
@@ -902,8 +1040,8 @@ GLDM_API int gldm_r1d_cond_embed(const float *z_cond, const float *w, const floa
 GLDM_API long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples) {
   if (validate(desc) != GLDM_OK || n_samples <= 0) return -1;
   const int S = kCols / desc->seq_len;
-  const long long tiles = (n_samples + S - 1) / S;
-  return tiles * desc->ss_rows * S * (long long)sizeof(float);
+  const Tiling tl = make_tiling(n_samples, desc->seq_len);
+  return (long long)(tl.full_tiles + tl.tail_tiles) * desc->ss_rows * S * (long long)sizeof(float);
 }
 
 GLDM_API int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,

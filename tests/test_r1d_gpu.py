@@ -121,3 +121,23 @@ def test_shared_conditioning_index(engines, fpc_state_dict):
     exp = R.resnet1d_forward(fpc_state_dict, "diffusion_model.model.", x, z_cond=z.repeat_interleave(20, 0), time=t)
     eps = den.denoise(x.cuda(), den.cond_embed(z.cuda()), 20, timesteps=torch.tensor([500], dtype=torch.int32).cuda())
     assert _err(eps, exp) < 2e-5
+
+
+@pytest.mark.parametrize("n", [4096 + 16 * 64, 4096 + 52, 2 * 4096 + 4 * 256 + 3])
+def test_tail_tiling_matches_single_tile_results(engines, n):
+    """More than one wave of workgroups: the tail of the batch runs as small (one n-tile)
+    workgroups.  Every sample must equal what it gets when run alone in a full tile."""
+    from graspldm_amd.r1d import SCHED_DDIM
+    den, _ = engines
+    g = torch.Generator().manual_seed(n)
+    z = torch.randn(7, 3, 64, generator=g).cuda()
+    cemb = den.cond_embed(z)
+    x = torch.randn(n, 1, 4, generator=g).cuda()
+    ts, coef = _ddim_tables(100)
+    ts, coef = ts[:3].cuda(), coef[:3].cuda()
+    spc = (n + 6) // 7
+    full = den.denoise(x, cemb, spc, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
+    probe = torch.tensor([0, 15, 4095, 4096, 4097, n - 53, n - 2, n - 1])
+    for i in probe.tolist():
+        one = den.denoise(x[i:i + 1], cemb[i // spc:i // spc + 1], 1, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
+        assert torch.equal(one[0], full[i]), i

@@ -1,0 +1,15 @@
+"""One fused denoise launch (n latents, s steps) for counter collection."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graspldm_amd.pipeline import build_fpc_ldm
+from graspldm_amd.r1d_pack import SCHED_DDIM
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+dev = torch.device("cuda:0")
+ldm = build_fpc_ldm(device=dev); ldm.set_inference_timesteps(100)
+eng = ldm.diffusion_model.model.engine(dev)
+z = torch.randn(n // 16, 3, 64, device=dev); x = torch.randn(n, 1, 4, device=dev)
+cemb = eng.cond_embed(z); ts, coef = ldm.diffusion_model._schedule(dev)
+for _ in range(2):
+    eng.denoise(x, cemb, 16, timesteps=ts[:steps].contiguous(), sched_kind=SCHED_DDIM, coef=coef[:steps].contiguous())
+torch.cuda.synchronize()
