@@ -35,6 +35,10 @@ _SIGNATURES = {
     "gldm_denoise": [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gldm_decode": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "gldm_pose_epilogue": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "gldm_conv3d_k3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "gldm_groupnorm_swish": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
+    "gldm_se_gate": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "gldm_devoxelize_fused": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "gldm_sa_mlp_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 
@@ -77,6 +81,8 @@ def lib():
         fn.restype = _i
     h.gldm_r1d_workspace_bytes.argtypes = [_vp, _i]
     h.gldm_r1d_workspace_bytes.restype = ctypes.c_longlong
+    h.gldm_conv3d_partial_floats.argtypes = [_i, _i, _i]
+    h.gldm_conv3d_partial_floats.restype = ctypes.c_longlong
     _lib = h
     return h
 

@@ -1,0 +1,342 @@
+// voxel_conv.hip -- the voxel branch of PVConv (ext/pvcnn/modules/pvconv.py:47-84) on gfx950:
+//   Conv3d(k=3, p=1)  as an implicit GEMM on v_mfma_f32_16x16x4_f32   (gldm_conv3d_k3)
+//   GroupNorm(8) + Swish (+ per-channel sums for the SE gate)          (gldm_groupnorm_swish)
+//   SE gate (se.py:12-25)                                              (gldm_se_gate)
+//   trilinear devoxelize x gate + point-branch features                (gldm_devoxelize_fused)
+//
+// conv3d mapping: a workgroup (4 waves) owns a 4 x 4 x r brick of output voxels (16 r outputs =
+// r n-tiles of 16) for ALL output channels.  Per 16-input-channel block the input brick with
+// its one-voxel halo (6 x 6 x (r+2), zero padded at the grid border) is staged in LDS once and
+// serves all 27 taps: a tap is a constant LDS offset, so the k-loop is LDS reads + MFMA only.
+// Weights (fragment order, k = tap * Cin_pad + ci) stream from L2 one tap ahead.  The LDS row
+// stride is = 16 (mod 32) dwords so the 4-row x 16-voxel B-fragment reads are conflict free.
+// Two workgroups fit per CU (62 KiB LDS each): one stages while the other computes.
+// The conv epilogue also emits per-brick per-channel (sum, sum of squares) so GroupNorm needs
+// no extra pass over the tensor for its statistics (combined in f64, fixed order).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gldm.h"
+
+#define GLDM_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef __attribute__((address_space(3))) float lds_f;
+
+constexpr int kConvThreads = 256;
+constexpr int kBrick = 4;  // brick is kBrick x kBrick x r output voxels
+
+__host__ __device__ inline int brick_row_stride(int r) {  // dwords per channel row in LDS, = 16 mod 32
+  const int bv = 6 * 6 * (r + 2);
+  int p = (bv + 31) / 32 * 32 + 16;
+  if (p - 32 >= bv) p -= 32;
+  return p;
+}
+
+template <int MT, int NTW>
+__global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float *__restrict__ x,
+                                                                    const float *__restrict__ wp,
+                                                                    const float *__restrict__ bias, int cin, int cout,
+                                                                    int r, float *__restrict__ y,
+                                                                    float *__restrict__ partial) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 15, kq = lane >> 4;
+  const int bpr = r / kBrick;                       // bricks per axis
+  const int bx0 = (blockIdx.x / bpr) * kBrick, by0 = (blockIdx.x % bpr) * kBrick;
+  const int b = blockIdx.y;
+  const int r3 = r * r * r, zp = r + 2, bv = 36 * zp, bvp = brick_row_stride(r);
+  const int cblocks = (cin + 15) >> 4, kblocks = 27 * cblocks;
+  x += (size_t)b * cin * r3;
+  y += (size_t)b * cout * r3;
+  typedef const __attribute__((address_space(1))) f32x4 *gf4p;
+  gf4p wv = (gf4p)(reinterpret_cast<const f32x4 *>(wp) + lane);
+  const lds_f *l3 = (const lds_f *)lds;
+
+  // output voxel of (n-tile, lane column) in brick coordinates; LDS base of its (0,0,0) tap
+  int obase[NTW], gvox[NTW];
+#pragma unroll
+  for (int ni = 0; ni < NTW; ++ni) {
+    const int o = 16 * (wave * NTW + ni) + col;       // 0 .. 16 r - 1
+    const int iz = o % r, ixy = o / r, ix = ixy >> 2, iy = ixy & 3;
+    obase[ni] = (ix * 6 + iy) * zp + iz + kq * bvp;    // + row kq of each 4-row k-step
+    gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + iz;
+  }
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    f32x4 bvv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bvv[q] = bias[min(16 * mi + 4 * kq + q, cout - 1)];
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = bvv;
+  }
+
+  for (int cb = 0; cb < cblocks; ++cb) {
+    __syncthreads();  // previous block's reads are done
+    // ---- stage 16 input channels of the haloed brick (zero outside the grid / past Cin)
+    for (int e = tid; e < 16 * bv; e += kConvThreads) {
+      const int ci = e / bv, rem = e - ci * bv;
+      const int ixy = rem / zp, izp = rem - ixy * zp;
+      const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1, gz = izp - 1;
+      const int ch = cb * 16 + ci;
+      float v = 0.f;
+      if (ch < cin && (unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r && (unsigned)gz < (unsigned)r)
+        v = x[(size_t)ch * r3 + (gx * r + gy) * r + gz];
+      lds[ci * bvp + rem] = v;
+    }
+    __syncthreads();
+    // ---- 27 taps x 4 k-steps of MFMA; weights one tap ahead
+    f32x4 a_cur[MT], a_nxt[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) a_cur[mi] = wv[((size_t)mi * kblocks + cb) * 64];
+    for (int tap = 0; tap < 27; ++tap) {
+      const int tn = tap + 1 < 27 ? tap + 1 : tap;
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) a_nxt[mi] = wv[((size_t)mi * kblocks + tn * cblocks + cb) * 64];
+      const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+      const int toff = (dx * 6 + dy) * zp + dz;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float bf[NTW];
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) bf[ni] = l3[obase[ni] + toff + 4 * j * bvp];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NTW; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mi][j], bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) a_cur[mi] = a_nxt[mi];
+    }
+  }
+  // ---- epilogue: store + per-channel partial statistics of this brick
+  __syncthreads();
+  float *s_part = lds;  // [4 waves][MT*16][2]
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = 16 * mi + 4 * kq + q;
+      float s = 0.f, s2 = 0.f;
+      if (co < cout) {
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) {
+          const float v = acc[mi][ni][q];
+          y[(size_t)co * r3 + gvox[ni]] = v;
+          s += v;
+          s2 += v * v;
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        s += __shfl_xor(s, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+      }
+      if (col == 0 && co < cout) {
+        s_part[(wave * MT * 16 + co) * 2] = s;
+        s_part[(wave * MT * 16 + co) * 2 + 1] = s2;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < cout) {
+    float s = 0.f, s2 = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      s += s_part[(w * MT * 16 + tid) * 2];
+      s2 += s_part[(w * MT * 16 + tid) * 2 + 1];
+    }
+    float *p = partial + (((size_t)b * gridDim.x + blockIdx.x) * cout + tid) * 2;
+    p[0] = s;
+    p[1] = s2;
+  }
+}
+
+// GroupNorm(groups) + Swish over [B, C, r^3]; statistics from the conv's per-brick partials.
+// grid = (groups, B); optional per-channel sum of the OUTPUT (for the SE squeeze).
+__global__ __launch_bounds__(512) void groupnorm_swish_kernel(float *__restrict__ y, const float *__restrict__ partial,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, int c, int r3,
+                                                              int nbricks, int groups, float eps,
+                                                              float *__restrict__ chan_sum) {
+  __shared__ double s_stat[2];
+  __shared__ float s_red[8];
+  const int g = blockIdx.x, b = blockIdx.y, cpg = c / groups;
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    double s = 0.0, s2 = 0.0;
+    for (int i = tid; i < nbricks * cpg; i += 64) {
+      const int br = i / cpg, ch = g * cpg + i % cpg;
+      const float *p = partial + (((size_t)b * nbricks + br) * c + ch) * 2;
+      s += (double)p[0];
+      s2 += (double)p[1];
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+      s += __shfl_xor(s, off, 64);
+      s2 += __shfl_xor(s2, off, 64);
+    }
+    if (tid == 0) {
+      const double n = (double)cpg * r3, mean = s / n;
+      s_stat[0] = mean;
+      s_stat[1] = 1.0 / sqrt(fmax(s2 / n - mean * mean, 0.0) + (double)eps);
+    }
+  }
+  __syncthreads();
+  const float mean = (float)s_stat[0], rstd = (float)s_stat[1];
+  for (int cc = 0; cc < cpg; ++cc) {
+    const int ch = g * cpg + cc;
+    float *row = y + ((size_t)b * c + ch) * r3;
+    const float ga = gamma[ch] * rstd, be = beta[ch] - mean * rstd * gamma[ch];
+    float acc = 0.f;
+    const int n4 = r3 >> 2;
+    for (int i = tid; i < n4; i += 512) {
+      float4 v = reinterpret_cast<float4 *>(row)[i];
+      float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float t = o[q] * ga + be;
+        o[q] = t / (1.0f + __expf(-t));
+        acc += o[q];
+      }
+      reinterpret_cast<float4 *>(row)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (chan_sum) {
+      for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      __syncthreads();
+      if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+      __syncthreads();
+      if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 8; ++w) t += s_red[w];
+        chan_sum[(size_t)b * c + ch] = t;
+      }
+    }
+  }
+}
+
+// SE gate: gate = sigmoid(W2 act(W1 mean)), W1 [c/red, c], W2 [c, c/red]; one block per cloud.
+__global__ void se_gate_kernel(const float *__restrict__ chan_sum, const float *__restrict__ w1,
+                               const float *__restrict__ w2, int c, int hid, int r3, int use_relu,
+                               float *__restrict__ gate) {
+  extern __shared__ float s[];  // mean[c], h[hid]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float *mean = s, *h = s + c;
+  for (int i = tid; i < c; i += blockDim.x) mean[i] = chan_sum[(size_t)b * c + i] / (float)r3;
+  __syncthreads();
+  for (int i = tid; i < hid; i += blockDim.x) {
+    float a = 0.f;
+    for (int q = 0; q < c; ++q) a += w1[i * c + q] * mean[q];
+    h[i] = use_relu ? fmaxf(a, 0.f) : a / (1.0f + expf(-a));
+  }
+  __syncthreads();
+  for (int i = tid; i < c; i += blockDim.x) {
+    float a = 0.f;
+    for (int q = 0; q < hid; ++q) a += w2[i * hid + q] * h[q];
+    gate[(size_t)b * c + i] = 1.0f / (1.0f + expf(-a));
+  }
+}
+
+// out[b,c,i] = gate[b,c] * trilinear(V[b,c], coords[b,:,i]) + add[b,c,i]
+__global__ __launch_bounds__(256) void devoxelize_fused_kernel(const float *__restrict__ coords,
+                                                               const float *__restrict__ feat,
+                                                               const float *__restrict__ gate,
+                                                               const float *__restrict__ add, int c, int n, int r,
+                                                               float *__restrict__ outs) {
+  const int b = blockIdx.z;
+  const int r2 = r * r, r3 = r2 * r;
+  coords += (size_t)b * 3 * n;
+  feat += (size_t)b * c * r3;
+  outs += (size_t)b * c * n;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = coords[i], y = coords[i + n], z = coords[i + 2 * n];
+  const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
+  const float xd1 = x - xl, yd1 = y - yl, zd1 = z - zl;
+  const float xd0 = 1.0f - xd1, yd0 = 1.0f - yd1, zd0 = 1.0f - zd1;
+  const float w000 = xd0 * yd0 * zd0, w001 = xd0 * yd0 * zd1, w010 = xd0 * yd1 * zd0, w011 = xd0 * yd1 * zd1;
+  const float w100 = xd1 * yd0 * zd0, w101 = xd1 * yd0 * zd1, w110 = xd1 * yd1 * zd0, w111 = xd1 * yd1 * zd1;
+  const int i000 = (int)xl * r2 + (int)yl * r + (int)zl;
+  const int zh = zd1 > 0 ? 1 : 0, yh = yd1 > 0 ? r : 0, xh = xd1 > 0 ? r2 : 0;
+  const int i001 = i000 + zh, i010 = i000 + yh, i011 = i010 + zh;
+  const int i100 = i000 + xh, i101 = i100 + zh, i110 = i100 + yh, i111 = i110 + zh;
+  const int c0 = blockIdx.y * 16, c1 = min(c0 + 16, c);
+  for (int l = c0; l < c1; ++l) {
+    const float *f = feat + (size_t)l * r3;
+    const float v = w000 * f[i000] + w001 * f[i001] + w010 * f[i010] + w011 * f[i011] + w100 * f[i100] +
+                    w101 * f[i101] + w110 * f[i110] + w111 * f[i111];
+    const float gt = gate ? gate[(size_t)b * c + l] : 1.0f;
+    const float ad = add ? add[((size_t)b * c + l) * n + i] : 0.f;
+    outs[(size_t)l * n + i] = gt * v + ad;
+  }
+}
+
+template <int MT, int NTW>
+int launch_conv(const float *x, const float *wp, const float *bias, int b, int cin, int cout, int r, float *y,
+                float *partial, hipStream_t s) {
+  const size_t lds_bytes = (size_t)16 * brick_row_stride(r) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_k3_kernel<MT, NTW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr = true;
+  }
+  const int bpr = r / kBrick;
+  hipLaunchKernelGGL((conv3d_k3_kernel<MT, NTW>), dim3(bpr * bpr, b), dim3(kConvThreads), lds_bytes, s, x, wp, bias,
+                     cin, cout, r, y, partial);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+}  // namespace
+
+GLDM_API long long gldm_conv3d_partial_floats(int b, int cout, int r) {
+  if (b <= 0 || cout <= 0 || r <= 0 || r % kBrick) return -1;
+  return (long long)b * (r / kBrick) * (r / kBrick) * cout * 2;
+}
+
+GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *bias, int b, int cin, int cout, int r,
+                            float *y, float *partial, gldm_stream_t stream) {
+  if (!x || !w_packed || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0)
+    return GLDM_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int mt = (cout + 15) / 16, ntw = r / 4;
+  if (r % 4 || (size_t)16 * brick_row_stride(r) * 4 > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
+#define GLDM_CONV_CASE(M, N) \
+  if (mt == M && ntw == N) return launch_conv<M, N>(x, w_packed, bias, b, cin, cout, r, y, partial, s)
+  GLDM_CONV_CASE(3, 6);   // 48 ch @ 24^3  (shipped fpc/ppc PVCNN encoder)
+  GLDM_CONV_CASE(6, 3);   // 96 ch @ 12^3
+  GLDM_CONV_CASE(2, 8);   // 32 ch @ 32^3  (PVCNN2)
+  GLDM_CONV_CASE(4, 4);   // 64 ch @ 16^3
+  GLDM_CONV_CASE(8, 2);   // 128 ch @ 8^3
+  GLDM_CONV_CASE(4, 8);   // 64 ch @ 32^3
+#undef GLDM_CONV_CASE
+  return GLDM_ERR_UNSUPPORTED;
+}
+
+GLDM_API int gldm_groupnorm_swish(float *y, const float *partial, const float *gamma, const float *beta, int b, int c,
+                                  int r, int groups, float eps, float *chan_sum, gldm_stream_t stream) {
+  if (!y || !partial || !gamma || !beta || b <= 0 || c <= 0 || r <= 0 || groups <= 0 || c % groups || r % 4)
+    return GLDM_ERR_INVALID_ARG;
+  const int nbricks = (r / kBrick) * (r / kBrick);
+  hipLaunchKernelGGL(groupnorm_swish_kernel, dim3(groups, b), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), y,
+                     partial, gamma, beta, c, r * r * r, nbricks, groups, eps, chan_sum);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_se_gate(const float *chan_sum, const float *w1, const float *w2, int b, int c, int hidden, int r,
+                          int use_relu, float *gate, gldm_stream_t stream) {
+  if (!chan_sum || !w1 || !w2 || !gate || b <= 0 || c <= 0 || hidden <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(se_gate_kernel, dim3(b), dim3(128), (size_t)(c + hidden) * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), chan_sum, w1, w2, c, hidden, r * r * r, use_relu, gate);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_devoxelize_fused(const float *coords, const float *features, const float *gate, const float *add,
+                                   int b, int c, int n, int r, float *out, gldm_stream_t stream) {
+  if (!coords || !features || !out || b <= 0 || c <= 0 || n <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(devoxelize_fused_kernel, dim3((n + 255) / 256, (c + 15) / 16, b), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), coords, features, gate, add, c, n, r, out);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}

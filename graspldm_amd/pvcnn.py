@@ -306,12 +306,23 @@ class PVConv(nn.Module):
         convs = [m for m in mods if isinstance(m, nn.Conv3d)]
         norms = [m for m in mods if isinstance(m, nn.GroupNorm)]
         se = mods[-1] if isinstance(mods[-1], SE3d) else None
+        from . import voxel
+        pf = self.point_features(features)
+        if all(voxel.conv_supported(c.out_channels, self.resolution) for c in convs):
+            # hand-written path: implicit-GEMM conv3d on f32 MFMA, GN+Swish, SE gate folded into the
+            # devoxelize pass together with the point-branch add
+            plan = self.__dict__.get("_voxel_plan")
+            key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs) + (str(vox.device),)
+            if plan is None or plan.key != key:
+                plan = voxel.VoxelBranchPlan(convs, vox.device)
+                self.__dict__["_voxel_plan"] = plan
+            return voxel.run(plan, convs, norms, se, vox, norm_coords, pf, self.resolution), coords
         h = dense.conv3d_gn_swish(vox, convs[0], norms[0])
         h = dense.conv3d_gn_swish(h, convs[1], norms[1])
         if se is not None:
             h = se(h)
         out = trilinear_devoxelize(h, norm_coords, self.resolution, False)
-        return out + self.point_features(features), coords
+        return out + pf, coords
 
 
 # --------------------------------------------------------------------- builders

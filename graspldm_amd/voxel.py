@@ -1,0 +1,65 @@
+"""Voxel branch of PVConv on the HIP path: Conv3d(k3) -> GroupNorm(8) -> Swish -> Conv3d(k3) ->
+GroupNorm(8) -> Swish -> SE -> trilinear devoxelize (+ point branch), pvconv.py:47-84, as
+gldm_conv3d_k3 / gldm_groupnorm_swish / gldm_se_gate / gldm_devoxelize_fused launches."""
+import torch
+
+from . import _lib as L
+from .r1d_pack import mfma_a_fragments
+
+SUPPORTED = {(3, 6), (6, 3), (2, 8), (4, 4), (8, 2), (4, 8)}  # (cout/16, r/4) instantiated in voxel_conv.hip
+
+
+def conv_supported(cout, r):
+    return cout % 16 == 0 and r % 4 == 0 and (cout // 16, r // 4) in SUPPORTED
+
+
+def pack_conv3d(weight):
+    """[cout, cin, 3, 3, 3] -> MFMA A fragments of [cout, 27 * cin_pad], k = tap * cin_pad + ci."""
+    cout, cin = weight.shape[:2]
+    cpad = (cin + 15) // 16 * 16
+    w = torch.zeros(cout, 27, cpad, dtype=torch.float32)
+    w[:, :, :cin] = weight.detach().float().cpu().reshape(cout, cin, 27).permute(0, 2, 1)
+    return mfma_a_fragments(w.reshape(cout, 27 * cpad))
+
+
+class VoxelBranchPlan:
+    """Packed conv weights of one PVConv on the device."""
+
+    def __init__(self, convs, device):
+        self.w = [pack_conv3d(c.weight).to(device) for c in convs]
+        self.key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs) + (str(device),)
+
+
+def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
+    """vox [B, Cin, r, r, r] -> fused features [B, Cout, N] = gate * devox(voxel stack) + point_feat."""
+    dev = vox.device
+    b = vox.shape[0]
+    st = L.current_stream(dev)
+    x = vox.contiguous()
+    chan_sum = None
+    with torch.cuda.device(dev):
+        for i, (conv, gn) in enumerate(zip(convs, norms)):
+            cin, cout = conv.in_channels, conv.out_channels
+            y = torch.empty((b, cout, r, r, r), dtype=torch.float32, device=dev)
+            nf = L.lib().gldm_conv3d_partial_floats(b, cout, r)
+            partial = torch.empty(int(nf), dtype=torch.float32, device=dev)
+            L.call("gldm_conv3d_k3", L.ptr(x), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r, L.ptr(y),
+                   L.ptr(partial), st)
+            last = i == len(convs) - 1
+            if last and se is not None:
+                chan_sum = torch.empty((b, cout), dtype=torch.float32, device=dev)
+            L.call("gldm_groupnorm_swish", L.ptr(y), L.ptr(partial), L.ptr(gn.weight), L.ptr(gn.bias), b, cout, r,
+                   gn.num_groups, float(gn.eps), L.ptr(chan_sum) if (last and se is not None) else None, st)
+            x = y
+        c = x.shape[1]
+        gate = None
+        if se is not None:
+            gate = torch.empty((b, c), dtype=torch.float32, device=dev)
+            w1, w2 = se.fc[0].weight, se.fc[2].weight
+            L.call("gldm_se_gate", L.ptr(chan_sum), L.ptr(w1), L.ptr(w2), b, c, w1.shape[0], r,
+                   1 if se.use_relu else 0, L.ptr(gate), st)
+        n = norm_coords.shape[2]
+        out = torch.empty((b, c, n), dtype=torch.float32, device=dev)
+        pf = point_feat.contiguous() if point_feat is not None else None
+        L.call("gldm_devoxelize_fused", L.ptr(norm_coords), L.ptr(x), L.ptr(gate), L.ptr(pf), b, c, n, r, L.ptr(out), st)
+    return out

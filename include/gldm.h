@@ -215,6 +215,36 @@ int gldm_sa_mlp_forward(const float *points /*[b,3,n]*/, const float *centers /*
                         const int32_t *cin_pad, const int32_t *cout, const int32_t *w_off, const int32_t *b_off,
                         float *out /*[b,cout_last,m]*/, gldm_stream_t stream);
 
+/* ---------------------------------------------------------- voxel branch of PVConv */
+
+/* ref: grasp_ldm/models/modules/ext/pvcnn/modules/pvconv.py:48-66 (nn.Conv3d k=3 p=1 on the
+ * [b, c, r, r, r] voxel grid).  Implicit GEMM on f32 MFMA; `w_packed` = weight [cout, cin, 3,3,3]
+ * re-laid as [cout, 27 * cin_pad] (k = tap * cin_pad + ci, tap = (dx*3+dy)*3+dz, cin_pad =
+ * roundup(cin,16)) in MFMA A-fragment order (graspldm_amd/voxel.py).  Also writes, per 4x4xr
+ * brick and output channel, (sum, sum of squares) of the outputs to `partial`
+ * [gldm_conv3d_partial_floats()] for the following GroupNorm.  r % 4 == 0. */
+long long gldm_conv3d_partial_floats(int b, int cout, int r);
+int gldm_conv3d_k3(const float *x /*[b,cin,r^3]*/, const float *w_packed, const float *bias /*[cout]*/,
+                   int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/, float *partial,
+                   gldm_stream_t stream);
+
+/* ref: pvconv.py:57-66 (nn.GroupNorm(8, c) + Swish), in place on y; statistics from `partial`
+ * (combined in f64 in a fixed order).  chan_sum [b,c] (optional) receives the per-channel sum of
+ * the OUTPUT: the squeeze of the SE block that follows. */
+int gldm_groupnorm_swish(float *y /*[b,c,r^3]*/, const float *partial, const float *gamma, const float *beta,
+                         int b, int c, int r, int groups, float eps, float *chan_sum, gldm_stream_t stream);
+
+/* ref: grasp_ldm/models/modules/ext/pvcnn/modules/se.py:12-25: gate = sigmoid(W2 act(W1 mean)),
+ * act = ReLU (use_relu) or Swish. */
+int gldm_se_gate(const float *chan_sum /*[b,c]*/, const float *w1 /*[hidden,c]*/, const float *w2 /*[c,hidden]*/,
+                 int b, int c, int hidden, int r, int use_relu, float *gate /*[b,c]*/, gldm_stream_t stream);
+
+/* ref: pvconv.py:79-83: trilinear_devoxelize(SE(v)) + point_features(x) in one pass:
+ * out = gate[b,c] * trilinear(V) + add  (gate / add may be NULL). */
+int gldm_devoxelize_fused(const float *coords /*[b,3,n]*/, const float *features /*[b,c,r^3]*/,
+                          const float *gate /*[b,c]*/, const float *add /*[b,c,n]*/, int b, int c, int n, int r,
+                          float *out /*[b,c,n]*/, gldm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,3 +167,35 @@ def test_fused_sa_mlp_equals_unfused_oracle(b, c, n, m, u, chans):
         got, ctr = mod((feats.cuda() if c else None, coords.cuda()))
     assert torch.equal(ctr.cpu(), ectr)
     assert _err(got, exp) < 2e-5, _err(got, exp)
+
+
+@pytest.mark.parametrize("cin,cout,r", [(3, 48, 24), (48, 48, 24), (48, 96, 12), (96, 96, 12), (3, 32, 32), (64, 64, 16)])
+def test_conv3d_groupnorm_swish_kernels(cin, cout, r):
+    """gldm_conv3d_k3 + gldm_groupnorm_swish vs torch conv3d / group_norm on the CPU (fp32, 2e-5:
+    K = 27 cin products per output in a different summation order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.nn.functional as F
+    from graspldm_amd import _lib as L
+    from graspldm_amd.voxel import pack_conv3d
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    b = 2
+    x = torch.randn(b, cin, r, r, r, generator=g)
+    x[:, :, ::3] = 0  # empty voxels, like a real occupancy grid
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    bias, gamma, beta = (torch.randn(cout, generator=g) * 0.1 for _ in range(3))
+    gamma = gamma + 1
+    ref = F.conv3d(x, w, bias, padding=1)
+    y = torch.empty(b, cout, r, r, r, device="cuda")
+    part = torch.empty(int(L.lib().gldm_conv3d_partial_floats(b, cout, r)), device="cuda")
+    st = L.current_stream()
+    dx, dw, db = x.cuda(), pack_conv3d(w).cuda(), bias.cuda()
+    L.call("gldm_conv3d_k3", L.ptr(dx), L.ptr(dw), L.ptr(db), b, cin, cout, r, L.ptr(y), L.ptr(part), st)
+    assert _err(y, ref) < 2e-5, _err(y, ref)
+    gn = F.group_norm(ref, 8, gamma, beta, 1e-5)
+    ref2 = gn * torch.sigmoid(gn)
+    cs = torch.empty(b, cout, device="cuda")
+    dg, dbt = gamma.cuda(), beta.cuda()
+    L.call("gldm_groupnorm_swish", L.ptr(y), L.ptr(part), L.ptr(dg), L.ptr(dbt), b, cout, r, 8, 1e-5, L.ptr(cs), st)
+    assert _err(y, ref2) < 2e-5, _err(y, ref2)
+    assert _err(cs / r ** 3, ref2.mean(dim=(2, 3, 4))) < 1e-5
