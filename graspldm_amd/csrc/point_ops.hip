@@ -16,6 +16,7 @@
 //    for bit.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gldm.h"
 
@@ -461,6 +462,7 @@ __global__ __launch_bounds__(kDevBlock) void trilinear_devoxelize_kernel(const f
 //            stores; reads are index gathers served from L2 (the per-cloud
 //            feature slab is <= 512 KiB and shared by all blocks of the cloud).
 constexpr int kSaBlock = 256;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <bool kUseLds>
 __global__ __launch_bounds__(kSaBlock) void sa_group_kernel(const float *__restrict__ points,
@@ -523,8 +525,8 @@ __global__ __launch_bounds__(kSaBlock) void sa_group_kernel(const float *__restr
 #pragma unroll 4
         for (int l = 0; l < c; ++l) {
           const float *f = feat + (size_t)l * n;
-          const float4 v = make_float4(f[id.x], f[id.y], f[id.z], f[id.w]);
-          *reinterpret_cast<float4 *>(o + (size_t)l * mu) = v;
+          f32x4_t v = {f[id.x], f[id.y], f[id.z], f[id.w]};
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t *>(o + (size_t)l * mu));  // streamed once
         }
       }
     } else {
@@ -674,9 +676,13 @@ GLDM_API int gldm_sa_group(const float *points, const float *centers, const floa
   if (!points || !centers || !out || b <= 0 || c < 0 || n <= 0 || m <= 0 || u <= 0) return GLDM_ERR_INVALID_ARG;
   if (c > 0 && !features) return GLDM_ERR_INVALID_ARG;
   const float r2 = radius * radius;
-  // 8 centres per block keeps >= 2 blocks per CU busy at B*M/8 blocks and makes
-  // each channel row a run of 8*u floats (2 KiB at u = 64).
-  int cpb = 8;
+  // 16 centres per block: every thread owns one 16-byte slot of each channel row's 4 KiB run
+  // (u = 64); measured best of {4, 8, 16, 32} on MI355X (tools/bench_point_ops.py).
+  int cpb = 16;
+  {
+    const char *e = getenv("GLDM_SA_CPB");  // tuning knob (diagnostic)
+    if (e) cpb = atoi(e);
+  }
   while (cpb > 1 && (size_t)cpb * u * sizeof(int32_t) > 32 * 1024) cpb >>= 1;
   const size_t fixed = (size_t)cpb * u * sizeof(int32_t) + (size_t)3 * cpb * sizeof(float);
   dim3 grid(ceil_div(m, cpb), b);

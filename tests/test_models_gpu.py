@@ -199,3 +199,24 @@ def test_conv3d_groupnorm_swish_kernels(cin, cout, r):
     L.call("gldm_groupnorm_swish", L.ptr(y), L.ptr(part), L.ptr(dg), L.ptr(dbt), b, cout, r, 8, 1e-5, L.ptr(cs), st)
     assert _err(y, ref2) < 2e-5, _err(y, ref2)
     assert _err(cs / r ** 3, ref2.mean(dim=(2, 3, 4))) < 1e-5
+
+
+def test_ppc_config_z16_latent_against_oracle():
+    """Second shipped experiment (configs/generation/partial_pc/ppc_1a_...z16_pc256: grasp latent 16,
+    pc latent [3,256], denoiser dim 16 -> the L=16 time-conditioned engine): end-to-end LDM
+    generation vs the torch-CPU oracle, 20 DDIM steps, identical weights / inputs / noise."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from graspldm_amd.pipeline import build_fpc_ldm
+    from graspldm_amd.synthetic import synthetic_batch
+    from oracle import torch_ref as R
+    ldm = build_fpc_ldm(latent=16, pc_latent=256).cuda()
+    ldm.set_inference_timesteps(20)
+    pcs, _ = synthetic_batch(2, 1024, partial=True)
+    x_T = torch.randn(10, 1, 16, generator=torch.Generator().manual_seed(5))
+    (tm, lg), _ = ldm.generate_grasps(pcs.cuda(), num_grasps=5, x_T=x_T)
+    sd = {k: v.detach().cpu() for k, v in ldm.state_dict().items()}
+    sched = R.make_scheduler("ddim")
+    sched.set_timesteps(20)
+    etm, elg = R.ldm_generate(sd, pcs, 5, sched, R.pvcnn_block_spec(0.75, 0.75), n_dims=16, x_T=x_T)
+    assert _err(tm, etm) < 1e-4 and _err(lg, elg) < 1e-4, (_err(tm, etm), _err(lg, elg))
