@@ -4,24 +4,31 @@
 //                    launch; the latent never leaves the chip between steps;
 //   * gldm_decode  : ConditionalGraspPoseDecoder.forward (in_layer, ResNet1D,
 //                    tmrp / class_logits heads);
+//   * gldm_sa_mlp_forward : the fused set-abstraction core (gather + grouped MLP + max)
+//                    on the same GEMM core;
 //   * gldm_r1d_cond_embed, gldm_pose_epilogue : the small ops either side.
 //
 // Mapping to CDNA4
-//   A workgroup (8 waves) owns a tile of kCols = 64 activation columns =
-//   64/L samples x L positions (L = 4: 16 latents, L = 16: 4 decoder rows) and
-//   walks every layer with activations resident in LDS as [channel][column]
-//   (XOR-swizzled so MFMA B-fragment reads are conflict free).  Every conv /
-//   1x1 is a GEMM  W[Cout x taps*Cin] * im2col(X)[taps*Cin x 64]  on
-//   v_mfma_f32_16x16x4_f32 (exact f32: the parity budget is 1e-4 on poses after
-//   100 steps, and the reference's eps is dtype dependent, so no bf16 here).
-//   A operands (weights, standardised and laid out in fragment order on the
-//   host) stream from L2 straight into VGPRs as 16-byte coalesced loads, one
-//   k-block ahead; B operands are LDS reads with the k=3 halo handled by a lane
-//   mask instead of a materialised im2col.  GroupNorm / LayerNorm / softmax run
-//   with lane = column so rows are read conflict-free and statistics reduce by
-//   wave shuffles plus one small cross-wave exchange.
-//   LinearAttention at n = L is reassociated:  out = V (K^T Q)  (an L x L
-//   matrix per sample and head) instead of (V K^T) Q: 8x fewer FLOPs, same math.
+//   A workgroup owns a tile of NC activation columns = NC/L samples x L positions and walks
+//   every layer with activations resident in LDS as [channel][column] (XOR-swizzled so MFMA
+//   B-fragment reads are conflict free).  Two geometries are built from one template:
+//     NC = 32: 4 waves, 76 KiB LDS  -> TWO workgroups per CU.  The network is ~80 short
+//              barrier-separated phases per step; a second, independent workgroup fills the
+//              MFMA pipe while the first sits in a norm pass, a barrier or an L2 round trip.
+//              This is the production geometry of the denoiser / decoder.
+//     NC = 64: 8 waves, 150 KiB LDS -> one workgroup per CU (fused set abstraction: one centre
+//              with U = 64 neighbours per tile).
+//   Every conv / 1x1 is a GEMM  W[Cout x taps*Cin] * X[taps*Cin x NC]  on
+//   v_mfma_f32_16x16x4_f32 (exact f32: the parity budget is 1e-4 on poses after 100 steps and
+//   the reference's eps is dtype dependent, so no bf16 here).  Weights (standardised and laid
+//   out in fragment order on the host) stream L2 -> VGPR as 16-byte coalesced global loads, a
+//   few 16-channel blocks ahead; B operands are unconditional, batched LDS reads.  k = 3 convs
+//   keep one accumulator set per tap on UNSHIFTED columns and apply the halo shift once to the
+//   result tiles (lane shifts inside the 16-lane rows of the C/D layout), so the k-loop is
+//   loads + MFMA only.  GroupNorm / LayerNorm / softmax run with lane = (row slot, column):
+//   rows are read conflict-free and statistics reduce by wave shuffles.
+//   LinearAttention at n = L is reassociated:  out = V (K^T Q)  (an L x L matrix per sample
+//   and head) instead of (V K^T) Q: 8x fewer FLOPs, same math.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -36,29 +43,37 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) float lds_f;   // explicit LDS pointers: 32-bit ds_* addressing
 typedef __attribute__((address_space(3))) f32x4 lds_f4;
+typedef const __attribute__((address_space(1))) f32x4 *gf4p;  // plain global_load (vmcnt only)
 
-constexpr int kThreads = 512;
-constexpr int kWaves = kThreads / 64;
-constexpr int kCols = 64;               // activation columns per workgroup
 constexpr int kHeads = 4, kDimHead = 32, kHidden = kHeads * kDimHead;  // LinearAttention defaults
 constexpr int kMaxC = 256;
 
-// LDS map (floats).  X: block input / residual stream, H: scratch.
-constexpr int kBufX = 0;
-constexpr int kBufH = kMaxC * kCols;            // 16384
-constexpr int kBufY = 128 * kCols;              // 8192  (attention: LayerNorm output, later to_out output)
-constexpr int kBufO = kBufH;                    // 16384 (attention output, 128 rows)
-constexpr int kBufQKV = kBufO + kHidden * kCols;  // 24576 (two heads of q,k,v: 192 rows)
-constexpr int kArena = kBufQKV + 192 * kCols;   // 36864
-constexpr int kMiscLat = kArena;                // [64] current latent row
-constexpr int kMiscEps = kMiscLat + kCols;      // [64]
-constexpr int kMiscG = kMiscEps + kCols;        // [S][E] <= 256
-constexpr int kMiscRed1 = kMiscG + 320;         // [8][64]
-constexpr int kMiscRed2 = kMiscRed1 + kWaves * kCols;
-constexpr int kLdsFloats = kMiscRed2 + kWaves * kCols;  // 38336 floats = 149.75 KiB
-static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
+// Geometry and LDS map (floats) of one workgroup.  X: block input / residual stream, H: scratch.
+template <int NC>
+struct Geo {
+  static constexpr int kWaves = NC / 8;           // 8 waves at 64 columns, 4 at 32
+  static constexpr int kThreads = kWaves * 64;
+  static constexpr int kNT = NC / 16;             // 16-column n-tiles
+  static constexpr int kRP = 64 / NC;             // rows a wave touches per pass: lane = (sub, column)
+  static constexpr int kBufX = 0;
+  static constexpr int kBufH = kMaxC * NC;
+  static constexpr int kBufY = 128 * NC;          // attention: LayerNorm output, later to_out output
+  static constexpr int kBufO = kBufH;             // attention output, 128 rows
+  static constexpr int kBufQKV = kBufO + kHidden * NC;  // two heads of q,k,v: 192 rows
+  static constexpr int kArena = kBufQKV + 192 * NC;
+  static constexpr int kMiscLat = kArena;         // [NC] current latent row
+  static constexpr int kMiscEps = kMiscLat + NC;
+  static constexpr int kMiscG = kMiscEps + NC;    // [S][E] <= 320
+  static constexpr int kMiscRed1 = kMiscG + 320;  // [kWaves][64]
+  static constexpr int kMiscRed2 = kMiscRed1 + kWaves * 64;
+  static constexpr int kMiscTape = kMiscRed2 + kWaves * 64;  // [kMaxOps][8] ints: the step program
+  static constexpr int kLdsFloats = kMiscTape + 8 * 128;
+};
+static_assert(Geo<64>::kLdsFloats * 4 <= 160 * 1024, "LDS budget (1 WG/CU)");
+static_assert(Geo<32>::kLdsFloats * 4 * 2 <= 160 * 1024, "LDS budget (2 WG/CU)");
 
-__device__ __forceinline__ int swz(int row, int col) { return row * kCols + (col ^ ((row & 1) << 4)); }
+template <int NC>
+__device__ __forceinline__ int swz(int row, int col) { return row * NC + (col ^ ((row & 1) << 4)); }
 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
@@ -67,22 +82,13 @@ struct Ctx {
   const float *w;   // packed weights
   float *lds;
   int tid, wave, lane;
-  int skip;
-  long long *dbg;   // diagnostic stamps (GLDM_R1D_STAMP), null in production
-  int *call;
-  int nta;          // active 16-column tiles of this workgroup (4 = full, 1 = tail tile)
+  int skip;         // diagnostic phase-skip mask (GLDM_R1D_SKIP), 0 in production
+  int nta;          // live 16-column n-tiles of this workgroup (kNT = full tile, 1 = tail tile)
 };
 
 // ---------------------------------------------------------------- GEMM ----
 // Every conv / 1x1 is  acc[mi][ni] += W[16(mt0+mi).., :] * im2col(src)[:, 16(nt0+ni)..]
 // on v_mfma_f32_16x16x4_f32.  Packed weights: k = tap * Cin + ci, 16-deep k-blocks.
-//
-// Fast path (Cin % 16 == 0): per 16-channel block the B fragments are read from LDS ONCE
-// (unconditional, batched reads) and the k=3 halo comes from DPP lane shifts inside each
-// 16-lane row: the left/right taps of column n live in lanes n-1 / n+1 of the same row.
-// A 16-column tile never straddles a sample (L divides 16), so row-boundary lanes are
-// exactly the lanes whose tap falls outside the sample -> zero fill (bound_ctrl) for
-// L = 16, an extra (col % L) mask for L = 4.
 template <int L>
 __device__ __forceinline__ float tap_left(float v, bool keep) {  // value of column n-1
   const float f = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /*row_shr:1*/, 0xf, 0xf, true));
@@ -94,24 +100,24 @@ __device__ __forceinline__ float tap_right(float v, bool keep) {  // value of co
   return (L >= 16 || keep) ? f : 0.f;
 }
 
-__device__ __forceinline__ float f4_get(const f32x4 &v, int j) { return v[j]; }
-
-template <int L, int TAPS, int MT, int NT>
-__device__ __forceinline__ void gemm_fast(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0, int nt0,
-                                          const float *src, f32x4 (&acc)[MT][NT]) {
-  // k = 3 convs keep one accumulator set per tap: Y_t = W_t X on UNSHIFTED columns, and the
-  // halo shift is applied once to the 16x16 result tiles (out[n] = Y0[n-1] + Y1[n] + Y2[n+1],
-  // lane shifts inside the 16-lane rows of the C/D layout) -- the k-loop is loads + MFMA only.
-  constexpr int PF = (MT * TAPS >= 6) ? 2 : 4;  // weight blocks in flight (register budget)
+// Fast path (Cin % 16 == 0).  A 16-column tile never straddles a sample (L divides 16), so the
+// row-boundary lanes of the halo shift are exactly the lanes whose tap falls outside the sample:
+// zero fill (bound_ctrl) for L = 16, an extra (col % L) mask for L = 4.
+template <int NC, int L, int TAPS, int MT, int NT, int PF>
+__device__ __forceinline__ void gemm_fast_pf(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0, int nt0,
+                                             const float *src, f32x4 (&acc)[MT][NT]) {
+  // PF = weight blocks in flight; cblocks % PF == 0.  The unrolled body is UNCONDITIONAL: a load
+  // whose only consumer sits behind a branch is sunk into that branch by the compiler (and then
+  // waited for at once), and a branch around a load forces s_waitcnt 0 at the join.  Block indices
+  // are clamped instead; the redundant re-loads at the tail are harmless.
   const int col = c.lane & 15, kq = c.lane >> 4;
   const int kblocks = TAPS * cblocks;
-  typedef const __attribute__((address_space(1))) f32x4 *gf4p;  // plain global_load (vmcnt only)
   gf4p wv = (gf4p)(reinterpret_cast<const f32x4 *>(wp) + c.lane);
   int boff[4][NT];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) boff[j][ni] = swz(4 * j + kq, 16 * (nt0 + ni) + col);
+    for (int ni = 0; ni < NT; ++ni) boff[j][ni] = swz<NC>(4 * j + kq, 16 * (nt0 + ni) + col);
   f32x4 a[PF][TAPS][MT];
   float b[2][4][NT];
   f32x4 side[TAPS > 1 ? 2 : 1][MT][NT];  // tap 0 and tap 2 partial results (tap 1 goes to acc)
@@ -123,64 +129,75 @@ __device__ __forceinline__ void gemm_fast(const Ctx &c, const float *__restrict_
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) side[t][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  auto load_a = [&](int buf, int cb) {
+  // part = -1: the whole block; part 0..2: the third of the block's fragments issued beside
+  // k-step `part` (a burst of every wave's loads at the block boundary stalls all of them in the
+  // vector-memory issue queue while the MFMA pipe idles: spread, the two pipes overlap)
+  auto load_a = [&](int buf, int cb, int part) {
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) a[buf][t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks + cb) * 64];
+      for (int mi = 0; mi < MT; ++mi)
+        if (part < 0 || (t * MT + mi) % 3 == part)
+          a[buf][t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks + cb) * 64];
   };
   const lds_f *src3 = (const lds_f *)src;
   auto load_b = [&](int buf, int cb) {
-    const lds_f *s = src3 + cb * 16 * kCols;
+    const lds_f *s = src3 + cb * 16 * NC;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) b[buf][j][ni] = s[boff[j][ni]];
   };
-  auto compute = [&](int abuf, int bbuf) {
+  auto mfma_step = [&](int abuf, int bbuf, int j) {
+    if (TAPS == 3) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (TAPS == 3) {
+      for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+        for (int ni = 0; ni < NT; ++ni)
+          side[0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][0][mi][j], b[bbuf][j][ni], side[0][mi][ni], 0, 0, 0);
 #pragma unroll
-          for (int ni = 0; ni < NT; ++ni)
-            side[0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][0][mi][j], b[bbuf][j][ni], side[0][mi][ni], 0, 0, 0);
+      for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+        for (int ni = 0; ni < NT; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][TAPS > 1 ? 1 : 0][mi][j], b[bbuf][j][ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-          for (int ni = 0; ni < NT; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][TAPS > 1 ? 1 : 0][mi][j], b[bbuf][j][ni], acc[mi][ni], 0, 0, 0);
+      for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+        for (int ni = 0; ni < NT; ++ni)
+          side[TAPS > 1 ? 1 : 0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][TAPS > 2 ? 2 : 0][mi][j], b[bbuf][j][ni], side[TAPS > 1 ? 1 : 0][mi][ni], 0, 0, 0);
+    } else {
 #pragma unroll
-          for (int ni = 0; ni < NT; ++ni)
-            side[TAPS > 1 ? 1 : 0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][TAPS > 2 ? 2 : 0][mi][j], b[bbuf][j][ni], side[TAPS > 1 ? 1 : 0][mi][ni], 0, 0, 0);
-      } else {
+      for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NT; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][0][mi][j], b[bbuf][j][ni], acc[mi][ni], 0, 0, 0);
-      }
+        for (int ni = 0; ni < NT; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[abuf][0][mi][j], b[bbuf][j][ni], acc[mi][ni], 0, 0, 0);
     }
   };
-  // loads are UNCONDITIONAL (block index clamped, a redundant re-load at the tail is harmless):
-  // a branch around a load forces s_waitcnt 0 at the join and serialises the pipeline
   const int last = cblocks - 1;
+  if constexpr (PF == 1) {
+    for (int cb = 0; cb < cblocks; ++cb) {
+      load_a(0, cb, -1);
+      load_b(0, cb);
 #pragma unroll
-  for (int u = 0; u < PF - 1; ++u) load_a(u, u < last ? u : last);
-  load_b(0, 0);
-  for (int cb0 = 0; cb0 < cblocks; cb0 += PF) {
+      for (int j = 0; j < 4; ++j) mfma_step(0, 0, j);
+    }
+  } else {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int cb = cb0 + u;
-      if (cb < cblocks) {
-        load_a((u + PF - 1) % PF, cb + PF - 1 < last ? cb + PF - 1 : last);
-        load_b((u + 1) & 1, cb + 1 < last ? cb + 1 : last);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(u, u & 1);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int u = 0; u < PF - 1; ++u) load_a(u, u < last ? u : last, -1);
+    load_b(0, 0);
+    for (int cb0 = 0; cb0 < cblocks; cb0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int cb = cb0 + u;
+        const int acb = cb + PF - 1 < last ? cb + PF - 1 : last, bcb = cb + 1 < last ? cb + 1 : last;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < 3) load_a((u + PF - 1) % PF, acb, j);
+          if (j == 0) load_b((u + 1) & 1, bcb);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_step(u, u & 1, j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
@@ -196,12 +213,25 @@ __device__ __forceinline__ void gemm_fast(const Ctx &c, const float *__restrict_
   }
 }
 
+template <int NC, int L, int TAPS, int MT, int NT>
+__device__ __forceinline__ void gemm_fast(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0, int nt0,
+                                          const float *src, f32x4 (&acc)[MT][NT]) {
+#ifndef GLDM_PFMAX6
+#define GLDM_PFMAX6 2
+#endif
+  constexpr int PFMAX = (MT * TAPS > 6) ? 2 : (MT * TAPS > 4 ? GLDM_PFMAX6 : 4);  // register budget
+  if (PFMAX == 4 && (cblocks & 3) == 0) gemm_fast_pf<NC, L, TAPS, MT, NT, PFMAX>(c, wp, cblocks, mt0, nt0, src, acc);
+  else if ((cblocks & 1) == 0) gemm_fast_pf<NC, L, TAPS, MT, NT, 2>(c, wp, cblocks, mt0, nt0, src, acc);
+  else gemm_fast_pf<NC, L, TAPS, MT, NT, 1>(c, wp, cblocks, mt0, nt0, src, acc);
+}
+
 // Generic path (Cin % 16 != 0: the 4-channel level of the latent denoiser): masked reads.
-template <int L, int MT, int NT>
+template <int NC, int L, int MT, int NT>
 __device__ __forceinline__ void gemm_small(const Ctx &c, const float *__restrict__ wp, int kblocks, int mt0, int nt0,
                                            const float *src, int cin, int ktaps, f32x4 (&acc)[MT][NT]) {
   const int col = c.lane & 15, kq = c.lane >> 4;
   const f32x4 *wv = reinterpret_cast<const f32x4 *>(wp);
+  const lds_f *src3 = (const lds_f *)src;
   int dk = 0, cib = 0;
   const int pad = ktaps == 3 ? 1 : 0;
   for (int kb = 0; kb < kblocks; ++kb) {
@@ -218,7 +248,7 @@ __device__ __forceinline__ void gemm_small(const Ctx &c, const float *__restrict
         const int n = 16 * (nt0 + ni) + col;
         const int p = (n & (L - 1)) + shift;
         const bool ok = (dk < ktaps) && (ci < cin) && (p >= 0) && (p < L);
-        float v = src[swz(ok ? ci : 0, ok ? n + shift : 0)];
+        float v = src3[swz<NC>(ok ? ci : 0, ok ? n + shift : 0)];
         asm volatile("" : "+v"(v));  // keep the LDS read unconditional (no branch + wait per element)
         b[ni] = ok ? v : 0.f;
       }
@@ -226,7 +256,7 @@ __device__ __forceinline__ void gemm_small(const Ctx &c, const float *__restrict
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(a[mi], j), b[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], b[ni], acc[mi][ni], 0, 0, 0);
       cib += 4;
       if (cib >= cin) {
         cib = 0;
@@ -236,10 +266,11 @@ __device__ __forceinline__ void gemm_small(const Ctx &c, const float *__restrict
   }
 }
 
-template <int MT, int NT>
+template <int NC, int MT, int NT>
 __device__ __forceinline__ void store_tiles(const Ctx &c, const f32x4 (&acc)[MT][NT], int mt0, int nt0, float *dst,
-                                            int cout, const float *__restrict__ bias, int act) {
+                                            int cout, int act) {
   const int col = c.lane & 15, kq = c.lane >> 4;
+  lds_f *d3 = (lds_f *)dst;
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
@@ -249,267 +280,302 @@ __device__ __forceinline__ void store_tiles(const Ctx &c, const f32x4 (&acc)[MT]
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
           const float v = acc[mi][ni][r];
-          ((lds_f *)dst)[swz(row, 16 * (nt0 + ni) + col)] = act ? fmaxf(v, 0.f) : v;
+          d3[swz<NC>(row, 16 * (nt0 + ni) + col)] = act ? fmaxf(v, 0.f) : v;
         }
       }
     }
   }
 }
 
-template <int L, int MT, int NT>
-__device__ __forceinline__ void gemm_fixed(const Ctx &c, const float *wp, int mt0, int nt0, bool active,
-                                           const float *src, int cin, int ktaps, float *dst, int cout,
-                                           const float *bias, bool alias, int act) {
-  // the bias is folded into the accumulator start value (its L2 load overlaps the GEMM)
-  f32x4 acc[MT][NT];
-  {
-    const int kq = c.lane >> 4;
+// One wave's share of a GEMM: PASSES x MT m-tiles by NT n-tiles, one k-sweep per pass.  Passes keep
+// the register footprint of a sweep small (MT * TAPS <= 6 fragments per block) so that every variant
+// fits beside the other phases of the kernel without spilling; the extra cost of a pass is one
+// pipeline fill.  The bias is folded into the accumulator start value.
+template <int NC, int L, int TAPS, int MT, int NT, int PASSES>
+__device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int mt0, int nt0, bool active,
+                                            const float *src, int cin, float *dst, int cout, const float *bias,
+                                            bool alias, int act) {
+  f32x4 acc[PASSES][MT][NT];
+  const int kq = c.lane >> 4;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
       if (bias) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * (mt0 + mi) + 4 * kq + r;
+          const int row = 16 * (mt0 + p * MT + mi) + 4 * kq + r;
           bv[r] = bias[row < cout ? row : cout - 1];
         }
       }
 #pragma unroll
-      for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = bv;
+      for (int ni = 0; ni < NT; ++ni) acc[p][mi][ni] = bv;
+    }
+    if (active) {
+      if ((cin & 15) == 0) gemm_fast<NC, L, TAPS, MT, NT>(c, wp, cin >> 4, mt0 + p * MT, nt0, src, acc[p]);
+      else gemm_small<NC, L, MT, NT>(c, wp, (TAPS * cin + 15) >> 4, mt0 + p * MT, nt0, src, cin, TAPS, acc[p]);
     }
   }
-  if (active) {
-    if ((cin & 15) == 0) {
-      if (ktaps == 3) gemm_fast<L, 3, MT, NT>(c, wp, cin >> 4, mt0, nt0, src, acc);
-      else gemm_fast<L, 1, MT, NT>(c, wp, cin >> 4, mt0, nt0, src, acc);
-    } else {
-      gemm_small<L, MT, NT>(c, wp, (ktaps * cin + 15) >> 4, mt0, nt0, src, cin, ktaps, acc);
-    }
-  }
-  if (c.dbg && c.lane == 0) c.dbg[(*c.call * 8 + c.wave) * 4 + 1] = (long long)__builtin_readcyclecounter();
   if (alias) __syncthreads();
-  if (active) store_tiles<MT, NT>(c, acc, mt0, nt0, dst, cout, bias, act);
+  if (active) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) store_tiles<NC, MT, NT>(c, acc[p], mt0 + p * MT, nt0, dst, cout, act);
+  }
 }
 
-// dst[cout][64] = W * im2col(src[cin][64]) + bias.  Ends with a barrier.
+// dst[cout][NC] = W * im2col(src[cin][NC]) + bias.  Ends with a barrier.
 // alias: dst overlaps src -> all reads complete (barrier) before any store.
 // Output widths are 16 x {1, 2, 4, 8, 12, 16} rows (validate() enforces it).
-template <int L>
-__device__ __noinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, const float *src, int cin, int ktaps,
-                                       float *dst, int cout, bool alias, int act = 0) {
+template <int NC, int L>
+__device__ __forceinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, const float *src, int cin, int ktaps,
+                                          float *dst, int cout, bool alias, int act = 0) {
   if (c.skip & 8) return;
-  // arguments of a non-inlined device function arrive in VGPRs: make the wave-uniform ones
-  // scalar again so loop bounds and address bases stay on the SALU
-  w_off = __builtin_amdgcn_readfirstlane(w_off);
-  b_off = __builtin_amdgcn_readfirstlane(b_off);
-  cin = __builtin_amdgcn_readfirstlane(cin);
-  ktaps = __builtin_amdgcn_readfirstlane(ktaps);
-  cout = __builtin_amdgcn_readfirstlane(cout);
-  act = __builtin_amdgcn_readfirstlane(act);
-  {
-    const int so = __builtin_amdgcn_readfirstlane((int)(src - c.lds)), dd = __builtin_amdgcn_readfirstlane((int)(dst - c.lds));
-    src = c.lds + so;
-    dst = c.lds + dd;
-  }
   const float *wp = c.w + w_off;
   const float *bias = b_off >= 0 ? c.w + b_off : nullptr;
   const int mtiles = (cout + 15) >> 4;
   const int w = c.wave;
-  if (c.dbg && c.lane == 0) {
-    c.dbg[(*c.call * 8 + c.wave) * 4 + 0] = (long long)__builtin_readcyclecounter();
-    c.dbg[(*c.call * 8 + c.wave) * 4 + 3] = ((long long)cout << 32) | ((long long)cin << 8) | ktaps;
-  }
-  if (c.nta == 1) {
-    // tail workgroup: only columns 0..15 are live -> one n-tile, m-tiles spread over the waves
-    if (mtiles == 16) gemm_fixed<L, 2, 1>(c, wp, 2 * w, 0, true, src, cin, ktaps, dst, cout, bias, alias, act);
-    else if (mtiles == 12) gemm_fixed<L, 2, 1>(c, wp, 2 * (w < 6 ? w : 0), 0, w < 6, src, cin, ktaps, dst, cout, bias, alias, act);
-    else gemm_fixed<L, 1, 1>(c, wp, w < mtiles ? w : 0, 0, w < mtiles, src, cin, ktaps, dst, cout, bias, alias, act);
-  } else if (mtiles == 16) {
-    gemm_fixed<L, 2, 4>(c, wp, 2 * w, 0, true, src, cin, ktaps, dst, cout, bias, alias, act);
-  } else if (mtiles == 12) {
-    gemm_fixed<L, 3, 2>(c, wp, 3 * (w & 3), 2 * (w >> 2), true, src, cin, ktaps, dst, cout, bias, alias, act);
-  } else if (mtiles == 8) {
-    gemm_fixed<L, 1, 4>(c, wp, w, 0, true, src, cin, ktaps, dst, cout, bias, alias, act);
-  } else if (mtiles == 4) {
-    gemm_fixed<L, 1, 2>(c, wp, w & 3, 2 * (w >> 2), true, src, cin, ktaps, dst, cout, bias, alias, act);
-  } else if (mtiles == 2) {
-    gemm_fixed<L, 1, 1>(c, wp, w & 1, w >> 1, true, src, cin, ktaps, dst, cout, bias, alias, act);
+  // G3: k = 3 taps (<= 2 m-tiles per sweep), G1: 1x1
+#define GLDM_G3(MT, NT, P, mt0, nt0, on) gemm_passes<NC, L, 3, MT, NT, P>(c, wp, mt0, nt0, on, src, cin, dst, cout, bias, alias, act)
+#define GLDM_G1(MT, NT, P, mt0, nt0, on) gemm_passes<NC, L, 1, MT, NT, P>(c, wp, mt0, nt0, on, src, cin, dst, cout, bias, alias, act)
+  if constexpr (NC == 64) {
+    // 8 waves x 4 n-tiles: the fused set abstraction (1x1 layers only)
+    if (mtiles == 16) GLDM_G1(2, 4, 1, 2 * w, 0, true);
+    else if (mtiles == 12) GLDM_G1(3, 2, 1, 3 * (w & 3), 2 * (w >> 2), true);
+    else if (mtiles == 8) GLDM_G1(1, 4, 1, w, 0, true);
+    else if (mtiles == 4) GLDM_G1(1, 2, 1, w & 3, 2 * (w >> 2), true);
+    else if (mtiles == 2) GLDM_G1(1, 1, 1, w & 1, w >> 1, true);
+    else GLDM_G1(1, 1, 1, 0, w & 3, w < 4);
+  } else if (ktaps == 3) {
+    if (c.nta == 1) {  // tail workgroup: only columns 0..15 are live
+      if (mtiles == 16) GLDM_G3(2, 1, 2, 4 * w, 0, true);
+      else if (mtiles == 12) GLDM_G3(1, 1, 3, 3 * w, 0, true);
+      else if (mtiles == 8) GLDM_G3(2, 1, 1, 2 * w, 0, true);
+      else GLDM_G3(1, 1, 1, w < mtiles ? w : 0, 0, w < mtiles);
+    } else if (mtiles == 16) GLDM_G3(2, 2, 2, 4 * w, 0, true);
+    else if (mtiles == 12) GLDM_G3(1, 2, 3, 3 * w, 0, true);
+    else if (mtiles == 8) GLDM_G3(2, 2, 1, 2 * w, 0, true);
+    else if (mtiles == 4) GLDM_G3(1, 2, 1, w, 0, true);
+    else if (mtiles == 2) GLDM_G3(1, 1, 1, w & 1, w >> 1, true);
+    else GLDM_G3(1, 1, 1, 0, w & 1, w < 2);
   } else {
-    gemm_fixed<L, 1, 1>(c, wp, 0, w & 3, w < 4, src, cin, ktaps, dst, cout, bias, alias, act);
+    if (c.nta == 1) {
+      if (mtiles == 16) GLDM_G1(4, 1, 1, 4 * w, 0, true);
+      else if (mtiles == 12) GLDM_G1(3, 1, 1, 3 * w, 0, true);
+      else if (mtiles == 8) GLDM_G1(2, 1, 1, 2 * w, 0, true);
+      else GLDM_G1(1, 1, 1, w < mtiles ? w : 0, 0, w < mtiles);
+    } else if (mtiles == 16) GLDM_G1(4, 2, 1, 4 * w, 0, true);
+    else if (mtiles == 12) GLDM_G1(3, 2, 1, 3 * w, 0, true);
+    else if (mtiles == 8) GLDM_G1(2, 2, 1, 2 * w, 0, true);
+    else if (mtiles == 4) GLDM_G1(1, 2, 1, w, 0, true);
+    else if (mtiles == 2) GLDM_G1(1, 1, 1, w & 1, w >> 1, true);
+    else GLDM_G1(1, 1, 1, 0, w & 1, w < 2);
   }
+#undef GLDM_G3
+#undef GLDM_G1
   __syncthreads();
-  if (c.dbg && c.lane == 0) c.dbg[(*c.call * 8 + c.wave) * 4 + 2] = (long long)__builtin_readcyclecounter();
-  if (c.dbg) ++*c.call;
 }
 
 // ----------------------------------------------------------- GroupNorm ----
 // In place on `buf` (or accumulated into `res` when given):
 //   y = silu( GN(buf) * gamma + beta  [ * scale_sum + shift_sum ] )  [ + res ]
-// lane = column; a group's channels are split over the waves that own it; all loads of a
-// wave are issued up front (rows are register resident through both statistics passes).
-template <int L, int RPW>
+// lane = (sub, column): a wave reads kRP consecutive rows per pass, conflict free; a group's
+// rows belong to one wave (no exchange) or to `awpg` waves that swap two scalars through LDS.
+// All loads of a wave are issued up front (rows stay in registers through both passes).
+template <int NC, int L, int ITERS>
 __device__ __forceinline__ void group_norm_rows(const Ctx &c, float *buf, float *res, int C, int cpg, int wpg, int awpg,
-                                                int gamma_off, int beta_off, const float *ss, int S) {
-  float *red1 = c.lds + kMiscRed1, *red2 = c.lds + kMiscRed2;
-  const int n = c.lane, s = n / L;
-  const int g = c.wave / wpg, sub = c.wave % wpg;
-  const bool active = sub < awpg;
-  const int row0 = g * cpg + (active ? sub : 0) * RPW;
-  float v[RPW], sc[RPW], sh[RPW];
+                                                int rpw, int gamma_off, int beta_off, const float *ss, int S) {
+  using GG = Geo<NC>;
+  float *red1 = c.lds + GG::kMiscRed1, *red2 = c.lds + GG::kMiscRed2;
+  const int n = c.lane & (NC - 1), sub = c.lane / NC, s = n / L;
+  const int g = c.wave / wpg, subw = c.wave % wpg;
+  const bool active_w = subw < awpg;
+  const int row0 = g * cpg + (active_w ? subw : 0) * rpw;
+  lds_f *b3 = (lds_f *)buf;
+  float v[ITERS], sc[ITERS], sh[ITERS];
+  bool ok[ITERS];
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) v[i] = buf[swz(row0 + i, n)];
-  if (ss) {
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      sc[i] = ss[(row0 + i) * S + s];
-      sh[i] = ss[(C + row0 + i) * S + s];
+  for (int i = 0; i < ITERS; ++i) {
+    const int rr = i * GG::kRP + sub;
+    ok[i] = active_w && rr < rpw;
+    const int row = row0 + (rr < rpw ? rr : 0);
+    v[i] = b3[swz<NC>(row, n)];
+    if (ss) {
+      sc[i] = ss[row * S + s];
+      sh[i] = ss[(C + row) * S + s];
     }
   }
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) sum += v[i];
+  for (int i = 0; i < ITERS; ++i) sum += ok[i] ? v[i] : 0.f;
 #pragma unroll
   for (int off = 1; off < L; off <<= 1) sum += __shfl_xor(sum, off, 64);
-  red1[c.wave * kCols + n] = active ? sum : 0.f;
-  __syncthreads();
+  if (GG::kRP == 2) sum += __shfl_xor(sum, 32, 64);
+  if (awpg > 1) {
+    red1[c.wave * 64 + c.lane] = active_w ? sum : 0.f;
+    __syncthreads();
+    sum = 0.f;
+    for (int q = 0; q < awpg; ++q) sum += red1[(g * wpg + q) * 64 + c.lane];
+  }
   const float cnt = (float)(cpg * L);
-  float tot = 0.f;
-  for (int q = 0; q < awpg; ++q) tot += red1[(g * wpg + q) * kCols + n];
-  const float mean = tot / cnt;
+  const float mean = sum / cnt;
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
+  for (int i = 0; i < ITERS; ++i) {
     const float d = v[i] - mean;
-    sq += d * d;
+    sq += ok[i] ? d * d : 0.f;
   }
 #pragma unroll
   for (int off = 1; off < L; off <<= 1) sq += __shfl_xor(sq, off, 64);
-  red2[c.wave * kCols + n] = active ? sq : 0.f;
-  __syncthreads();
-  float vt = 0.f;
-  for (int q = 0; q < awpg; ++q) vt += red2[(g * wpg + q) * kCols + n];
-  const float rstd = 1.0f / sqrtf(vt / cnt + 1e-5f);
+  if (GG::kRP == 2) sq += __shfl_xor(sq, 32, 64);
+  if (awpg > 1) {
+    red2[c.wave * 64 + c.lane] = active_w ? sq : 0.f;
+    __syncthreads();
+    sq = 0.f;
+    for (int q = 0; q < awpg; ++q) sq += red2[(g * wpg + q) * 64 + c.lane];
+  }
+  const float rstd = 1.0f / sqrtf(sq / cnt + 1e-5f);
   const float *gamma = c.w + gamma_off, *beta = c.w + beta_off;
-  if (active) {
+  lds_f *r3 = (lds_f *)res;
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int row = row0 + i;
+  for (int i = 0; i < ITERS; ++i) {
+    if (ok[i]) {
+      const int row = row0 + i * GG::kRP + sub;
       float y = (v[i] - mean) * rstd * gamma[row] + beta[row];
       if (ss) y = y * sc[i] + sh[i];
       y = silu(y);
-      const int a = swz(row, n);
-      if (res) res[a] = res[a] + y;
-      else buf[a] = y;
+      const int a = swz<NC>(row, n);
+      if (res) r3[a] = r3[a] + y;
+      else b3[a] = y;
     }
   }
   __syncthreads();
 }
 
-template <int L>
-__device__ __noinline__ void group_norm_pass(const Ctx &c, float *buf, float *res, int C, int groups, int gamma_off,
+template <int NC, int L>
+__device__ __forceinline__ void group_norm_pass(const Ctx &c, float *buf, float *res, int C, int groups, int gamma_off,
                                              int beta_off, const float *ss, int S) {
   if (c.skip & 1) return;
-  const int cpg = C / groups;            // channels per group
-  const int wpg = kWaves / groups;       // waves that share one group
+  using GG = Geo<NC>;
+  C = __builtin_amdgcn_readfirstlane(C);
+  groups = __builtin_amdgcn_readfirstlane(groups);
+  const int cpg = C / groups;                 // channels per group
+  const int wpg = GG::kWaves / groups;        // waves that share one group (>= 1: validate())
   const int awpg = cpg < wpg ? cpg : wpg;
-  const int rpw = cpg / awpg;            // rows per active wave (power of two <= 32)
-  switch (rpw) {
-    case 1: group_norm_rows<L, 1>(c, buf, res, C, cpg, wpg, awpg, gamma_off, beta_off, ss, S); break;
-    case 2: group_norm_rows<L, 2>(c, buf, res, C, cpg, wpg, awpg, gamma_off, beta_off, ss, S); break;
-    case 4: group_norm_rows<L, 4>(c, buf, res, C, cpg, wpg, awpg, gamma_off, beta_off, ss, S); break;
-    case 8: group_norm_rows<L, 8>(c, buf, res, C, cpg, wpg, awpg, gamma_off, beta_off, ss, S); break;
-    case 16: group_norm_rows<L, 16>(c, buf, res, C, cpg, wpg, awpg, gamma_off, beta_off, ss, S); break;
-    default: group_norm_rows<L, 32>(c, buf, res, C, cpg, wpg, awpg, gamma_off, beta_off, ss, S); break;
+  const int rpw = cpg / awpg;                 // rows per active wave (power of two <= 64)
+  const int iters = (rpw + GG::kRP - 1) / GG::kRP;
+#define GLDM_GN(I) group_norm_rows<NC, L, I>(c, buf, res, C, cpg, wpg, awpg, rpw, gamma_off, beta_off, ss, S)
+  switch (iters) {
+    case 1: GLDM_GN(1); break;
+    case 2: GLDM_GN(2); break;
+    case 4: GLDM_GN(4); break;
+    case 8: GLDM_GN(8); break;
+    case 16: GLDM_GN(16); break;
+    default: GLDM_GN(32); break;
   }
+#undef GLDM_GN
 }
 
 // ----------------------------------------------------------- LayerNorm ----
-// dst = LN_channels(src) * g  (or res += LN(src) * g when res != null)
-template <int RPW>
+// dst = LN_channels(src) * g  (or res += LN(src) * g when res != null).  Row slot = wave*kRP + sub
+// (8 slots in both geometries), rows slot + 8 i.
+template <int NC, int ITERS>
 __device__ __forceinline__ void layer_norm_rows(const Ctx &c, const float *src, float *dst, float *res, int C,
                                                 int g_off) {
-  float *red1 = c.lds + kMiscRed1, *red2 = c.lds + kMiscRed2;
-  const int n = c.lane;
-  float v[RPW];
+  using GG = Geo<NC>;
+  float *red1 = c.lds + GG::kMiscRed1, *red2 = c.lds + GG::kMiscRed2;
+  const int n = c.lane & (NC - 1), slot = c.wave * GG::kRP + c.lane / NC;
+  const lds_f *s3 = (const lds_f *)src;
+  float v[ITERS];
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int row = c.wave + i * kWaves;
-    const float x = src[swz(row < C ? row : 0, n)];
+  for (int i = 0; i < ITERS; ++i) {
+    const int row = slot + 8 * i;
+    const float x = s3[swz<NC>(row < C ? row : 0, n)];
     v[i] = row < C ? x : 0.f;
     sum += v[i];
   }
-  red1[c.wave * kCols + n] = sum;
+  if (GG::kRP == 2) sum += __shfl_xor(sum, 32, 64);
+  red1[c.wave * 64 + c.lane] = sum;
   __syncthreads();
   float tot = 0.f;
 #pragma unroll
-  for (int q = 0; q < kWaves; ++q) tot += red1[q * kCols + n];
+  for (int q = 0; q < GG::kWaves; ++q) tot += red1[q * 64 + c.lane];
   const float mean = tot / (float)C;
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int row = c.wave + i * kWaves;
+  for (int i = 0; i < ITERS; ++i) {
+    const int row = slot + 8 * i;
     const float d = row < C ? v[i] - mean : 0.f;
     sq += d * d;
   }
-  red2[c.wave * kCols + n] = sq;
+  if (GG::kRP == 2) sq += __shfl_xor(sq, 32, 64);
+  red2[c.wave * 64 + c.lane] = sq;
   __syncthreads();
   float vt = 0.f;
 #pragma unroll
-  for (int q = 0; q < kWaves; ++q) vt += red2[q * kCols + n];
+  for (int q = 0; q < GG::kWaves; ++q) vt += red2[q * 64 + c.lane];
   const float rstd = 1.0f / sqrtf(vt / (float)C + 1e-5f);
   const float *g = c.w + g_off;
+  lds_f *d3 = (lds_f *)dst, *r3 = (lds_f *)res;
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int row = c.wave + i * kWaves;
+  for (int i = 0; i < ITERS; ++i) {
+    const int row = slot + 8 * i;
     if (row < C) {
       const float y = (v[i] - mean) * rstd * g[row];
-      const int a = swz(row, n);
-      if (res) res[a] = res[a] + y;
-      else dst[a] = y;
+      const int a = swz<NC>(row, n);
+      if (res) r3[a] = r3[a] + y;
+      else d3[a] = y;
     }
   }
   __syncthreads();
 }
 
-__device__ __noinline__ void layer_norm_pass(const Ctx &c, const float *src, float *dst, float *res, int C, int g_off) {
+template <int NC>
+__device__ __forceinline__ void layer_norm_pass(const Ctx &c, const float *src, float *dst, float *res, int C, int g_off) {
   if (c.skip & 2) return;
-  const int rpw = (C + kWaves - 1) / kWaves;
-  if (rpw <= 1) layer_norm_rows<1>(c, src, dst, res, C, g_off);
-  else if (rpw <= 2) layer_norm_rows<2>(c, src, dst, res, C, g_off);
-  else if (rpw <= 4) layer_norm_rows<4>(c, src, dst, res, C, g_off);
-  else if (rpw <= 8) layer_norm_rows<8>(c, src, dst, res, C, g_off);
-  else layer_norm_rows<16>(c, src, dst, res, C, g_off);
+  C = __builtin_amdgcn_readfirstlane(C);
+  const int it = (C + 7) / 8;
+  if (it <= 1) layer_norm_rows<NC, 1>(c, src, dst, res, C, g_off);
+  else if (it <= 2) layer_norm_rows<NC, 2>(c, src, dst, res, C, g_off);
+  else if (it <= 4) layer_norm_rows<NC, 4>(c, src, dst, res, C, g_off);
+  else if (it <= 8) layer_norm_rows<NC, 8>(c, src, dst, res, C, g_off);
+  else layer_norm_rows<NC, 16>(c, src, dst, res, C, g_off);
 }
 
 // -------------------------------------------------- linear attention -------
-// qkv: [192][64] = q(2 heads x 32) | k | v for one head pair; writes 64 rows of o.
-// Wave w: head hl = w >> 2 of the pair, output rows e in [8 (w & 3), +8).
-template <int L>
-__device__ __noinline__ void attention_pair(const Ctx &c, float *qkv, float *o_rows) {
+// qkv: [192][NC] = q(2 heads x 32) | k | v for one head pair; writes 64 rows of o.
+// The 32 channels of a head are split in 4 parts of 8 over (waves of the head) x (row slots).
+template <int NC, int L>
+__device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *o_rows) {
   if (c.skip & 4) return;
-  const int n = c.lane, sbase = n & ~(L - 1);
-  const int hl = c.wave >> 2, part = c.wave & 3, e0 = 8 * part;
+  using GG = Geo<NC>;
+  constexpr int WPH = GG::kWaves / 2;       // waves per head
+  const int n = c.lane & (NC - 1), sub = c.lane / NC, sbase = n & ~(L - 1);
+  const int hl = c.wave / WPH, part = (c.wave % WPH) * GG::kRP + sub, e0 = 8 * part;
   const int qrow0 = hl * kDimHead, krow0 = 64 + hl * kDimHead, vrow0 = 128 + hl * kDimHead;
+  const lds_f *q3 = (const lds_f *)qkv;
+  lds_f *o3 = (lds_f *)o_rows;
   if constexpr (L == 4) {
-    // The 32 head channels are split over the 4 waves of a head (8 each); softmax statistics
-    // and the 4x4 matrix A = softmax_n(k)^T softmax_d(q) are combined through LDS.
-    float *red1 = c.lds + kMiscRed1, *red2 = c.lds + kMiscRed2;
-    float *part_a = qkv;  // q rows are dead after phase 1: [8 waves][4][64] partial A
+    // softmax statistics and the 4x4 matrix A = softmax_n(k)^T softmax_d(q) are combined over
+    // the parts by a lane swap (row slots) and one exchange through LDS (waves)
+    float *red1 = c.lds + GG::kMiscRed1, *red2 = c.lds + GG::kMiscRed2;
+    lds_f *part_a = (lds_f *)qkv;  // q rows are dead after phase 1: [kWaves][4][64] partial A
     float q[8];
     float qmax = -3.0e38f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      q[i] = qkv[swz(qrow0 + e0 + i, n)];
+      q[i] = q3[swz<NC>(qrow0 + e0 + i, n)];
       qmax = fmaxf(qmax, q[i]);
     }
-    float4 kv[8];
+    f32x4 kv[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const float4 *>(&qkv[swz(krow0 + e0 + i, sbase)]);
-    red1[c.wave * kCols + n] = qmax;
+    for (int i = 0; i < 8; ++i) kv[i] = *(const lds_f4 *)(q3 + swz<NC>(krow0 + e0 + i, sbase));
+    if (GG::kRP == 2) qmax = fmaxf(qmax, __shfl_xor(qmax, 32, 64));
+    red1[c.wave * 64 + c.lane] = qmax;
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 4; ++w) qmax = fmaxf(qmax, red1[(hl * 4 + w) * kCols + n]);
+    for (int w = 0; w < WPH; ++w) qmax = fmaxf(qmax, red1[(hl * WPH + w) * 64 + c.lane]);
     float qsum = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -521,48 +587,53 @@ __device__ __noinline__ void attention_pair(const Ctx &c, float *qkv, float *o_r
       const float f = e * __builtin_amdgcn_rcpf(k0 + k1 + k2 + k3);
       a0 += k0 * f; a1 += k1 * f; a2 += k2 * f; a3 += k3 * f;
     }
-    red2[c.wave * kCols + n] = qsum;
-    part_a[(c.wave * 4 + 0) * kCols + n] = a0;
-    part_a[(c.wave * 4 + 1) * kCols + n] = a1;
-    part_a[(c.wave * 4 + 2) * kCols + n] = a2;
-    part_a[(c.wave * 4 + 3) * kCols + n] = a3;
-    float4 vv[8];
+    if (GG::kRP == 2) {
+      qsum += __shfl_xor(qsum, 32, 64);
+      a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
+      a2 += __shfl_xor(a2, 32, 64); a3 += __shfl_xor(a3, 32, 64);
+    }
+    red2[c.wave * 64 + c.lane] = qsum;
+    part_a[(c.wave * 4 + 0) * 64 + c.lane] = a0;
+    part_a[(c.wave * 4 + 1) * 64 + c.lane] = a1;
+    part_a[(c.wave * 4 + 2) * 64 + c.lane] = a2;
+    part_a[(c.wave * 4 + 3) * 64 + c.lane] = a3;
+    f32x4 vv[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) vv[i] = *reinterpret_cast<const float4 *>(&qkv[swz(vrow0 + e0 + i, sbase)]);
+    for (int i = 0; i < 8; ++i) vv[i] = *(const lds_f4 *)(q3 + swz<NC>(vrow0 + e0 + i, sbase));
     __syncthreads();
     qsum = 0.f; a0 = a1 = a2 = a3 = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int ww = hl * 4 + w;
-      qsum += red2[ww * kCols + n];
-      a0 += part_a[(ww * 4 + 0) * kCols + n];
-      a1 += part_a[(ww * 4 + 1) * kCols + n];
-      a2 += part_a[(ww * 4 + 2) * kCols + n];
-      a3 += part_a[(ww * 4 + 3) * kCols + n];
+    for (int w = 0; w < WPH; ++w) {
+      const int ww = hl * WPH + w;
+      qsum += red2[ww * 64 + c.lane];
+      a0 += part_a[(ww * 4 + 0) * 64 + c.lane];
+      a1 += part_a[(ww * 4 + 1) * 64 + c.lane];
+      a2 += part_a[(ww * 4 + 2) * 64 + c.lane];
+      a3 += part_a[(ww * 4 + 3) * 64 + c.lane];
     }
     const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(qsum);  // dim_head ** -0.5 / sum
     a0 *= sc; a1 *= sc; a2 *= sc; a3 *= sc;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      o_rows[swz(hl * kDimHead + e0 + i, n)] = vv[i].x * a0 + vv[i].y * a1 + vv[i].z * a2 + vv[i].w * a3;
+      o3[swz<NC>(hl * kDimHead + e0 + i, n)] = vv[i].x * a0 + vv[i].y * a1 + vv[i].z * a2 + vv[i].w * a3;
     __syncthreads();
   } else {
-    // L = 16 (pose decoder, once per grasp): every wave recomputes A for its head
+    // L = 16 (pose decoder, once per grasp): every lane recomputes A for its head and column
     float qmax = -3.0e38f;
-    for (int d = 0; d < kDimHead; ++d) qmax = fmaxf(qmax, qkv[swz(qrow0 + d, n)]);
+    for (int d = 0; d < kDimHead; ++d) qmax = fmaxf(qmax, q3[swz<NC>(qrow0 + d, n)]);
     float qsum = 0.f;
-    for (int d = 0; d < kDimHead; ++d) qsum += fast_exp(qkv[swz(qrow0 + d, n)] - qmax);
+    for (int d = 0; d < kDimHead; ++d) qsum += fast_exp(q3[swz<NC>(qrow0 + d, n)] - qmax);
     const float qscale = 0.17677669529663687f / qsum;
     float A[L];
 #pragma unroll
     for (int i = 0; i < L; ++i) A[i] = 0.f;
     for (int d = 0; d < kDimHead; ++d) {
-      const float qd = fast_exp(qkv[swz(qrow0 + d, n)] - qmax) * qscale;
+      const float qd = fast_exp(q3[swz<NC>(qrow0 + d, n)] - qmax) * qscale;
       float kv[L];
       float kmax = -3.0e38f;
 #pragma unroll
       for (int i = 0; i < L; ++i) {
-        kv[i] = qkv[swz(krow0 + d, sbase + i)];
+        kv[i] = q3[swz<NC>(krow0 + d, sbase + i)];
         kmax = fmaxf(kmax, kv[i]);
       }
       float ksum = 0.f;
@@ -578,8 +649,8 @@ __device__ __noinline__ void attention_pair(const Ctx &c, float *qkv, float *o_r
     for (int e = e0; e < e0 + 8; ++e) {
       float acc = 0.f;
 #pragma unroll
-      for (int i = 0; i < L; ++i) acc += qkv[swz(vrow0 + e, sbase + i)] * A[i];
-      o_rows[swz(hl * kDimHead + e, n)] = acc;
+      for (int i = 0; i < L; ++i) acc += q3[swz<NC>(vrow0 + e, sbase + i)] * A[i];
+      o3[swz<NC>(hl * kDimHead + e, n)] = acc;
     }
     __syncthreads();
   }
@@ -604,24 +675,23 @@ struct RunArgs {
   float *out1;            // decode: logit [n]
   float *ws;              // [tiles][ss_rows][S]
   int skip;               // diagnostic phase-skip mask (GLDM_R1D_SKIP env; 0 in production)
-  long long *dbg;         // diagnostic per-GEMM stamps (GLDM_R1D_STAMP env)
   int full_tiles, tail_tiles, tail_samples;
 };
 
 // scale/shift rows of one ResnetBlock: ss[row][s] = Wmlp[row,:] . G[s,:] + (R b + R on scale rows),
 // rows 0..C-1 = sum_r (scale_r + 1), rows C..2C-1 = sum_r shift_r.  One 16x16 MFMA tile per 16
 // rows (N = the tile's samples), written to this workgroup's L2-resident scratch [2C][S].
-template <int L>
-__device__ __noinline__ void scale_shift_table(const Ctx &c, const gldm_r1d_resblock &rb, int C, int E, float *ss,
-                                               int S) {
+template <int NC>
+__device__ __forceinline__ void scale_shift_table(const Ctx &c, int ss_w, int ss_b, int C, int E, float *ss, int S) {
   if (c.skip & 16) return;
-  const float *G = c.lds + kMiscG;
+  using GG = Geo<NC>;
+  const lds_f *G = (const lds_f *)(c.lds + GG::kMiscG);
   const int col = c.lane & 15, kq = c.lane >> 4;
   const int sidx = col < S ? col : S - 1;
   const int mtiles = (2 * C + 15) >> 4, kblocks = (E + 15) >> 4;
-  const f32x4 *wv = reinterpret_cast<const f32x4 *>(c.w + rb.ss_w);
-  const float *bias = c.w + rb.ss_b;
-  for (int mt = c.wave; mt < mtiles; mt += kWaves) {
+  const f32x4 *wv = reinterpret_cast<const f32x4 *>(c.w + ss_w);
+  const float *bias = c.w + ss_b;
+  for (int mt = c.wave; mt < mtiles; mt += GG::kWaves) {
     f32x4 acc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -647,27 +717,88 @@ __device__ __noinline__ void scale_shift_table(const Ctx &c, const gldm_r1d_resb
   }
 }
 
-template <int L>
-__device__ void resnet_block(const Ctx &c, const gldm_r1d_desc &d, const gldm_r1d_resblock &rb, int C,
-                             float *ss_tile, int S) {
-  float *X = c.lds + kBufX, *H = c.lds + kBufH;
-  scale_shift_table<L>(c, rb, C, d.emb_dim, ss_tile, S);  // published by the barrier that ends conv_gemm
-  conv_gemm<L>(c, rb.c1_w, rb.c1_b, X, C, 3, H, C, false);
-  group_norm_pass<L>(c, H, nullptr, C, d.groups, rb.n1_w, rb.n1_b, (c.skip & 16) ? nullptr : ss_tile, S);
-  conv_gemm<L>(c, rb.c2_w, rb.c2_b, H, C, 3, H, C, true);
-  group_norm_pass<L>(c, H, X, C, d.groups, rb.n2_w, rb.n2_b, nullptr, S);
+// One denoiser / decoder step is a fixed program of ~80 barrier-separated ops.  It is written once
+// per workgroup into LDS (8 ints per op) and interpreted by a switch inside the step loop, so every
+// phase body exists once, inlined, with registers allocated across the whole kernel: no calls, no
+// callee-save traffic and no spilled kernel state between phases.
+enum { OP_SS = 0, OP_CONV = 1, OP_GN = 2, OP_LN = 3, OP_ATT = 4 };
+constexpr int kMaxOps = 128;
+
+template <int NC>
+__device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
+  using GG = Geo<NC>;
+  int n = 0;
+  auto emit = [&](int type, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0, int a6 = 0, int a7 = 0) {
+    int *o = tape + 8 * n++;
+    o[0] = type; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; o[6] = a6; o[7] = a7;
+  };
+  constexpr int X = GG::kBufX, H = GG::kBufH, Y = GG::kBufY, O = GG::kBufO, QKV = GG::kBufQKV;
+  auto resblock = [&](const gldm_r1d_resblock &rb, int C) {
+    emit(OP_SS, rb.ss_w, rb.ss_b, C);                      // published by the barrier that ends the conv
+    emit(OP_CONV, rb.c1_w, rb.c1_b, X, H, C, C, 3);
+    emit(OP_GN, H, -1, C, rb.n1_w, rb.n1_b, 1);
+    emit(OP_CONV, rb.c2_w, rb.c2_b, H, H, C, C, 3 | 256);  // in place: alias
+    emit(OP_GN, H, X, C, rb.n2_w, rb.n2_b, 0);
+  };
+  // constant indices only: a dynamically indexed kernel argument is copied to scratch memory
+#pragma unroll
+  for (int lv = 0; lv < GLDM_R1D_MAX_LEVELS; ++lv) {
+    if (lv < d.n_levels) {
+      const int C = d.dims[lv], Cn = d.dims[lv + 1];
+      resblock(d.rb[2 * lv], C);
+      resblock(d.rb[2 * lv + 1], C);
+      const gldm_r1d_level &v = d.lv[lv];
+      emit(OP_LN, X, Y, -1, C, v.ln_g);
+      emit(OP_CONV, v.qkv_w[0], -1, Y, QKV, C, 192, 1);
+      emit(OP_ATT, QKV, O);
+      emit(OP_CONV, v.qkv_w[1], -1, Y, QKV, C, 192, 1);
+      emit(OP_ATT, QKV, O + 64 * NC);
+      emit(OP_CONV, v.out_w, v.out_b, O, Y, kHidden, C, 1);
+      emit(OP_LN, Y, -1, X, C, v.ln2_g);
+      emit(OP_CONV, v.down_w, v.down_b, X, X, C, Cn, 3 | 256);
+    }
+  }
+#pragma unroll
+  for (int lv = 1; lv <= GLDM_R1D_MAX_LEVELS; ++lv)
+    if (lv == d.n_levels) resblock(d.rb[2 * lv], d.dims[lv]);
+  return n;
 }
 
-template <int L>
-__device__ void attention_block(const Ctx &c, const gldm_r1d_level &lv, int C) {
-  float *X = c.lds + kBufX, *Y = c.lds + kBufY, *O = c.lds + kBufO, *QKV = c.lds + kBufQKV;
-  layer_norm_pass(c, X, Y, nullptr, C, lv.ln_g);
-  for (int p = 0; p < 2; ++p) {
-    conv_gemm<L>(c, lv.qkv_w[p], -1, Y, C, 1, QKV, 192, false);
-    attention_pair<L>(c, QKV, O + p * 64 * kCols);
+template <int NC, int L>
+__device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_ops, int groups, int E, float *ss_tile) {
+  constexpr int S = NC / L;
+  for (int op = 0; op < n_ops; ++op) {
+    // the lane ids are laundered per op: otherwise every variant's lane-derived LDS offsets are
+    // hoisted out of the step loop as invariants and live (spilled) across the whole kernel
+    Ctx c = c0;
+    asm volatile("" : "+v"(c.tid), "+v"(c.lane));
+    int o[8];
+    {
+      const int4 lo = *reinterpret_cast<const int4 *>(tape + 8 * op), hi = *reinterpret_cast<const int4 *>(tape + 8 * op + 4);
+      o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = __builtin_amdgcn_readfirstlane(o[i]);
+    }
+    switch (o[0]) {
+      case OP_SS:
+        scale_shift_table<NC>(c, o[1], o[2], o[3], E, ss_tile, S);
+        break;
+      case OP_CONV:
+        conv_gemm<NC, L>(c, o[1], o[2], c.lds + o[3], o[5], o[7] & 255, c.lds + o[4], o[6], (o[7] & 256) != 0);
+        break;
+      case OP_GN:
+        group_norm_pass<NC, L>(c, c.lds + o[1], o[2] >= 0 ? c.lds + o[2] : nullptr, o[3], groups, o[4], o[5],
+                               (o[6] && !(c.skip & 16)) ? ss_tile : nullptr, S);
+        break;
+      case OP_LN:
+        layer_norm_pass<NC>(c, c.lds + o[1], o[2] >= 0 ? c.lds + o[2] : nullptr, o[3] >= 0 ? c.lds + o[3] : nullptr,
+                            o[4], o[5]);
+        break;
+      default:
+        attention_pair<NC, L>(c, c.lds + o[1], c.lds + o[2]);
+        break;
+    }
   }
-  conv_gemm<L>(c, lv.out_w, lv.out_b, O, kHidden, 1, Y, C, false);
-  layer_norm_pass(c, Y, nullptr, X, C, lv.ln2_g);
 }
 
 #pragma clang fp contract(off)
@@ -690,32 +821,39 @@ __device__ __forceinline__ float scheduler_update(int kind, int clip, const floa
 }
 #pragma clang fp contract(fast)
 
-template <int L>
-__global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
+template <int NC, int L>
+__global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs a) {
+  using GG = Geo<NC>;
   extern __shared__ float lds[];
   const gldm_r1d_desc &d = a.d;
-  constexpr int S = kCols / L;
-  int call_idx = 0;
-  Ctx c{a.weights, lds, (int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, a.skip,
-        blockIdx.x == 0 ? a.dbg : nullptr, &call_idx, 4};
+  constexpr int S = NC / L;
+  Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
+        a.skip, GG::kNT};
   // Tiles: the first `full_tiles` workgroups own S samples each; the remainder of the batch is
-  // spread over `tail_tiles` workgroups of `tail_samples` (one 16-column n-tile when it fits)
-  // so that the last wave of workgroups is not 64-column tiles on a quarter of the CUs.
+  // spread over `tail_tiles` workgroups of `tail_samples` (one live 16-column n-tile) so the last
+  // round of workgroups is not full-width tiles on a fraction of the CUs.
   const int tile = blockIdx.x;
   const bool is_tail = tile >= a.full_tiles;
   const int samp0 = is_tail ? a.full_tiles * S + (tile - a.full_tiles) * a.tail_samples : tile * S;
-  c.nta = (is_tail && a.tail_samples * L <= 16) ? 1 : 4;
+  c.nta = (is_tail && a.tail_samples * L <= 16) ? 1 : GG::kNT;
   const int nsamp = is_tail ? a.tail_samples : S;  // samples this workgroup owns
   const int E = d.emb_dim, R = d.cond_rows;
-  float *lat = lds + kMiscLat, *epsr = lds + kMiscEps, *G = lds + kMiscG;
-  float *X = lds + kBufX;
+  float *lat = lds + GG::kMiscLat, *epsr = lds + GG::kMiscEps, *G = lds + GG::kMiscG;
+  float *X = lds + GG::kBufX;
   float *ss_tile = a.ws + (size_t)tile * d.ss_rows * S;  // [2 Cmax][S], reused by every ResnetBlock
   const bool has_in = d.latent_dim > 0, has_head = d.n_head > 0;
+  int CF = d.dims[1];  // width of the last level (constant indices: see build_tape)
+#pragma unroll
+  for (int lv = 2; lv <= GLDM_R1D_MAX_LEVELS; ++lv) CF = lv == d.n_levels ? d.dims[lv] : CF;
 
-  for (int i = c.tid; i < kLdsFloats; i += kThreads) lds[i] = 0.f;  // dead columns must stay finite
+  for (int i = c.tid; i < GG::kLdsFloats; i += GG::kThreads) lds[i] = 0.f;  // dead columns must stay finite
   __syncthreads();
+  int *tape = reinterpret_cast<int *>(lds + GG::kMiscTape);
+  if (c.tid == 0) tape[8 * (kMaxOps - 1)] = build_tape<NC>(d, tape);
+  __syncthreads();
+  const int n_ops = __builtin_amdgcn_readfirstlane(tape[8 * (kMaxOps - 1)]);
   // ---- latent row for this tile
-  if (c.tid < kCols) {
+  if (c.tid < NC) {
     const int s = c.tid / L, l = c.tid % L;
     const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
     float v;
@@ -731,9 +869,8 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
   __syncthreads();
 
   for (int step = 0; step < a.n_steps; ++step) {
-    call_idx = 0;
     // ---- G[s][e] = sum_r silu(temb[t][e] + cemb[cond][r][e])
-    for (int i = c.tid; i < S * E; i += kThreads) {
+    for (int i = c.tid; i < S * E; i += GG::kThreads) {
       const int s = i / E, e = i - s * E;
       const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
       const float *ce = a.cemb + ((size_t)(gi / a.samples_per_cond) * R) * E + e;
@@ -746,11 +883,10 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
       for (int r = 0; r < R; ++r) g += silu(te + ce[r * E]);
       G[s * E + e] = g;
     }
-    __syncthreads();
-    // ---- init conv (k = 7, one input channel)
+    // ---- init conv (k = 7, one input channel); the barrier below also publishes G
     const int C0 = d.dims[0];
-    for (int i = c.tid; i < C0 * kCols; i += kThreads) {
-      const int ch = i / kCols, n = i - ch * kCols;
+    for (int i = c.tid; i < C0 * NC; i += GG::kThreads) {
+      const int ch = i / NC, n = i - ch * NC;
       const int l = n & (L - 1), base = n - l;
       float acc = a.weights[d.init_b + ch];
       const float *wk = a.weights + d.init_w + ch * 7;
@@ -759,32 +895,25 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
         const int p = l + q - 3;
         if (p >= 0 && p < L) acc += wk[q] * lat[base + p];
       }
-      X[swz(ch, n)] = acc;
+      X[swz<NC>(ch, n)] = acc;
     }
     __syncthreads();
 
-    int rbi = 0;
-    for (int lv = 0; lv < d.n_levels; ++lv) {
-      const int C = d.dims[lv], Cn = d.dims[lv + 1];
-      resnet_block<L>(c, d, d.rb[rbi++], C, ss_tile, S);
-      resnet_block<L>(c, d, d.rb[rbi++], C, ss_tile, S);
-      attention_block<L>(c, d.lv[lv], C);
-      conv_gemm<L>(c, d.lv[lv].down_w, d.lv[lv].down_b, X, C, 3, X, Cn, true);
-    }
-    const int CF = d.dims[d.n_levels];
-    resnet_block<L>(c, d, d.rb[rbi], CF, ss_tile, S);
+    run_tape<NC, L>(c, tape, n_ops, d.groups, E, ss_tile);
 
     // ---- final 1x1 conv to one channel: eps[n] = b + sum_c w[c] X[c][n]
     {
-      float *red1 = lds + kMiscRed1;
+      float *red1 = lds + GG::kMiscRed1;
+      const int n = c.lane & (NC - 1), slot = c.wave * GG::kRP + c.lane / NC;
       float part = 0.f;
-      for (int row = c.wave; row < CF; row += kWaves) part += a.weights[d.final_w + row] * X[swz(row, c.lane)];
-      red1[c.wave * kCols + c.lane] = part;
+      for (int row = slot; row < CF; row += 8) part += a.weights[d.final_w + row] * X[swz<NC>(row, n)];
+      if (GG::kRP == 2) part += __shfl_xor(part, 32, 64);
+      red1[c.wave * 64 + c.lane] = part;
       __syncthreads();
-      if (c.tid < kCols) {
+      if (c.tid < NC) {
         float e = a.weights[d.final_b];
 #pragma unroll
-        for (int q = 0; q < kWaves; ++q) e += red1[q * kCols + c.tid];
+        for (int q = 0; q < GG::kWaves; ++q) e += red1[q * 64 + c.tid];
         epsr[c.tid] = e;
         if (a.sched_kind != GLDM_SCHED_NONE) {
           const int s = c.tid / L, l = c.tid % L;
@@ -802,7 +931,7 @@ __global__ __launch_bounds__(kThreads, 2) void r1d_kernel(const RunArgs a) {
 
   // ---- outputs
   if (!has_head) {
-    if (c.tid < kCols) {
+    if (c.tid < NC) {
       const int s = c.tid / L, l = c.tid % L;
       const int gi = samp0 + s;
       if (s < nsamp && gi < a.n_samples) a.out0[(size_t)gi * L + l] = a.sched_kind == GLDM_SCHED_NONE ? epsr[c.tid] : lat[c.tid];
@@ -868,12 +997,12 @@ __global__ void pose_epilogue_kernel(const float *__restrict__ tmrp, const float
 // PointNetSAModule core (ext/pvcnn/modules/pointnet.py:100-111 without the FPS):
 //   grouped = cat(p[idx] - centre, f[idx])          (BallQuery.forward)
 //   out[b, :, j] = max_k  SharedMLP2d(grouped)[b, :, j, k]
-// One workgroup = one 64-column tile = 64/U centres x U neighbours.  The grouped tensor
-// ([B, 3+C, M, U], 4.3 MB per cloud at SSG-SA2) never exists in HBM: the neighbour tile is
-// gathered straight into LDS, the MLP layers (BatchNorm folded, ReLU) run on the same
-// f32-MFMA GEMM core as the ResNet1D engine with weights streamed from L2, and the max
-// over the U neighbours is taken on chip.  HBM traffic: 12N + 4CN + 12M + 4MU (idx)
-// in, 4 Cout M out per cloud.
+// One workgroup = one 64-column tile = 64/U centres x U neighbours (NC = 64 geometry).  The
+// grouped tensor ([B, 3+C, M, U], 4.3 MB per cloud at SSG-SA2) never exists in HBM: the
+// neighbour tile is gathered straight into LDS, the MLP layers (BatchNorm folded, ReLU) run on
+// the same f32-MFMA GEMM core as the ResNet1D engine with weights streamed from L2, and the max
+// over the U neighbours is taken on chip.  HBM traffic: 12N + 4CN + 12M + 4MU (idx) in,
+// 4 Cout M out per cloud.
 struct SaArgs {
   const float *points, *centers, *feat;
   const int32_t *idx;
@@ -883,66 +1012,70 @@ struct SaArgs {
   int cin_pad[4], cout[4], w_off[4], b_off[4];
 };
 
-__global__ __launch_bounds__(kThreads, 2) void sa_mlp_kernel(const SaArgs a) {
+__global__ __launch_bounds__(Geo<64>::kThreads, 2) void sa_mlp_kernel(const SaArgs a) {
+  using GG = Geo<64>;
+  constexpr int NC = 64;
   extern __shared__ float lds[];
-  Ctx c{a.weights, lds, (int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, 0, nullptr, nullptr, 4};
+  Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
+        0, GG::kNT};
   const int b = blockIdx.y, tile = blockIdx.x;
-  const int cpt = kCols / a.u;                 // centres per tile
+  const int cpt = NC / a.u;                 // centres per tile
   const int j0 = tile * cpt;
   const float *pts = a.points + (size_t)b * 3 * a.n;
   const float *ctr = a.centers + (size_t)b * 3 * a.m;
   const float *feat = a.feat ? a.feat + (size_t)b * a.c * a.n : nullptr;
   const int32_t *idx = a.idx + ((size_t)b * a.m + j0) * a.u;
-  float *X = lds + kBufX, *H = lds + kBufH;
+  float *X = lds + GG::kBufX, *H = lds + GG::kBufH;
   // ---- gather the neighbour tile: rows 0..2 relative coords, 3..3+C features, zero pad
   {
     const int col = c.lane, jj = col / a.u;
     const bool live = j0 + jj < a.m;
     const int id = live ? idx[col] : 0;
     const int rows = a.cin_pad[0];
-    for (int r = c.wave; r < rows; r += kWaves) {
+    for (int r = c.wave; r < rows; r += GG::kWaves) {
       float v = 0.f;
       if (live) {
         if (r < 3) v = pts[r * a.n + id] - ctr[r * a.m + j0 + jj];
         else if (r < 3 + a.c) v = feat[(size_t)(r - 3) * a.n + id];
       }
-      X[swz(r, col)] = v;
+      X[swz<NC>(r, col)] = v;
     }
   }
   __syncthreads();
   // ---- grouped MLP (1x1 convs + folded BN + ReLU), ping-pong X <-> H
   float *src = X, *dst = H;
   for (int l = 0; l < a.n_layers; ++l) {
-    conv_gemm<16>(c, a.w_off[l], a.b_off[l], src, a.cin_pad[l], 1, dst, a.cout[l], false, 1);
+    conv_gemm<NC, 16>(c, a.w_off[l], a.b_off[l], src, a.cin_pad[l], 1, dst, a.cout[l], false, 1);
     float *t = src; src = dst; dst = t;
   }
   // ---- max over the U neighbours of each centre
   const int cout = a.cout[a.n_layers - 1];
   float *out = a.out + (size_t)b * cout * a.m;
-  for (int i = c.tid; i < cout * cpt; i += kThreads) {
+  for (int i = c.tid; i < cout * cpt; i += GG::kThreads) {
     const int row = i / cpt, jj = i - row * cpt;
     if (j0 + jj >= a.m) continue;
     float mx = -3.0e38f;
-    for (int k = 0; k < a.u; ++k) mx = fmaxf(mx, src[swz(row, jj * a.u + k)]);
+    for (int k = 0; k < a.u; ++k) mx = fmaxf(mx, src[swz<NC>(row, jj * a.u + k)]);
     out[(size_t)row * a.m + j0 + jj] = mx;
   }
 }
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+constexpr int kEngineNC = 32;  // denoiser / decoder geometry: 32 columns, two workgroups per CU
+int engine_nc() { return kEngineNC; }
+
 int validate(const gldm_r1d_desc *d) {
   if (!d) return GLDM_ERR_INVALID_ARG;
   if (d->seq_len != 4 && d->seq_len != 16) return GLDM_ERR_UNSUPPORTED;
   if (d->n_levels < 1 || d->n_levels > GLDM_R1D_MAX_LEVELS) return GLDM_ERR_UNSUPPORTED;
-  const int S = kCols / d->seq_len;
+  const int nc = engine_nc(), waves = nc / 8;
+  const int S = nc / d->seq_len;
   if (d->emb_dim <= 0 || S * d->emb_dim > 320) return GLDM_ERR_UNSUPPORTED;
-  if (d->groups <= 0 || kWaves % d->groups != 0) return GLDM_ERR_UNSUPPORTED;
+  if (d->groups <= 0 || waves % d->groups != 0) return GLDM_ERR_UNSUPPORTED;
   for (int i = 0; i <= d->n_levels; ++i) {
     const int C = d->dims[i];
     if (C < d->groups || C > kMaxC || C < 4 || !pow2(C) || C % d->groups != 0) return GLDM_ERR_UNSUPPORTED;
-    const int cpg = C / d->groups, wpg = kWaves / d->groups;
-    const int awpg = cpg < wpg ? cpg : wpg;
-    if (cpg % awpg != 0 || cpg / awpg > 32) return GLDM_ERR_UNSUPPORTED;
     if (i < d->n_levels && C > 128) return GLDM_ERR_UNSUPPORTED;  // attention levels keep 4 regions in LDS
   }
   return GLDM_OK;
@@ -950,7 +1083,7 @@ int validate(const gldm_r1d_desc *d) {
 
 struct Tiling { int full_tiles, tail_tiles, tail_samples; };
 
-Tiling make_tiling(int n_samples, int L) {
+int cu_count() {
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -958,72 +1091,51 @@ Tiling make_tiling(int n_samples, int L) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
-  const int S = kCols / L, unit = 16 / L;  // samples per 64-column tile / per 16-column n-tile
+  return cus;
+}
+
+Tiling make_tiling(int n_samples, int L, int nc) {
+  const int cus = cu_count();
+  const int slots = cus * (nc == 32 ? 2 : 1);     // workgroups resident at once
+  const int S = nc / L, unit = 16 / L, nt = nc / 16;  // samples per tile / per 16-column n-tile
   const int tiles = (n_samples + S - 1) / S;
   Tiling t{tiles, 0, 0};
-  if (tiles <= cus || tiles % cus == 0) return t;
-  const int full = (tiles / cus) * cus;
-  const int left = n_samples - full * S;          // < cus * S samples for the last wave of workgroups
+  if (tiles <= slots || tiles % slots == 0) return t;
+  const int full = (tiles / slots) * slots;
+  const int left = n_samples - full * S;          // < slots * S samples for the last round of workgroups
   const int units = (left + unit - 1) / unit;
-  const int upt = (units + cus - 1) / cus;        // n-tiles per tail workgroup (1..4)
-  if (upt >= 4) return t;
+  const int upt = (units + slots - 1) / slots;    // n-tiles per tail workgroup
+  if (upt >= nt) return t;
   t.full_tiles = full;
   t.tail_samples = upt * unit;
   t.tail_tiles = (left + t.tail_samples - 1) / t.tail_samples;
   return t;
 }
 
+template <int NC, int L>
+int launch_one(const RunArgs &a, int tiles, hipStream_t s) {
+  const size_t lds_bytes = (size_t)Geo<NC>::kLdsFloats * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&r1d_kernel<NC, L>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr = true;
+  }
+  hipLaunchKernelGGL((r1d_kernel<NC, L>), dim3(tiles), dim3(Geo<NC>::kThreads), lds_bytes, s, a);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
 int launch_r1d(const RunArgs &a_in, hipStream_t s) {
-  const int L = a_in.d.seq_len;
-  const Tiling tl = make_tiling(a_in.n_samples, L);
+  const int L = a_in.d.seq_len, nc = engine_nc();
+  const Tiling tl = make_tiling(a_in.n_samples, L, nc);
   const int tiles = tl.full_tiles + tl.tail_tiles;
-  const size_t lds_bytes = (size_t)kLdsFloats * sizeof(float);
   RunArgs a = a_in;
   a.full_tiles = tl.full_tiles; a.tail_tiles = tl.tail_tiles; a.tail_samples = tl.tail_samples;
   {
     const char *e = getenv("GLDM_R1D_SKIP");
     a.skip = e ? atoi(e) : 0;
   }
-  const bool stamp = getenv("GLDM_R1D_STAMP") != nullptr;  // diagnostic: blocks, copies and prints
-  static long long *dbg = nullptr;
-  if (stamp && !dbg) (void)hipMalloc(&dbg, 64 * 8 * 4 * sizeof(long long));
-  a.dbg = stamp ? dbg : nullptr;
-  if (stamp) (void)hipMemset(dbg, 0, 64 * 8 * 4 * sizeof(long long));
-  if (L == 4) {
-    static bool attr4 = false;
-    if (!attr4) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&r1d_kernel<4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      attr4 = true;
-    }
-    hipLaunchKernelGGL(r1d_kernel<4>, dim3(tiles), dim3(kThreads), lds_bytes, s, a);
-  } else {
-    static bool attr16 = false;
-    if (!attr16) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&r1d_kernel<16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      attr16 = true;
-    }
-    hipLaunchKernelGGL(r1d_kernel<16>, dim3(tiles), dim3(kThreads), lds_bytes, s, a);
-  }
-  if (stamp) {
-    static long long host[64 * 8 * 4];
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
-    for (int cidx = 0; cidx < 64 && host[cidx * 32 + 3]; ++cidx) {
-      const long long meta = host[cidx * 32 + 3];
-      long long t0 = host[cidx * 32], lo = 1ll << 62, hi = 0, end = 0;
-      for (int w = 0; w < 8; ++w) {
-        t0 = host[(cidx * 8 + w) * 4] < t0 ? host[(cidx * 8 + w) * 4] : t0;
-        const long long d = host[(cidx * 8 + w) * 4 + 1];
-        if (d) { lo = d < lo ? d : lo; hi = d > hi ? d : hi; }
-        end = host[(cidx * 8 + w) * 4 + 2] > end ? host[(cidx * 8 + w) * 4 + 2] : end;
-      }
-      printf("gemm %2d cout=%3d cin=%3d taps=%d  first wave done %6lld  last wave done %6lld  end %6lld\n", cidx,
-             (int)(meta >> 32), (int)((meta >> 8) & 0xffffff), (int)(meta & 0xff), lo - t0, hi - t0, end - t0);
-    }
-  }
-  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+  return L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s);
 }
 
 }  // namespace
@@ -1039,8 +1151,8 @@ GLDM_API int gldm_r1d_cond_embed(const float *z_cond, const float *w, const floa
 
 GLDM_API long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples) {
   if (validate(desc) != GLDM_OK || n_samples <= 0) return -1;
-  const int S = kCols / desc->seq_len;
-  const Tiling tl = make_tiling(n_samples, desc->seq_len);
+  const int nc = engine_nc(), S = nc / desc->seq_len;
+  const Tiling tl = make_tiling(n_samples, desc->seq_len, nc);
   return (long long)(tl.full_tiles + tl.tail_tiles) * desc->ss_rows * S * (long long)sizeof(float);
 }
 
@@ -1102,7 +1214,7 @@ GLDM_API int gldm_sa_mlp_forward(const float *points, const float *centers, cons
     return GLDM_ERR_INVALID_ARG;
   if (c > 0 && !features) return GLDM_ERR_INVALID_ARG;
   if (n_layers < 1 || n_layers > 4) return GLDM_ERR_UNSUPPORTED;
-  if (u > kCols || (kCols % u) != 0) return GLDM_ERR_UNSUPPORTED;
+  if (u > 64 || (64 % u) != 0) return GLDM_ERR_UNSUPPORTED;
   SaArgs a{};
   a.points = points; a.centers = centers; a.feat = c > 0 ? features : nullptr; a.idx = idx; a.weights = weights;
   a.out = out; a.c = c; a.n = n; a.m = m; a.u = u; a.n_layers = n_layers;
@@ -1115,15 +1227,15 @@ GLDM_API int gldm_sa_mlp_forward(const float *points, const float *centers, cons
     a.cin_pad[l] = cin_pad[l]; a.cout[l] = cout[l]; a.w_off[l] = w_off[l]; a.b_off[l] = b_off[l];
   }
   if (cin_pad[0] < 3 + c) return GLDM_ERR_INVALID_ARG;
-  const size_t lds_bytes = (size_t)(kBufH + kMaxC * kCols) * sizeof(float);
+  const size_t lds_bytes = (size_t)(Geo<64>::kBufH + kMaxC * 64) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes);
     attr = true;
   }
-  const int cpt = kCols / u;
-  hipLaunchKernelGGL(sa_mlp_kernel, dim3((m + cpt - 1) / cpt, b), dim3(kThreads), lds_bytes,
+  const int cpt = 64 / u;
+  hipLaunchKernelGGL(sa_mlp_kernel, dim3((m + cpt - 1) / cpt, b), dim3(Geo<64>::kThreads), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }

@@ -1,5 +1,5 @@
-"""One fused denoise launch (n latents, s steps) for counter collection."""
-import os, sys, torch
+"""One fused denoise launch (n latents, s steps) for counter collection; prints the launch time."""
+import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graspldm_amd.pipeline import build_fpc_ldm
 from graspldm_amd.r1d_pack import SCHED_DDIM
@@ -10,6 +10,9 @@ ldm = build_fpc_ldm(device=dev); ldm.set_inference_timesteps(100)
 eng = ldm.diffusion_model.model.engine(dev)
 z = torch.randn(n // 16, 3, 64, device=dev); x = torch.randn(n, 1, 4, device=dev)
 cemb = eng.cond_embed(z); ts, coef = ldm.diffusion_model._schedule(dev)
-for _ in range(2):
-    eng.denoise(x, cemb, 16, timesteps=ts[:steps].contiguous(), sched_kind=SCHED_DDIM, coef=coef[:steps].contiguous())
-torch.cuda.synchronize()
+ts, coef = ts[:steps].contiguous(), coef[:steps].contiguous()
+for _ in range(3):
+    torch.cuda.synchronize(); t0 = time.time()
+    eng.denoise(x, cemb, 16, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
+    torch.cuda.synchronize(); dt = time.time() - t0
+print(f"n={n} steps={steps}: {dt * 1e3:.2f} ms  {n * steps * 7589120 / dt / 1e12:.1f} TFLOP/s")
