@@ -379,9 +379,23 @@ __device__ __forceinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, co
 // ----------------------------------------------------------- GroupNorm ----
 // In place on `buf` (or accumulated into `res` when given):
 //   y = silu( GN(buf) * gamma + beta  [ * scale_sum + shift_sum ] )  [ + res ]
-// lane = (sub, column): a wave reads kRP consecutive rows per pass, conflict free; a group's
-// rows belong to one wave (no exchange) or to `awpg` waves that swap two scalars through LDS.
-// All loads of a wave are issued up front (rows stay in registers through both passes).
+// lane = (sub, column): each half of a wave owns a run of consecutive rows (two conflict-free LDS
+// rows per read); a group's rows belong to one wave (no exchange) or to `awpg` waves that swap two
+// scalars through LDS.  All loads are issued up front (rows stay in registers through both passes).
+template <int N>
+__device__ __forceinline__ void load_row_params(const float *p, float (&out)[N]) {  // N consecutive floats
+  if constexpr (N % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4 *>(p + 4 * q);
+      out[4 * q] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = p[i];
+  }
+}
+
 template <int NC, int L, int ITERS>
 __device__ __forceinline__ void group_norm_rows(const Ctx &c, float *buf, float *res, int C, int cpg, int wpg, int awpg,
                                                 int rpw, int gamma_off, int beta_off, const float *ss, int S) {
@@ -389,30 +403,28 @@ __device__ __forceinline__ void group_norm_rows(const Ctx &c, float *buf, float 
   float *red1 = c.lds + GG::kMiscRed1, *red2 = c.lds + GG::kMiscRed2;
   const int n = c.lane & (NC - 1), sub = c.lane / NC, s = n / L;
   const int g = c.wave / wpg, subw = c.wave % wpg;
-  const bool active_w = subw < awpg;
-  const int row0 = g * cpg + (active_w ? subw : 0) * rpw;
+  // this lane's rows: ITERS consecutive ones (per-row parameters come in as 16-byte loads)
+  const bool ok = subw < awpg && sub * ITERS < rpw;
+  const int rbase = g * cpg + (subw < awpg ? subw : 0) * rpw + (sub * ITERS < rpw ? sub * ITERS : 0);
   lds_f *b3 = (lds_f *)buf;
-  float v[ITERS], sc[ITERS], sh[ITERS];
-  bool ok[ITERS];
+  float v[ITERS], sc[ITERS], sh[ITERS], ga[ITERS], be[ITERS];
 #pragma unroll
-  for (int i = 0; i < ITERS; ++i) {
-    const int rr = i * GG::kRP + sub;
-    ok[i] = active_w && rr < rpw;
-    const int row = row0 + (rr < rpw ? rr : 0);
-    v[i] = b3[swz<NC>(row, n)];
-    if (ss) {
-      sc[i] = ss[row * S + s];
-      sh[i] = ss[(C + row) * S + s];
-    }
+  for (int i = 0; i < ITERS; ++i) v[i] = b3[swz<NC>(rbase + i, n)];
+  load_row_params<ITERS>(c.w + gamma_off + rbase, ga);
+  load_row_params<ITERS>(c.w + beta_off + rbase, be);
+  if (ss) {
+    load_row_params<ITERS>(ss + s * 2 * C + rbase, sc);
+    load_row_params<ITERS>(ss + s * 2 * C + C + rbase, sh);
   }
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < ITERS; ++i) sum += ok[i] ? v[i] : 0.f;
+  for (int i = 0; i < ITERS; ++i) sum += v[i];
+  sum = ok ? sum : 0.f;
 #pragma unroll
   for (int off = 1; off < L; off <<= 1) sum += __shfl_xor(sum, off, 64);
   if (GG::kRP == 2) sum += __shfl_xor(sum, 32, 64);
   if (awpg > 1) {
-    red1[c.wave * 64 + c.lane] = active_w ? sum : 0.f;
+    red1[c.wave * 64 + c.lane] = sum;
     __syncthreads();
     sum = 0.f;
     for (int q = 0; q < awpg; ++q) sum += red1[(g * wpg + q) * 64 + c.lane];
@@ -423,28 +435,27 @@ __device__ __forceinline__ void group_norm_rows(const Ctx &c, float *buf, float 
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
     const float d = v[i] - mean;
-    sq += ok[i] ? d * d : 0.f;
+    sq += d * d;
   }
+  sq = ok ? sq : 0.f;
 #pragma unroll
   for (int off = 1; off < L; off <<= 1) sq += __shfl_xor(sq, off, 64);
   if (GG::kRP == 2) sq += __shfl_xor(sq, 32, 64);
   if (awpg > 1) {
-    red2[c.wave * 64 + c.lane] = active_w ? sq : 0.f;
+    red2[c.wave * 64 + c.lane] = sq;
     __syncthreads();
     sq = 0.f;
     for (int q = 0; q < awpg; ++q) sq += red2[(g * wpg + q) * 64 + c.lane];
   }
   const float rstd = 1.0f / sqrtf(sq / cnt + 1e-5f);
-  const float *gamma = c.w + gamma_off, *beta = c.w + beta_off;
   lds_f *r3 = (lds_f *)res;
+  if (ok) {
 #pragma unroll
-  for (int i = 0; i < ITERS; ++i) {
-    if (ok[i]) {
-      const int row = row0 + i * GG::kRP + sub;
-      float y = (v[i] - mean) * rstd * gamma[row] + beta[row];
+    for (int i = 0; i < ITERS; ++i) {
+      float y = (v[i] - mean) * rstd * ga[i] + be[i];
       if (ss) y = y * sc[i] + sh[i];
       y = silu(y);
-      const int a = swz<NC>(row, n);
+      const int a = swz<NC>(rbase + i, n);
       if (res) r3[a] = r3[a] + y;
       else b3[a] = y;
     }
@@ -678,41 +689,56 @@ struct RunArgs {
   int full_tiles, tail_tiles, tail_samples;
 };
 
-// scale/shift rows of one ResnetBlock: ss[row][s] = Wmlp[row,:] . G[s,:] + (R b + R on scale rows),
+// scale/shift rows of one ResnetBlock: ss[s][row] = Wmlp[row,:] . G[s,:] + (R b + R on scale rows),
 // rows 0..C-1 = sum_r (scale_r + 1), rows C..2C-1 = sum_r shift_r.  One 16x16 MFMA tile per 16
-// rows (N = the tile's samples), written to this workgroup's L2-resident scratch [2C][S].
+// rows (N = the tile's samples), written sample-major to this workgroup's L2-resident scratch
+// [S][2C] (a lane's four rows are one 16-byte store, and GroupNorm reads runs of rows).  Weight and
+// bias loads of a chunk of m-tiles are all issued before the first MFMA.
 template <int NC>
 __device__ __forceinline__ void scale_shift_table(const Ctx &c, int ss_w, int ss_b, int C, int E, float *ss, int S) {
   if (c.skip & 16) return;
   using GG = Geo<NC>;
+  constexpr int CH = 4;  // m-tiles in flight per wave
   const lds_f *G = (const lds_f *)(c.lds + GG::kMiscG);
   const int col = c.lane & 15, kq = c.lane >> 4;
   const int sidx = col < S ? col : S - 1;
   const int mtiles = (2 * C + 15) >> 4, kblocks = (E + 15) >> 4;
-  const f32x4 *wv = reinterpret_cast<const f32x4 *>(c.w + ss_w);
+  gf4p wv = (gf4p)(reinterpret_cast<const f32x4 *>(c.w + ss_w) + c.lane);
   const float *bias = c.w + ss_b;
-  for (int mt = c.wave; mt < mtiles; mt += GG::kWaves) {
-    f32x4 acc;
+  const int last_mt = mtiles - 1;
+  for (int m0 = c.wave; m0 < mtiles; m0 += CH * GG::kWaves) {
+    f32x4 acc[CH];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * mt + 4 * kq + r;
-      acc[r] = bias[row < 2 * C ? row : 2 * C - 1];
+    for (int u = 0; u < CH; ++u) {
+      const int mt = m0 + u * GG::kWaves < last_mt ? m0 + u * GG::kWaves : last_mt;  // clamped: loads stay unconditional
+      const int row = 16 * mt + 4 * kq;
+      if (row + 3 < 2 * C) acc[u] = *reinterpret_cast<const f32x4 *>(bias + row);
+      else acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int kb = 0; kb < kblocks; ++kb) {
-      const f32x4 a = wv[((size_t)mt * kblocks + kb) * 64 + c.lane];
+      f32x4 a[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int mt = m0 + u * GG::kWaves < last_mt ? m0 + u * GG::kWaves : last_mt;
+        a[u] = wv[((size_t)mt * kblocks + kb) * 64];
+      }
+      float b[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int e = 16 * kb + 4 * j + kq;
-        const float b = e < E ? G[sidx * E + e] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b, acc, 0, 0, 0);
+        const float t = G[sidx * E + (e < E ? e : 0)];
+        b[j] = e < E ? t : 0.f;
       }
-    }
-    if (col < S) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * mt + 4 * kq + r;
-        if (row < 2 * C) ss[row * S + col] = acc[r];
-      }
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < CH; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[j], acc[u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int mt = m0 + u * GG::kWaves;
+      const int row = 16 * mt + 4 * kq;
+      if (mt < mtiles && col < S && row + 3 < 2 * C) *reinterpret_cast<f32x4 *>(ss + (size_t)col * 2 * C + row) = acc[u];
     }
   }
 }
@@ -870,6 +896,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
 
   for (int step = 0; step < a.n_steps; ++step) {
     // ---- G[s][e] = sum_r silu(temb[t][e] + cemb[cond][r][e])
+    if (!(c.skip & 32))
     for (int i = c.tid; i < S * E; i += GG::kThreads) {
       const int s = i / E, e = i - s * E;
       const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
@@ -885,6 +912,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     }
     // ---- init conv (k = 7, one input channel); the barrier below also publishes G
     const int C0 = d.dims[0];
+    if (!(c.skip & 64))
     for (int i = c.tid; i < C0 * NC; i += GG::kThreads) {
       const int ch = i / NC, n = i - ch * NC;
       const int l = n & (L - 1), base = n - l;
@@ -902,7 +930,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     run_tape<NC, L>(c, tape, n_ops, d.groups, E, ss_tile);
 
     // ---- final 1x1 conv to one channel: eps[n] = b + sum_c w[c] X[c][n]
-    {
+    if (!(c.skip & 128)) {
       float *red1 = lds + GG::kMiscRed1;
       const int n = c.lane & (NC - 1), slot = c.wave * GG::kRP + c.lane / NC;
       float part = 0.f;

@@ -16,7 +16,7 @@ f(); torch.cuda.synchronize(); t = time.time(); f(); torch.cuda.synchronize()
 print("RESULT", (time.time() - t) * 1e3 / 20)
 ''' % ROOT
 for name, mask in [("all", 0), ("noGN", 1), ("noLN", 2), ("noAttnMath", 4), ("noGEMM", 8), ("noSS", 16), ("onlyGEMM", 1 | 2 | 4 | 16),
-                   ("nothing", 31)]:
+                   ("nothing", 31), ("nothing-G", 31 | 32), ("nothing-G-init", 31 | 32 | 64), ("tape only", 31 | 32 | 64 | 128)]:
     env = dict(os.environ, GLDM_R1D_SKIP=str(mask))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     val = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
