@@ -78,6 +78,31 @@ __device__ __forceinline__ int swz(int row, int col) { return row * NC + (col ^ 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 
+
+// Cross-lane reductions on the VALU: DPP operands for the lanes of a sample (quad / row mirrors: each
+// step adds the partial sum of the complementary lane group, so every lane ends with the total) and
+// v_permlane32_swap for the two halves of a wave.  A ds_bpermute shuffle costs an LDS round trip each.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int L>
+__device__ __forceinline__ float group_sum(float x) {  // sum over the L lanes (columns) of a sample
+  x += dpp_mov<0xB1>(x);                   // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E>(x);                   // quad_perm [2,3,0,1]
+  if constexpr (L >= 8) x += dpp_mov<0x141>(x);   // row_half_mirror
+  if constexpr (L >= 16) x += dpp_mov<0x140>(x);  // row_mirror
+  return x;
+}
+__device__ __forceinline__ float half_sum(float x) {  // lanes i and i ^ 32
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float half_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 struct Ctx {
   const float *w;   // packed weights
   float *lds;
@@ -420,9 +445,8 @@ __device__ __forceinline__ void group_norm_rows(const Ctx &c, float *buf, float 
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) sum += v[i];
   sum = ok ? sum : 0.f;
-#pragma unroll
-  for (int off = 1; off < L; off <<= 1) sum += __shfl_xor(sum, off, 64);
-  if (GG::kRP == 2) sum += __shfl_xor(sum, 32, 64);
+  sum = group_sum<L>(sum);
+  if (GG::kRP == 2) sum = half_sum(sum);
   if (awpg > 1) {
     red1[c.wave * 64 + c.lane] = sum;
     __syncthreads();
@@ -438,9 +462,8 @@ __device__ __forceinline__ void group_norm_rows(const Ctx &c, float *buf, float 
     sq += d * d;
   }
   sq = ok ? sq : 0.f;
-#pragma unroll
-  for (int off = 1; off < L; off <<= 1) sq += __shfl_xor(sq, off, 64);
-  if (GG::kRP == 2) sq += __shfl_xor(sq, 32, 64);
+  sq = group_sum<L>(sq);
+  if (GG::kRP == 2) sq = half_sum(sq);
   if (awpg > 1) {
     red2[c.wave * 64 + c.lane] = sq;
     __syncthreads();
@@ -506,7 +529,7 @@ __device__ __forceinline__ void layer_norm_rows(const Ctx &c, const float *src, 
     v[i] = row < C ? x : 0.f;
     sum += v[i];
   }
-  if (GG::kRP == 2) sum += __shfl_xor(sum, 32, 64);
+  if (GG::kRP == 2) sum = half_sum(sum);
   red1[c.wave * 64 + c.lane] = sum;
   __syncthreads();
   float tot = 0.f;
@@ -520,7 +543,7 @@ __device__ __forceinline__ void layer_norm_rows(const Ctx &c, const float *src, 
     const float d = row < C ? v[i] - mean : 0.f;
     sq += d * d;
   }
-  if (GG::kRP == 2) sq += __shfl_xor(sq, 32, 64);
+  if (GG::kRP == 2) sq = half_sum(sq);
   red2[c.wave * 64 + c.lane] = sq;
   __syncthreads();
   float vt = 0.f;
@@ -582,7 +605,7 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
     f32x4 kv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) kv[i] = *(const lds_f4 *)(q3 + swz<NC>(krow0 + e0 + i, sbase));
-    if (GG::kRP == 2) qmax = fmaxf(qmax, __shfl_xor(qmax, 32, 64));
+    if (GG::kRP == 2) qmax = half_max(qmax);
     red1[c.wave * 64 + c.lane] = qmax;
     __syncthreads();
 #pragma unroll
@@ -599,9 +622,9 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
       a0 += k0 * f; a1 += k1 * f; a2 += k2 * f; a3 += k3 * f;
     }
     if (GG::kRP == 2) {
-      qsum += __shfl_xor(qsum, 32, 64);
-      a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
-      a2 += __shfl_xor(a2, 32, 64); a3 += __shfl_xor(a3, 32, 64);
+      qsum = half_sum(qsum);
+      a0 = half_sum(a0); a1 = half_sum(a1);
+      a2 = half_sum(a2); a3 = half_sum(a3);
     }
     red2[c.wave * 64 + c.lane] = qsum;
     part_a[(c.wave * 4 + 0) * 64 + c.lane] = a0;
@@ -687,6 +710,8 @@ struct RunArgs {
   float *ws;              // [tiles][ss_rows][S]
   int skip;               // diagnostic phase-skip mask (GLDM_R1D_SKIP env; 0 in production)
   int full_tiles, tail_tiles, tail_samples;
+  int stagger_ticks, n_cus;  // start offset (100 MHz ticks) of the second workgroup of a CU
+  long long *stamps;         // diagnostic (GLDM_R1D_STAMP): cycle counter at every op of the last step, block 0
 };
 
 // scale/shift rows of one ResnetBlock: ss[s][row] = Wmlp[row,:] . G[s,:] + (R b + R on scale rows),
@@ -791,9 +816,11 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
 }
 
 template <int NC, int L>
-__device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_ops, int groups, int E, float *ss_tile) {
+__device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_ops, int groups, int E, float *ss_tile,
+                                         long long *stamps) {
   constexpr int S = NC / L;
   for (int op = 0; op < n_ops; ++op) {
+    if (stamps && c0.tid == 0) stamps[op] = (long long)__builtin_readcyclecounter();
     // the lane ids are laundered per op: otherwise every variant's lane-derived LDS offsets are
     // hoisted out of the step loop as invariants and live (spilled) across the whole kernel
     Ctx c = c0;
@@ -878,6 +905,10 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   if (c.tid == 0) tape[8 * (kMaxOps - 1)] = build_tape<NC>(d, tape);
   __syncthreads();
   const int n_ops = __builtin_amdgcn_readfirstlane(tape[8 * (kMaxOps - 1)]);
+  if (a.stagger_ticks > 0 && ((blockIdx.x / a.n_cus) & 1)) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < a.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+  }
   // ---- latent row for this tile
   if (c.tid < NC) {
     const int s = c.tid / L, l = c.tid % L;
@@ -927,7 +958,8 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     }
     __syncthreads();
 
-    run_tape<NC, L>(c, tape, n_ops, d.groups, E, ss_tile);
+    run_tape<NC, L>(c, tape, n_ops, d.groups, E, ss_tile, blockIdx.x == 0 ? a.stamps : nullptr);
+    if (a.stamps && blockIdx.x == 0 && c.tid == 0) a.stamps[n_ops] = (long long)__builtin_readcyclecounter();
 
     // ---- final 1x1 conv to one channel: eps[n] = b + sum_c w[c] X[c][n]
     if (!(c.skip & 128)) {
@@ -935,7 +967,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       const int n = c.lane & (NC - 1), slot = c.wave * GG::kRP + c.lane / NC;
       float part = 0.f;
       for (int row = slot; row < CF; row += 8) part += a.weights[d.final_w + row] * X[swz<NC>(row, n)];
-      if (GG::kRP == 2) part += __shfl_xor(part, 32, 64);
+      if (GG::kRP == 2) part = half_sum(part);
       red1[c.wave * 64 + c.lane] = part;
       __syncthreads();
       if (c.tid < NC) {
@@ -1162,8 +1194,39 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   {
     const char *e = getenv("GLDM_R1D_SKIP");
     a.skip = e ? atoi(e) : 0;
+    const char *g = getenv("GLDM_R1D_STAGGER_US");
+    a.stagger_ticks = g ? atoi(g) * 100 : 0;
+    a.n_cus = cu_count();
   }
-  return L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s);
+  const bool stamp = getenv("GLDM_R1D_STAMP") != nullptr;  // diagnostic: blocks, copies and prints
+  static long long *dstamps = nullptr;
+  if (stamp && !dstamps) (void)hipMalloc(&dstamps, (kMaxOps + 1) * sizeof(long long));
+  a.stamps = stamp ? dstamps : nullptr;
+  const int rc = L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s);
+  if (stamp) {
+    static long long host[kMaxOps + 1];
+    static const char *names[] = {"SS", "CONV", "GN", "LN", "ATT"};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host, dstamps, sizeof(host), hipMemcpyDeviceToHost);
+    // the tape is rebuilt on the host only to label the stamps
+    int dims[GLDM_R1D_MAX_LEVELS + 1];
+    for (int i = 0; i <= a.d.n_levels; ++i) dims[i] = a.d.dims[i];
+    int op = 0;
+    auto line = [&](int type, int C, int cout, int taps) {
+      printf("op %3d %-4s C=%3d cout=%3d k=%d : %7lld clk\n", op, names[type], C, cout, taps, host[op + 1] - host[op]);
+      ++op;
+    };
+    auto resblock = [&](int C) { line(0, C, 2 * C, 0); line(1, C, C, 3); line(2, C, C, 0); line(1, C, C, 3); line(2, C, C, 0); };
+    for (int lv = 0; lv < a.d.n_levels; ++lv) {
+      const int C = dims[lv];
+      resblock(C); resblock(C);
+      line(3, C, C, 0); line(1, C, 192, 1); line(4, C, 64, 0); line(1, C, 192, 1); line(4, C, 64, 0);
+      line(1, 128, C, 1); line(3, C, C, 0); line(1, C, dims[lv + 1], 3);
+    }
+    resblock(dims[a.d.n_levels]);
+    printf("step total (ops): %lld clk\n", host[op] - host[0]);
+  }
+  return rc;
 }
 
 }  // namespace

@@ -29,6 +29,9 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void gemm_probe(const float *
     asm volatile("" : "+v"(cc.tid), "+v"(cc.lane));  // as run_tape does: no hoisting of lane-derived offsets
     int ci = cin, co = cout, tp = taps;
     asm volatile("" : "+s"(ci), "+s"(co), "+s"(tp));  // per-op values in the real kernel (read from the tape)
+#ifdef GLDM_PROBE_COLD
+    cc.w = w + (size_t)(i % 48) * (1 << 19);  // 48 x 2 MiB apart: every call streams weights that left L2 (96 MiB cycle)
+#endif
     conv_gemm<NC, L>(cc, 0, 1 << 18, lds + GG::kBufX, ci, tp, lds + GG::kBufH, co, false);
   }
   const long long t1 = __builtin_readcyclecounter();
@@ -66,8 +69,8 @@ void run(const float *w, long long *dcyc, int wgs, int cin, int cout, int taps) 
 
 int main() {
   float *w; long long *dcyc;
-  (void)hipMalloc(&w, (1 << 20) * 4 + 4096);
-  (void)hipMemset(w, 0, (1 << 20) * 4 + 4096);
+  (void)hipMalloc(&w, (size_t)50 * (1 << 21));
+  (void)hipMemset(w, 0, (size_t)50 * (1 << 21));
   (void)hipMalloc(&dcyc, 1024 * sizeof(long long));
 #ifdef GLDM_PROBE_SHORT
   const int shapes[][3] = {{256, 256, 3}, {128, 128, 3}, {128, 192, 1}, {64, 64, 3}};
