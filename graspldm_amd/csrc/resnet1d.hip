@@ -66,8 +66,8 @@ struct Geo {
   static constexpr int kMiscG = kMiscEps + NC;    // [S][E] <= 320
   static constexpr int kMiscRed1 = kMiscG + 320;  // [kWaves][64]
   static constexpr int kMiscRed2 = kMiscRed1 + kWaves * 64;
-  static constexpr int kMiscTape = kMiscRed2 + kWaves * 64;  // [kMaxOps][8] ints: the step program
-  static constexpr int kLdsFloats = kMiscTape + 8 * 128;
+  static constexpr int kMiscTape = kMiscRed2 + kWaves * 64;  // [kMaxOps][12] ints: the step program (+ its length)
+  static constexpr int kLdsFloats = kMiscTape + 1024;
 };
 static_assert(Geo<64>::kLdsFloats * 4 <= 160 * 1024, "LDS budget (1 WG/CU)");
 static_assert(Geo<32>::kLdsFloats * 4 * 2 <= 160 * 1024, "LDS budget (2 WG/CU)");
@@ -96,6 +96,10 @@ __device__ __forceinline__ float group_sum(float x) {  // sum over the L lanes (
 }
 __device__ __forceinline__ float half_sum(float x) {  // lanes i and i ^ 32
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float row_pair_sum(float x) {  // lanes i and i ^ 16
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float half_max(float x) {
@@ -312,6 +316,20 @@ __device__ __forceinline__ void store_tiles(const Ctx &c, const f32x4 (&acc)[MT]
   }
 }
 
+// GroupNorm fused into the conv epilogue (Block: proj -> GroupNorm -> [scale/shift] -> SiLU,
+// resnets.py:104-122; ResnetBlock residual add, :125-151).  With 4 groups and 4 waves the output
+// rows of a group are exactly the rows one wave accumulates (or, for narrow levels, part of its one
+// m-tile), so the statistics are reductions over that wave's accumulator registers: in-lane over the
+// tiles, DPP over the columns of the sample, permlane swaps over the row quarters.  No LDS round trip
+// and no barrier of its own.
+struct GnEpilogue {
+  int mode;            // 0: plain conv, 1: dst = act(GN(conv)), 2: res += act(GN(conv))
+  int gamma_off, beta_off;
+  const float *ss;     // scale/shift table [S][2C] of this tile (mode 1 with time/cond embedding) or null
+  int C, cpg;          // channels, channels per group
+  float *res;          // residual stream (mode 2)
+};
+
 // One wave's share of a GEMM: PASSES x MT m-tiles by NT n-tiles, one k-sweep per pass.  Passes keep
 // the register footprint of a sweep small (MT * TAPS <= 6 fragments per block) so that every variant
 // fits beside the other phases of the kernel without spilling; the extra cost of a pass is one
@@ -319,9 +337,9 @@ __device__ __forceinline__ void store_tiles(const Ctx &c, const f32x4 (&acc)[MT]
 template <int NC, int L, int TAPS, int MT, int NT, int PASSES>
 __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int mt0, int nt0, bool active,
                                             const float *src, int cin, float *dst, int cout, const float *bias,
-                                            bool alias, int act) {
+                                            bool alias, int act, const GnEpilogue &g) {
   f32x4 acc[PASSES][MT][NT];
-  const int kq = c.lane >> 4;
+  const int kq = c.lane >> 4, col = c.lane & 15;
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
 #pragma unroll
@@ -342,6 +360,85 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
       else gemm_small<NC, L, MT, NT>(c, wp, (TAPS * cin + 15) >> 4, mt0 + p * MT, nt0, src, cin, TAPS, acc[p]);
     }
   }
+  if constexpr (TAPS == 3 && NC == 32) {
+    if (g.mode) {
+      if (g.ss) __syncthreads();  // the scale/shift rows were written by other waves (OP_SS)
+      if (active) {
+        const float inv_cnt = 1.0f / (float)(g.cpg * L);  // a power of two: exact
+        lds_f *d3 = (lds_f *)(g.mode == 2 ? g.res : dst);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          const int n = 16 * (nt0 + ni) + col;
+          const float *ssp = g.ss ? g.ss + (n / L) * 2 * g.C : nullptr;
+          float mean[4], rstd[4];  // per row quarter r (cpg == 1) or one value replicated
+          if (PASSES * MT == 1 && g.cpg == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float x = acc[0][0][ni][r];
+              mean[r] = group_sum<L>(x) * inv_cnt;
+              const float dx = x - mean[r];
+              rstd[r] = __builtin_amdgcn_rsqf(group_sum<L>(dx * dx) * inv_cnt + 1e-5f);
+            }
+          } else {
+            const bool whole = !(PASSES * MT == 1 && g.cpg == 8);  // else: the group is two row quarters
+            float s1 = 0.f;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+              for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s1 += acc[p][mi][ni][r];
+            s1 = row_pair_sum(group_sum<L>(s1));
+            if (whole) s1 = half_sum(s1);
+            const float m = s1 * inv_cnt;
+            float s2 = 0.f;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+              for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const float dx = acc[p][mi][ni][r] - m;
+                  s2 += dx * dx;
+                }
+            s2 = row_pair_sum(group_sum<L>(s2));
+            if (whole) s2 = half_sum(s2);
+            const float rs = __builtin_amdgcn_rsqf(s2 * inv_cnt + 1e-5f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              mean[r] = m;
+              rstd[r] = rs;
+            }
+          }
+#pragma unroll
+          for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+              const int row0 = 16 * (mt0 + p * MT + mi) + 4 * kq;
+              const int prow = row0 + 3 < cout ? row0 : 0;  // rows past cout (narrow levels) are not stored
+              const f32x4 ga = *reinterpret_cast<const f32x4 *>(c.w + g.gamma_off + prow);
+              const f32x4 be = *reinterpret_cast<const f32x4 *>(c.w + g.beta_off + prow);
+              f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (ssp) {
+                sc = *reinterpret_cast<const f32x4 *>(ssp + prow);
+                sh = *reinterpret_cast<const f32x4 *>(ssp + g.C + prow);
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float y = (acc[p][mi][ni][r] - mean[r]) * rstd[r] * ga[r] + be[r];
+                if (ssp) y = y * sc[r] + sh[r];
+                y = silu(y);
+                if (row0 + r < cout) {
+                  const int a = swz<NC>(row0 + r, n);
+                  d3[a] = g.mode == 2 ? d3[a] + y : y;
+                }
+              }
+            }
+        }
+      }
+      return;
+    }
+  }
   if (alias) __syncthreads();
   if (active) {
 #pragma unroll
@@ -354,15 +451,16 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
 // Output widths are 16 x {1, 2, 4, 8, 12, 16} rows (validate() enforces it).
 template <int NC, int L>
 __device__ __forceinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, const float *src, int cin, int ktaps,
-                                          float *dst, int cout, bool alias, int act = 0) {
+                                          float *dst, int cout, bool alias, int act = 0,
+                                          const GnEpilogue &g = GnEpilogue{0, 0, 0, nullptr, 0, 0, nullptr}) {
   if (c.skip & 8) return;
   const float *wp = c.w + w_off;
   const float *bias = b_off >= 0 ? c.w + b_off : nullptr;
   const int mtiles = (cout + 15) >> 4;
   const int w = c.wave;
   // G3: k = 3 taps (<= 2 m-tiles per sweep), G1: 1x1
-#define GLDM_G3(MT, NT, P, mt0, nt0, on) gemm_passes<NC, L, 3, MT, NT, P>(c, wp, mt0, nt0, on, src, cin, dst, cout, bias, alias, act)
-#define GLDM_G1(MT, NT, P, mt0, nt0, on) gemm_passes<NC, L, 1, MT, NT, P>(c, wp, mt0, nt0, on, src, cin, dst, cout, bias, alias, act)
+#define GLDM_G3(MT, NT, P, mt0, nt0, on) gemm_passes<NC, L, 3, MT, NT, P>(c, wp, mt0, nt0, on, src, cin, dst, cout, bias, alias, act, g)
+#define GLDM_G1(MT, NT, P, mt0, nt0, on) gemm_passes<NC, L, 1, MT, NT, P>(c, wp, mt0, nt0, on, src, cin, dst, cout, bias, alias, act, g)
   if constexpr (NC == 64) {
     // 8 waves x 4 n-tiles: the fused set abstraction (1x1 layers only)
     if (mtiles == 16) GLDM_G1(2, 4, 1, 2 * w, 0, true);
@@ -470,7 +568,7 @@ __device__ __forceinline__ void group_norm_rows(const Ctx &c, float *buf, float 
     sq = 0.f;
     for (int q = 0; q < awpg; ++q) sq += red2[(g * wpg + q) * 64 + c.lane];
   }
-  const float rstd = 1.0f / sqrtf(sq / cnt + 1e-5f);
+  const float rstd = __builtin_amdgcn_rsqf(sq / cnt + 1e-5f);
   lds_f *r3 = (lds_f *)res;
   if (ok) {
 #pragma unroll
@@ -549,7 +647,7 @@ __device__ __forceinline__ void layer_norm_rows(const Ctx &c, const float *src, 
   float vt = 0.f;
 #pragma unroll
   for (int q = 0; q < GG::kWaves; ++q) vt += red2[q * 64 + c.lane];
-  const float rstd = 1.0f / sqrtf(vt / (float)C + 1e-5f);
+  const float rstd = __builtin_amdgcn_rsqf(vt / (float)C + 1e-5f);
   const float *g = c.w + g_off;
   lds_f *d3 = (lds_f *)dst, *r3 = (lds_f *)res;
 #pragma unroll
@@ -768,28 +866,43 @@ __device__ __forceinline__ void scale_shift_table(const Ctx &c, int ss_w, int ss
   }
 }
 
-// One denoiser / decoder step is a fixed program of ~80 barrier-separated ops.  It is written once
-// per workgroup into LDS (8 ints per op) and interpreted by a switch inside the step loop, so every
+// One denoiser / decoder step is a fixed program of ~60 barrier-separated ops.  It is written once
+// per workgroup into LDS (12 ints per op) and interpreted by a switch inside the step loop, so every
 // phase body exists once, inlined, with registers allocated across the whole kernel: no calls, no
 // callee-save traffic and no spilled kernel state between phases.
 enum { OP_SS = 0, OP_CONV = 1, OP_GN = 2, OP_LN = 3, OP_ATT = 4 };
-constexpr int kMaxOps = 128;
+constexpr int kOpInts = 12, kMaxOps = 84;  // 84 * 12 = 1008 ints; the op count lives in int 1023
+
+// GroupNorm rides in the conv epilogue when a group's rows are one wave's rows (see GnEpilogue)
+__device__ __forceinline__ bool gn_fusable(int NC, int C, int groups) {
+  if (NC != 32 || groups != 4 || C % 4) return false;
+  const int cpg = C / 4;
+  return (cpg == 1 && C <= 16) || (cpg == 8 && C == 32) || (cpg % 16 == 0 && cpg <= 64);
+}
 
 template <int NC>
-__device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
+__device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape, int skip) {
   using GG = Geo<NC>;
   int n = 0;
-  auto emit = [&](int type, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0, int a6 = 0, int a7 = 0) {
-    int *o = tape + 8 * n++;
+  auto emit = [&](int type, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0, int a6 = 0, int a7 = 0,
+                  int a8 = 0, int a9 = 0, int a10 = 0) {
+    int *o = tape + kOpInts * n++;
     o[0] = type; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; o[6] = a6; o[7] = a7;
+    o[8] = a8; o[9] = a9; o[10] = a10; o[11] = 0;
   };
   constexpr int X = GG::kBufX, H = GG::kBufH, Y = GG::kBufY, O = GG::kBufO, QKV = GG::kBufQKV;
+  // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9 | uses the scale/shift table << 11
   auto resblock = [&](const gldm_r1d_resblock &rb, int C) {
-    emit(OP_SS, rb.ss_w, rb.ss_b, C);                      // published by the barrier that ends the conv
-    emit(OP_CONV, rb.c1_w, rb.c1_b, X, H, C, C, 3);
-    emit(OP_GN, H, -1, C, rb.n1_w, rb.n1_b, 1);
-    emit(OP_CONV, rb.c2_w, rb.c2_b, H, H, C, C, 3 | 256);  // in place: alias
-    emit(OP_GN, H, X, C, rb.n2_w, rb.n2_b, 0);
+    emit(OP_SS, rb.ss_w, rb.ss_b, C);  // published by the barrier inside / at the end of the first conv
+    if (gn_fusable(NC, C, d.groups) && !(skip & 1)) {
+      emit(OP_CONV, rb.c1_w, rb.c1_b, X, H, C, C, 3 | (1 << 9) | (1 << 11), rb.n1_w, rb.n1_b);
+      emit(OP_CONV, rb.c2_w, rb.c2_b, H, X, C, C, 3 | (2 << 9), rb.n2_w, rb.n2_b);  // X += act(GN(conv(H)))
+    } else {
+      emit(OP_CONV, rb.c1_w, rb.c1_b, X, H, C, C, 3);
+      emit(OP_GN, H, -1, C, rb.n1_w, rb.n1_b, 1);
+      emit(OP_CONV, rb.c2_w, rb.c2_b, H, H, C, C, 3 | 256);  // in place: alias
+      emit(OP_GN, H, X, C, rb.n2_w, rb.n2_b, 0);
+    }
   };
   // constant indices only: a dynamically indexed kernel argument is copied to scratch memory
 #pragma unroll
@@ -825,20 +938,30 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
     // hoisted out of the step loop as invariants and live (spilled) across the whole kernel
     Ctx c = c0;
     asm volatile("" : "+v"(c.tid), "+v"(c.lane));
-    int o[8];
+    int o[kOpInts];
     {
-      const int4 lo = *reinterpret_cast<const int4 *>(tape + 8 * op), hi = *reinterpret_cast<const int4 *>(tape + 8 * op + 4);
-      o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+      const int4 *t4 = reinterpret_cast<const int4 *>(tape + kOpInts * op);
+      const int4 q0 = t4[0], q1 = t4[1], q2 = t4[2];
+      o[0] = q0.x; o[1] = q0.y; o[2] = q0.z; o[3] = q0.w; o[4] = q1.x; o[5] = q1.y; o[6] = q1.z; o[7] = q1.w;
+      o[8] = q2.x; o[9] = q2.y; o[10] = q2.z; o[11] = q2.w;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = __builtin_amdgcn_readfirstlane(o[i]);
+      for (int i = 0; i < kOpInts; ++i) o[i] = __builtin_amdgcn_readfirstlane(o[i]);
     }
+    // the short latency-bound phases get issue priority over the co-resident workgroup's long MFMA
+    // streams (which need one issue slot per 32 cycles and lose nothing)
+    if (o[0] == OP_CONV && o[5] * o[6] >= 128 * 128) __builtin_amdgcn_s_setprio(0);
+    else __builtin_amdgcn_s_setprio(3);
     switch (o[0]) {
       case OP_SS:
         scale_shift_table<NC>(c, o[1], o[2], o[3], E, ss_tile, S);
         break;
-      case OP_CONV:
-        conv_gemm<NC, L>(c, o[1], o[2], c.lds + o[3], o[5], o[7] & 255, c.lds + o[4], o[6], (o[7] & 256) != 0);
+      case OP_CONV: {
+        const int mode = (o[7] >> 9) & 3;
+        const GnEpilogue g{mode, o[8], o[9], ((o[7] >> 11) & 1) && !(c.skip & 16) ? ss_tile : nullptr, o[6], o[6] / 4,
+                           c.lds + o[4]};
+        conv_gemm<NC, L>(c, o[1], o[2], c.lds + o[3], o[5], o[7] & 255, c.lds + o[4], o[6], (o[7] & 256) != 0, 0, g);
         break;
+      }
       case OP_GN:
         group_norm_pass<NC, L>(c, c.lds + o[1], o[2] >= 0 ? c.lds + o[2] : nullptr, o[3], groups, o[4], o[5],
                                (o[6] && !(c.skip & 16)) ? ss_tile : nullptr, S);
@@ -902,9 +1025,9 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   for (int i = c.tid; i < GG::kLdsFloats; i += GG::kThreads) lds[i] = 0.f;  // dead columns must stay finite
   __syncthreads();
   int *tape = reinterpret_cast<int *>(lds + GG::kMiscTape);
-  if (c.tid == 0) tape[8 * (kMaxOps - 1)] = build_tape<NC>(d, tape);
+  if (c.tid == 0) tape[1023] = build_tape<NC>(d, tape, a.skip);
   __syncthreads();
-  const int n_ops = __builtin_amdgcn_readfirstlane(tape[8 * (kMaxOps - 1)]);
+  const int n_ops = __builtin_amdgcn_readfirstlane(tape[1023]);
   if (a.stagger_ticks > 0 && ((blockIdx.x / a.n_cus) & 1)) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < a.stagger_ticks) __builtin_amdgcn_s_sleep(32);
@@ -1128,7 +1251,7 @@ int engine_nc() { return kEngineNC; }
 int validate(const gldm_r1d_desc *d) {
   if (!d) return GLDM_ERR_INVALID_ARG;
   if (d->seq_len != 4 && d->seq_len != 16) return GLDM_ERR_UNSUPPORTED;
-  if (d->n_levels < 1 || d->n_levels > GLDM_R1D_MAX_LEVELS) return GLDM_ERR_UNSUPPORTED;
+  if (d->n_levels < 1 || d->n_levels > GLDM_R1D_MAX_LEVELS || 18 * d->n_levels + 5 > kMaxOps) return GLDM_ERR_UNSUPPORTED;
   const int nc = engine_nc(), waves = nc / 8;
   const int S = nc / d->seq_len;
   if (d->emb_dim <= 0 || S * d->emb_dim > 320) return GLDM_ERR_UNSUPPORTED;
@@ -1216,7 +1339,14 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
       printf("op %3d %-4s C=%3d cout=%3d k=%d : %7lld clk\n", op, names[type], C, cout, taps, host[op + 1] - host[op]);
       ++op;
     };
-    auto resblock = [&](int C) { line(0, C, 2 * C, 0); line(1, C, C, 3); line(2, C, C, 0); line(1, C, C, 3); line(2, C, C, 0); };
+    auto resblock = [&](int C) {
+      line(0, C, 2 * C, 0);
+      const int cpg = C / 4;
+      const bool fused = a.d.groups == 4 && C % 4 == 0 && !(a.skip & 1) &&
+                         ((cpg == 1 && C <= 16) || (cpg == 8 && C == 32) || (cpg % 16 == 0 && cpg <= 64));
+      if (fused) { line(1, C, C, 3); line(1, C, C, 3); }
+      else { line(1, C, C, 3); line(2, C, C, 0); line(1, C, C, 3); line(2, C, C, 0); }
+    };
     for (int lv = 0; lv < a.d.n_levels; ++lv) {
       const int C = dims[lv];
       resblock(C); resblock(C);
