@@ -132,9 +132,17 @@ def main():
         dn()
         t_den = event_time(dn, 3)
         flop = B * G * S * DENOISER_FLOP_PER_LATENT_STEP
-        roof = dict(kernel="r1d_kernel<4> (gldm_denoise: %d DDIM steps fused)" % S, bound="mfma",
+        # memory-side bytes of one launch from the committed PMC passes (tools/pmc_denoise.sh: FETCH_SIZE, doubled
+        # per the gfx950 16-B/lane rule, + WRITE_SIZE); only quoted for the workload they were collected on
+        traffic = None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01c_denoise_pmc.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("n_latents") == B * G and pmc.get("steps") == S:
+                traffic = pmc["fetch_bytes_corrected"] + pmc["write_bytes"]
+        roof = dict(kernel="r1d_kernel<32, 4> (gldm_denoise: %d DDIM steps fused)" % S, bound="mfma",
                     achieved=flop / t_den / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=flop / t_den / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                    frac=flop / t_den / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
                     algorithmic_flop_per_launch=flop, avg_launch_ms=t_den * 1e3)
         # ---- stage split and the set-abstraction gather (north-star HBM kernel), same run
         t_enc = event_time(lambda: ldm.vae_model.encode_pc(pcs), 3)
@@ -144,7 +152,7 @@ def main():
         kernels = [dict(kernel="PVCNNEncoder.forward (all launches)", bound="mfma", avg_ms=t_enc * 1e3,
                         achieved=B * ENCODER_FLOP_PER_CLOUD / t_enc / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=B * ENCODER_FLOP_PER_CLOUD / t_enc / 1e12 / PEAK_F32_MFMA_TFLOPS),
-                   dict(kernel="r1d_kernel<16> (gldm_decode)", bound="mfma", avg_ms=t_dec * 1e3,
+                   dict(kernel="r1d_kernel<32, 16> (gldm_decode)", bound="mfma", avg_ms=t_dec * 1e3,
                         achieved=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12 / PEAK_F32_MFMA_TFLOPS)]
         from graspldm_amd import _lib as L

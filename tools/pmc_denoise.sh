@@ -6,7 +6,7 @@ tag=${1:-x}
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out
-run() { name=$1; shift; timeout 200 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $out/$name -o run -- /usr/bin/python3 $GRAFT_REPO_ROOT/tools/run_denoise_once.py 4096 100 > $out/$name.log 2>&1; }
+run() { name=$1; shift; timeout 200 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $out/$name -o run -- /usr/bin/python3 $GRAFT_REPO_ROOT/tools/run_denoise_once.py ${NLAT:-5120} 100 > $out/$name.log 2>&1; }
 run busy GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run icache SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH
 run l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum

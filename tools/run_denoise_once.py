@@ -5,14 +5,15 @@ from graspldm_amd.pipeline import build_fpc_ldm
 from graspldm_amd.r1d_pack import SCHED_DDIM
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+G = int(sys.argv[3]) if len(sys.argv) > 3 else (20 if n % 20 == 0 else 16)  # latents per cloud
 dev = torch.device("cuda:0")
 ldm = build_fpc_ldm(device=dev); ldm.set_inference_timesteps(100)
 eng = ldm.diffusion_model.model.engine(dev)
-z = torch.randn(n // 16, 3, 64, device=dev); x = torch.randn(n, 1, 4, device=dev)
+z = torch.randn(n // G, 3, 64, device=dev); x = torch.randn(n, 1, 4, device=dev)
 cemb = eng.cond_embed(z); ts, coef = ldm.diffusion_model._schedule(dev)
 ts, coef = ts[:steps].contiguous(), coef[:steps].contiguous()
 for _ in range(3):
     torch.cuda.synchronize(); t0 = time.time()
-    eng.denoise(x, cemb, 16, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
+    eng.denoise(x, cemb, G, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
     torch.cuda.synchronize(); dt = time.time() - t0
 print(f"n={n} steps={steps}: {dt * 1e3:.2f} ms  {n * steps * 7589120 / dt / 1e12:.1f} TFLOP/s")
