@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--ddim-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the steps alternate over (2: batch k+1's encoder overlaps batch k's denoise tail)")
     return ap.parse_args()
 
 
@@ -87,7 +89,19 @@ def main():
     gstd = metas_u["grasp_std"].repeat(reps, 1)[:B].contiguous().to(dev)
     x_T = torch.randn(B * G, 1, 4, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
 
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+    counter = [0]
+
     def step():
+        if streams is None:
+            return one_batch()
+        st = streams[counter[0] % len(streams)]
+        counter[0] += 1
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            return one_batch()
+
+    def one_batch():
         (tm, lg), _ = ldm.generate_grasps(pcs, num_grasps=G, x_T=x_T)
         rows = torch.cat([tm, lg], dim=1)
         if world > 1:

@@ -18,7 +18,7 @@ class R1dEngine:
         self.cond_w = packed["cond_w"].to(self.device)
         self.cond_b = packed["cond_b"].to(self.device)
         self.seq_len = int(self.desc.seq_len)
-        self._ws = None
+        self._ws = {}   # scratch per HIP stream: launches on different streams may run concurrently
 
     # -- helpers
     def _desc_ptr(self):
@@ -28,9 +28,11 @@ class R1dEngine:
         need = L.lib().gldm_r1d_workspace_bytes(self._desc_ptr(), int(n))
         if need < 0:
             raise L.GldmError("gldm_r1d_workspace_bytes: this ResNet1D configuration is not supported by the HIP engine")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return ws
 
     def cond_embed(self, z_cond):
         """input_emb_layers (Linear + SiLU) on [n, R, Dc] (or [n, Dc]) -> [n, R, E]."""
