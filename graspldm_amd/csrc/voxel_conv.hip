@@ -289,6 +289,22 @@ int launch_conv(const float *x, const float *wp, const float *bias, int b, int c
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 
+// y[b, c, :] = act(y[b, c, :] + bias[c]) in place: the epilogue of the k = 1 convs that run as plain
+// library GEMMs (one pass instead of a bias pass and an activation pass).
+__global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ y, const float *__restrict__ bias, int c,
+                                                       long long n, int relu) {
+  const long long row = blockIdx.y;  // b * c + channel
+  const float bv = bias[row % c];
+  float *p = y + row * n;
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<float4 *>(p)[i];
+    v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    reinterpret_cast<float4 *>(p)[i] = v;
+  }
+}
+
 }  // namespace
 
 GLDM_API long long gldm_conv3d_partial_floats(int b, int cout, int r) {
@@ -338,5 +354,15 @@ GLDM_API int gldm_devoxelize_fused(const float *coords, const float *features, c
   if (!coords || !features || !out || b <= 0 || c <= 0 || n <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(devoxelize_fused_kernel, dim3((n + 255) / 256, (c + 15) / 16, b), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), coords, features, gate, add, c, n, r, out);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_bias_act(float *y, const float *bias, int b, int c, long long n, int relu, gldm_stream_t stream) {
+  if (!y || !bias || b <= 0 || c <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
+  if (n & 3) return GLDM_ERR_UNSUPPORTED;  // rows must stay 16-byte aligned
+  const long long n4 = n >> 2;
+  const int bx = (int)((n4 + 255) / 256 < 1 ? 1 : ((n4 + 255) / 256 > 64 ? 64 : (n4 + 255) / 256));
+  hipLaunchKernelGGL(bias_act_kernel, dim3(bx, b * c), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, bias, c, n,
+                     relu);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }

@@ -20,21 +20,51 @@ def swish(x):
     return x * torch.sigmoid(x)
 
 
+def _gemm_bias_act(x, w2d, bias, relu):
+    """act(W x + b) over [B, Cin, ...]: one library GEMM (the k = 1 convolution without bias: MIOpen hands it to
+    rocBLAS strided-batched) + ONE in-place epilogue pass (gldm_bias_act) instead of a bias pass and a ReLU pass."""
+    from . import _lib as L
+    shape = x.shape
+    x3 = x.reshape(shape[0], shape[1], -1)
+    y = F.conv1d(x3, w2d.unsqueeze(-1))
+    n = y.shape[-1]
+    if bias is not None or relu:
+        if n % 4 == 0 and y.is_contiguous():
+            b = bias if bias is not None else torch.zeros(w2d.shape[0], dtype=y.dtype, device=y.device)
+            L.call("gldm_bias_act", L.ptr(y), L.ptr(b.contiguous()), int(y.shape[0]), int(y.shape[1]), n, int(relu),
+                   L.current_stream(y.device))
+        else:
+            if bias is not None:
+                y = y + bias.view(1, -1, 1)
+            if relu:
+                y = torch.relu_(y)
+    return y.reshape(shape[0], w2d.shape[0], *shape[2:])
+
+
 def pointwise_conv(x, conv):
     """Conv1d/Conv2d with kernel 1 (+bias), no activation."""
     _need_cuda(x)
-    fn = F.conv1d if conv.weight.ndim == 3 else F.conv2d
-    return fn(x, conv.weight, conv.bias)
+    return _gemm_bias_act(x.float(), conv.weight.reshape(conv.weight.shape[0], -1), conv.bias, False)
+
+
+_FOLDED = {}
 
 
 def pointwise_conv_bn_relu(x, conv, bn):
-    """relu(BN_eval(conv(x))) with BN folded into the weights: y = relu(W' x + b')."""
+    """relu(BN_eval(conv(x))) with BN folded into the weights: y = relu(W' x + b').  The folded pair is
+    computed once per (weights, statistics) version, not per call."""
     _need_cuda(x)
-    s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-    w = conv.weight * s.view(-1, *([1] * (conv.weight.ndim - 1)))
-    b = (conv.bias - bn.running_mean) * s + bn.bias
-    fn = F.conv1d if conv.weight.ndim == 3 else F.conv2d
-    return torch.relu_(fn(x, w, b))
+    key = (conv.weight.data_ptr(), conv.weight._version, bn.weight._version, bn.bias._version,
+           bn.running_mean._version, bn.running_var._version, str(x.device))
+    hit = _FOLDED.get(id(conv))
+    if hit is None or hit[0] != key:
+        s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        w = (conv.weight.reshape(conv.weight.shape[0], -1) * s.view(-1, 1)).contiguous()
+        cb = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+        b = ((cb - bn.running_mean) * s + bn.bias).contiguous()
+        hit = (key, w, b)
+        _FOLDED[id(conv)] = hit
+    return _gemm_bias_act(x.float(), hit[1], hit[2], True)
 
 
 def conv3d_gn_swish(x, conv, gn):

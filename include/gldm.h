@@ -245,6 +245,12 @@ int gldm_devoxelize_fused(const float *coords /*[b,3,n]*/, const float *features
                           const float *gate /*[b,c]*/, const float *add /*[b,c,n]*/, int b, int c, int n, int r,
                           float *out /*[b,c,n]*/, gldm_stream_t stream);
 
+/* y[b, c, :] = act(y[b, c, :] + bias[c]) in place (relu != 0: ReLU).  Epilogue of the k = 1 Conv1d /
+ * Conv2d + BatchNorm(eval, folded) + ReLU of ext/pvcnn/modules/shared_mlp.py:24-36 when the GEMM itself
+ * runs as a plain library call.  n % 4 == 0 (rows stay 16-byte aligned). */
+int gldm_bias_act(float *y /*[b,c,n]*/, const float *bias /*[c]*/, int b, int c, long long n, int relu,
+                  gldm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
