@@ -373,8 +373,36 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
       const float inv_cnt = 1.0f / (float)(g.cpg * L);  // a power of two: exact
       lds_f *d3 = (lds_f *)(g.mode == 2 ? g.res : dst);
       const bool has_ss = g.ss_w >= 0;
+      const bool wide = g.C >= 16;  // else C = 4: one m-tile holds scale rows 0..3 (row quarter 0) and shift rows 4..7
       const int ekb = g.E >> 4;
       gf4p wss = (gf4p)(reinterpret_cast<const f32x4 *>(c.w + (has_ss ? g.ss_w : 0)) + c.lane);
+      // ---- every parameter load of the epilogue goes out first; the statistics below run in their shadow
+      f32x4 ga[PASSES][MT], be[PASSES][MT], sc0[PASSES][MT], sh0[PASSES][MT], a_sc[PASSES][MT], a_sh[PASSES][MT];
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const int mt = mt0 + p * MT + mi;
+          const int row0 = 16 * mt + 4 * kq;
+          const int prow = row0 + 3 < cout ? row0 : 0;  // rows past cout (narrow levels) are not stored
+          ga[p][mi] = *reinterpret_cast<const f32x4 *>(c.w + g.gamma_off + prow);
+          be[p][mi] = *reinterpret_cast<const f32x4 *>(c.w + g.beta_off + prow);
+          sc0[p][mi] = f32x4{1.f, 1.f, 1.f, 1.f};
+          sh0[p][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (has_ss) {
+            const float *sb = c.w + g.ss_b;
+            if (wide) {  // scale rows: m-tile mt, shift rows: m-tile C/16 + mt of the [2C x E] Linear
+              sc0[p][mi] = *reinterpret_cast<const f32x4 *>(sb + row0);
+              sh0[p][mi] = *reinterpret_cast<const f32x4 *>(sb + g.C + row0);
+              a_sc[p][mi] = wss[(size_t)mt * ekb * 64];
+              a_sh[p][mi] = wss[(size_t)((g.C >> 4) + mt) * ekb * 64];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sc0[p][mi][r] = sb[4 * kq + r < 2 * g.C ? 4 * kq + r : 0];
+              a_sc[p][mi] = wss[0];
+            }
+          }
+        }
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) {
         const int n = 16 * (nt0 + ni) + col;
@@ -450,40 +478,43 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
               }
             }
         }
-        // ---- normalise, scale/shift, SiLU, store / accumulate
+        // ---- scale/shift rows of this column's sample, normalise, SiLU, store / accumulate
+        float gb[4];
+        if (has_ss) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) gb[j] = Gs[4 * j + kq];
+        }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p)
 #pragma unroll
           for (int mi = 0; mi < MT; ++mi) {
             const int mt = mt0 + p * MT + mi;
             const int row0 = 16 * mt + 4 * kq;
-            const int prow = row0 + 3 < cout ? row0 : 0;  // rows past cout (narrow levels) are not stored
-            const f32x4 ga = *reinterpret_cast<const f32x4 *>(c.w + g.gamma_off + prow);
-            const f32x4 be = *reinterpret_cast<const f32x4 *>(c.w + g.beta_off + prow);
-            f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 sc = sc0[p][mi], sh = sh0[p][mi];
             if (has_ss) {
-              const float *sb = c.w + g.ss_b;
-              if (g.C >= 16) {  // scale rows: m-tile mt, shift rows: m-tile C/16 + mt of the [2C x E] Linear
-                const int mts = (g.C >> 4) + mt;
-                sc = *reinterpret_cast<const f32x4 *>(sb + row0);
-                sh = *reinterpret_cast<const f32x4 *>(sb + g.C + row0);
-                for (int kb = 0; kb < ekb; ++kb) {
-                  const f32x4 a_sc = wss[((size_t)mt * ekb + kb) * 64], a_sh = wss[((size_t)mts * ekb + kb) * 64];
+              if (wide) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  sc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_sc[p][mi][j], gb[j], sc, 0, 0, 0);
+                  sh = __builtin_amdgcn_mfma_f32_16x16x4f32(a_sh[p][mi][j], gb[j], sh, 0, 0, 0);
+                }
+                for (int kb = 1; kb < ekb; ++kb) {  // wide embeddings (the pose decoder: E = 64)
+                  const f32x4 a2 = wss[((size_t)mt * ekb + kb) * 64], a3 = wss[((size_t)((g.C >> 4) + mt) * ekb + kb) * 64];
 #pragma unroll
                   for (int j = 0; j < 4; ++j) {
                     const float bj = Gs[16 * kb + 4 * j + kq];
-                    sc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_sc[j], bj, sc, 0, 0, 0);
-                    sh = __builtin_amdgcn_mfma_f32_16x16x4f32(a_sh[j], bj, sh, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j], bj, sc, 0, 0, 0);
+                    sh = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[j], bj, sh, 0, 0, 0);
                   }
                 }
-              } else {  // C = 4: one m-tile holds scale rows 0..3 (row quarter 0) and shift rows 4..7 (quarter 1)
-                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+              } else {
+                f32x4 t = sc;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] = sb[4 * kq + r < 2 * g.C ? 4 * kq + r : 0];
-                for (int kb = 0; kb < ekb; ++kb) {
-                  const f32x4 a_t = wss[(size_t)kb * 64];
+                for (int j = 0; j < 4; ++j) t = __builtin_amdgcn_mfma_f32_16x16x4f32(a_sc[p][mi][j], gb[j], t, 0, 0, 0);
+                for (int kb = 1; kb < ekb; ++kb) {
+                  const f32x4 a2 = wss[(size_t)kb * 64];
 #pragma unroll
-                  for (int j = 0; j < 4; ++j) t = __builtin_amdgcn_mfma_f32_16x16x4f32(a_t[j], Gs[16 * kb + 4 * j + kq], t, 0, 0, 0);
+                  for (int j = 0; j < 4; ++j) t = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j], Gs[16 * kb + 4 * j + kq], t, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -495,7 +526,7 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float y = (acc[p][mi][ni][r] - mean[p][mi][r]) * rstd[p][mi][r] * ga[r] + be[r];
+              float y = (acc[p][mi][ni][r] - mean[p][mi][r]) * rstd[p][mi][r] * ga[p][mi][r] + be[p][mi][r];
               if (has_ss) y = y * sc[r] + sh[r];
               y = silu(y);
               if (row0 + r < cout) {
@@ -581,12 +612,14 @@ __device__ __forceinline__ void layer_norm_rows(const Ctx &c, const float *src, 
   float *red1 = c.lds + GG::kMiscRed1, *red2 = c.lds + GG::kMiscRed2;
   const int n = c.lane & (NC - 1), slot = c.wave * GG::kRP + c.lane / NC;
   const lds_f *s3 = (const lds_f *)src;
-  float v[ITERS];
+  const float *g = c.w + g_off;
+  float v[ITERS], gv[ITERS];  // the gains are requested up front: their L2 round trip hides behind the statistics
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
     const int row = slot + 8 * i;
     const float x = s3[swz<NC>(row < C ? row : 0, n)];
+    gv[i] = g[row < C ? row : 0];
     v[i] = row < C ? x : 0.f;
     sum += v[i];
   }
@@ -611,13 +644,12 @@ __device__ __forceinline__ void layer_norm_rows(const Ctx &c, const float *src, 
 #pragma unroll
   for (int q = 0; q < GG::kWaves; ++q) vt += red2[q * 64 + c.lane];
   const float rstd = __builtin_amdgcn_rsqf(vt / (float)C + 1e-5f);
-  const float *g = c.w + g_off;
   lds_f *d3 = (lds_f *)dst, *r3 = (lds_f *)res;
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
     const int row = slot + 8 * i;
     if (row < C) {
-      const float y = (v[i] - mean) * rstd * g[row];
+      const float y = (v[i] - mean) * rstd * gv[i];
       const int a = swz<NC>(row, n);
       if (res) r3[a] = r3[a] + y;
       else d3[a] = y;
