@@ -149,7 +149,7 @@ def main():
         # memory-side bytes of one launch from the committed PMC passes (tools/pmc_denoise.sh: FETCH_SIZE, doubled
         # per the gfx950 16-B/lane rule, + WRITE_SIZE); only quoted for the workload they were collected on
         traffic = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01c_denoise_pmc.json")
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01d_denoise_pmc.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             if pmc.get("n_latents") == B * G and pmc.get("steps") == S:
@@ -157,7 +157,9 @@ def main():
         roof = dict(kernel="r1d_kernel<32, 4> (gldm_denoise: %d DDIM steps fused)" % S, bound="mfma",
                     achieved=flop / t_den / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=flop / t_den / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
-                    algorithmic_flop_per_launch=flop, avg_launch_ms=t_den * 1e3)
+                    algorithmic_flop_per_launch=flop, avg_launch_ms=t_den * 1e3,
+                    timing="HIP events around 3 launches on their own (no other stream active); in the pipelined "
+                           "steps the other stream's encoder kernels share the GPU with the launch")
         # ---- stage split and the set-abstraction gather (north-star HBM kernel), same run
         t_enc = event_time(lambda: ldm.vae_model.encode_pc(pcs), 3)
         dec = ldm.vae_model.decoder
