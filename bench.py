@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--ddim-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps alternate over (2: batch k+1's encoder overlaps batch k's denoise tail)")
     return ap.parse_args()
 
