@@ -90,6 +90,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
     __syncthreads();
     // ---- 27 taps x 4 k-steps of MFMA; weights one tap ahead
     f32x4 a_cur[MT], a_nxt[MT];
+    const int jn = (min(cin - cb * 16, 16) + 3) >> 2;  // k-steps of 4 channels that hold real channels (Cin = 3: one)
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) a_cur[mi] = wv[((size_t)mi * kblocks + cb) * 64];
     for (int tap = 0; tap < 27; ++tap) {
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
       const int toff = (dx * 6 + dy) * zp + dz;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (j >= jn) break;
         float bf[NTW];
 #pragma unroll
         for (int ni = 0; ni < NTW; ++ni) bf[ni] = l3[obase[ni] + toff + 4 * j * bvp];
