@@ -973,6 +973,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   __syncthreads();
 
   for (int step = 0; step < a.n_steps; ++step) {
+    if (a.stamps && blockIdx.x == 0 && c.tid == 0) a.stamps[kMaxOps + 1] = (long long)__builtin_readcyclecounter();
     // ---- G[s][e] = sum_r silu(temb[t][e] + cemb[cond][r][e])
     if (!(c.skip & 32))
     for (int i = c.tid; i < S * E; i += GG::kThreads) {
@@ -1247,11 +1248,11 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   }
   const bool stamp = getenv("GLDM_R1D_STAMP") != nullptr;  // diagnostic: blocks, copies and prints
   static long long *dstamps = nullptr;
-  if (stamp && !dstamps) (void)hipMalloc(&dstamps, (kMaxOps + 1) * sizeof(long long));
+  if (stamp && !dstamps) (void)hipMalloc(&dstamps, (kMaxOps + 2) * sizeof(long long));
   a.stamps = stamp ? dstamps : nullptr;
   const int rc = L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s);
   if (stamp) {
-    static long long host[kMaxOps + 1];
+    static long long host[kMaxOps + 2];
     static const char *names[] = {"", "CONV", "", "LN", "ATT"};
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(host, dstamps, sizeof(host), hipMemcpyDeviceToHost);
@@ -1271,7 +1272,8 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
       line(1, 128, C, 1); line(3, C, C, 0); line(1, C, dims[lv + 1], 3);
     }
     resblock(dims[a.d.n_levels]);
-    printf("step total (ops): %lld clk\n", host[op] - host[0]);
+    printf("step total (ops): %lld clk; step prologue (embedding sums, init conv): %lld clk\n", host[op] - host[0],
+           host[0] - host[kMaxOps + 1]);
   }
   return rc;
 }

@@ -169,7 +169,29 @@ def test_fused_sa_mlp_equals_unfused_oracle(b, c, n, m, u, chans):
     assert _err(got, exp) < 2e-5, _err(got, exp)
 
 
-@pytest.mark.parametrize("cin,cout,r", [(3, 48, 24), (48, 48, 24), (48, 96, 12), (96, 96, 12), (3, 32, 32), (64, 64, 16)])
+@pytest.mark.parametrize("b,c,n,relu", [(3, 48, 1024, 1), (2, 1536, 512, 1), (4, 3, 64, 0), (1, 7, 20, 1)])
+def test_bias_act_epilogue(b, c, n, relu):
+    """gldm_bias_act: the one-pass bias + ReLU epilogue of the k = 1 convs (shared_mlp.py:24-36); bit-exact (add, max)."""
+    from graspldm_amd import _lib as L
+    g = torch.Generator().manual_seed(b * 100 + c)
+    y = torch.randn(b, c, n, generator=g).cuda()
+    bias = torch.randn(c, generator=g).cuda()
+    want = y + bias.view(1, -1, 1)
+    if relu:
+        want = torch.relu(want)
+    L.call("gldm_bias_act", L.ptr(y), L.ptr(bias), b, c, n, relu, L.current_stream(y.device))
+    assert torch.equal(y, want)
+
+
+def test_bias_act_rejects_unaligned_rows():
+    from graspldm_amd import _lib as L
+    y = torch.zeros(1, 2, 6).cuda()
+    with pytest.raises(L.GldmError):
+        L.call("gldm_bias_act", L.ptr(y), L.ptr(torch.zeros(2).cuda()), 1, 2, 6, 1, L.current_stream(y.device))
+
+
+@pytest.mark.parametrize("cin,cout,r", [(3, 48, 24), (48, 48, 24), (48, 96, 12), (96, 96, 12), (3, 32, 32), (64, 64, 16),
+                                        (20, 48, 24)])
 def test_conv3d_groupnorm_swish_kernels(cin, cout, r):
     """gldm_conv3d_k3 + gldm_groupnorm_swish vs torch conv3d / group_norm on the CPU (fp32, 2e-5:
     K = 27 cin products per output in a different summation order)."""
