@@ -933,7 +933,9 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   // Tiles: the first `full_tiles` workgroups own S samples each; the remainder of the batch is
   // spread over `tail_tiles` workgroups of `tail_samples` (one live 16-column n-tile) so the last
   // round of workgroups is not full-width tiles on a fraction of the CUs.
-  const int tile = blockIdx.x;
+  // the short tail tiles are dispatched first (blockIdx < tail_tiles): each then shares its CU with a full
+  // tile from the start instead of running alone at the end
+  const int tile = (int)blockIdx.x < a.tail_tiles ? a.full_tiles + (int)blockIdx.x : (int)blockIdx.x - a.tail_tiles;
   const bool is_tail = tile >= a.full_tiles;
   const int samp0 = is_tail ? a.full_tiles * S + (tile - a.full_tiles) * a.tail_samples : tile * S;
   c.nta = (is_tail && a.tail_samples * L <= 16) ? 1 : GG::kNT;
