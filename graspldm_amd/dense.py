@@ -41,6 +41,12 @@ def _gemm_bias_act(x, w2d, bias, relu):
     return y.reshape(shape[0], w2d.shape[0], *shape[2:])
 
 
+def pointwise_gemm(x, w2d, bias):
+    """W x + b over [B, Cin, ...] with an explicit (e.g. folded) weight matrix."""
+    _need_cuda(x)
+    return _gemm_bias_act(x.float(), w2d, bias, False)
+
+
 def pointwise_conv(x, conv):
     """Conv1d/Conv2d with kernel 1 (+bias), no activation."""
     _need_cuda(x)

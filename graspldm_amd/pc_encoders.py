@@ -38,10 +38,27 @@ class PVCNNEncoder(nn.Module):
             raise RuntimeError("pointcloud must be a CUDA tensor (graspldm_amd has no CPU path)")
         x = torch.transpose(out, 1, 2).contiguous()
         x = self.pvcnn_modules(x, cond=cond)
-        x = dense.pointwise_conv(x, self.conv_downscale)
-        x = dense.pointwise_conv(x, self.out_layer[0])
+        w, b = self._folded_head()
+        x = dense.pointwise_gemm(x, w, b)
         x = dense.linear(x, self.out_layer[1])
         return x.squeeze(1) if x.shape[-2] == 1 else x
+
+    def _folded_head(self):
+        """conv_downscale (C -> C/2, k=1) and out_layer[0] (C/2 -> out_channels, k=1) have nothing between them
+        when global attention is off (pc_encoders.py:104-111): W = W_out W_down, b = W_out b_down + b_out, one
+        [out_channels x C] GEMM over the points instead of a 2 C^2/2 FLOP-per-point one.  Folded in f64 once per
+        weight version."""
+        cd, o0 = self.conv_downscale, self.out_layer[0]
+        key = (cd.weight.data_ptr(), cd.weight._version, cd.bias._version, o0.weight.data_ptr(), o0.weight._version,
+               o0.bias._version)
+        hit = self.__dict__.get("_head_cache")
+        if hit is None or hit[0] != key:
+            wo, wd = o0.weight[:, :, 0].double(), cd.weight[:, :, 0].double()
+            w = (wo @ wd).float().contiguous()
+            b = (wo @ cd.bias.double() + o0.bias.double()).float().contiguous()
+            hit = (key, w, b)
+            self.__dict__["_head_cache"] = hit
+        return hit[1], hit[2]
 
     def load_ckpt_and_freeze(self, ckpt_path, fine_tune=False):
         ckpt = torch.load(ckpt_path, map_location="cpu")
