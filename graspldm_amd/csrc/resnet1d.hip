@@ -347,6 +347,38 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
   using GG = Geo<NC>;
   f32x4 acc[PASSES][MT][NT];
   const int kq = c.lane >> 4, col = c.lane & 15;
+  // ---- parameters of the GroupNorm epilogue.  Every load goes out in one batch: before the k-sweep when the
+  // variant is a single pass (registers to spare: the round trip hides behind the GEMM), else at the start of
+  // the epilogue, in the shadow of the statistics.
+  constexpr bool kEarlyParams = TAPS == 3 && NC == 32 && PASSES == 1;
+  const bool has_ss = g.ss_w >= 0;
+  const bool wide = g.C >= 16;  // else C = 4: one m-tile holds scale rows 0..3 (row quarter 0) and shift rows 4..7
+  const int ekb = g.E >> 4;
+  gf4p wss = (gf4p)(reinterpret_cast<const f32x4 *>(c.w + (has_ss ? g.ss_w : 0)) + c.lane);
+  f32x4 ga[PASSES][MT], be[PASSES][MT], sc0[PASSES][MT], sh0[PASSES][MT], a_sc[PASSES][MT], a_sh[PASSES][MT];
+#define GLDM_LOAD_GN_PARAMS()                                                                                       \
+  _Pragma("unroll") for (int p = 0; p < PASSES; ++p) _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) {            \
+    const int mt_ = mt0 + p * MT + mi;                                                                              \
+    const int row0_ = 16 * mt_ + 4 * kq;                                                                            \
+    const int prow_ = row0_ + 3 < cout ? row0_ : 0; /* rows past cout (narrow levels) are not stored */             \
+    ga[p][mi] = *reinterpret_cast<const f32x4 *>(c.w + g.gamma_off + prow_);                                        \
+    be[p][mi] = *reinterpret_cast<const f32x4 *>(c.w + g.beta_off + prow_);                                         \
+    sc0[p][mi] = f32x4{1.f, 1.f, 1.f, 1.f};                                                                         \
+    sh0[p][mi] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                         \
+    if (has_ss) {                                                                                                   \
+      const float *sb_ = c.w + g.ss_b;                                                                              \
+      if (wide) { /* scale rows: m-tile mt, shift rows: m-tile C/16 + mt of the [2C x E] Linear */                  \
+        sc0[p][mi] = *reinterpret_cast<const f32x4 *>(sb_ + row0_);                                                 \
+        sh0[p][mi] = *reinterpret_cast<const f32x4 *>(sb_ + g.C + row0_);                                           \
+        a_sc[p][mi] = wss[(size_t)mt_ * ekb * 64];                                                                  \
+        a_sh[p][mi] = wss[(size_t)((g.C >> 4) + mt_) * ekb * 64];                                                   \
+      } else {                                                                                                      \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) sc0[p][mi][r] = sb_[4 * kq + r < 2 * g.C ? 4 * kq + r : 0];   \
+        a_sc[p][mi] = wss[0];                                                                                       \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+  if (kEarlyParams && g.mode && active) { GLDM_LOAD_GN_PARAMS() }
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
 #pragma unroll
@@ -372,37 +404,7 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
       if (!active) return;
       const float inv_cnt = 1.0f / (float)(g.cpg * L);  // a power of two: exact
       lds_f *d3 = (lds_f *)(g.mode == 2 ? g.res : dst);
-      const bool has_ss = g.ss_w >= 0;
-      const bool wide = g.C >= 16;  // else C = 4: one m-tile holds scale rows 0..3 (row quarter 0) and shift rows 4..7
-      const int ekb = g.E >> 4;
-      gf4p wss = (gf4p)(reinterpret_cast<const f32x4 *>(c.w + (has_ss ? g.ss_w : 0)) + c.lane);
-      // ---- every parameter load of the epilogue goes out first; the statistics below run in their shadow
-      f32x4 ga[PASSES][MT], be[PASSES][MT], sc0[PASSES][MT], sh0[PASSES][MT], a_sc[PASSES][MT], a_sh[PASSES][MT];
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          const int mt = mt0 + p * MT + mi;
-          const int row0 = 16 * mt + 4 * kq;
-          const int prow = row0 + 3 < cout ? row0 : 0;  // rows past cout (narrow levels) are not stored
-          ga[p][mi] = *reinterpret_cast<const f32x4 *>(c.w + g.gamma_off + prow);
-          be[p][mi] = *reinterpret_cast<const f32x4 *>(c.w + g.beta_off + prow);
-          sc0[p][mi] = f32x4{1.f, 1.f, 1.f, 1.f};
-          sh0[p][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (has_ss) {
-            const float *sb = c.w + g.ss_b;
-            if (wide) {  // scale rows: m-tile mt, shift rows: m-tile C/16 + mt of the [2C x E] Linear
-              sc0[p][mi] = *reinterpret_cast<const f32x4 *>(sb + row0);
-              sh0[p][mi] = *reinterpret_cast<const f32x4 *>(sb + g.C + row0);
-              a_sc[p][mi] = wss[(size_t)mt * ekb * 64];
-              a_sh[p][mi] = wss[(size_t)((g.C >> 4) + mt) * ekb * 64];
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) sc0[p][mi][r] = sb[4 * kq + r < 2 * g.C ? 4 * kq + r : 0];
-              a_sc[p][mi] = wss[0];
-            }
-          }
-        }
+      if (!kEarlyParams) { GLDM_LOAD_GN_PARAMS() }
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) {
         const int n = 16 * (nt0 + ni) + col;
@@ -545,6 +547,8 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
     for (int p = 0; p < PASSES; ++p) store_tiles<NC, MT, NT>(c, acc[p], mt0 + p * MT, nt0, dst, cout, act);
   }
 }
+
+#undef GLDM_LOAD_GN_PARAMS
 
 // dst[cout][NC] = W * im2col(src[cin][NC]) + bias: the waves split the output rows (all n-tiles each).
 // Ends with a barrier.  alias: dst overlaps src -> all reads complete (barrier) before any store.
