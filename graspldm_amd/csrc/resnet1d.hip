@@ -55,6 +55,7 @@ struct Geo {
   static constexpr int kThreads = kWaves * 64;
   static constexpr int kNT = NC / 16;             // 16-column n-tiles
   static constexpr int kRP = 64 / NC;             // rows a wave touches per pass: lane = (sub, column)
+  static constexpr int kSlots = kWaves * kRP;     // row slots of the norm passes
   static constexpr int kBufX = 0;
   static constexpr int kBufH = kMaxC * NC;
   static constexpr int kBufY = 128 * NC;          // attention: LayerNorm output, later to_out output
@@ -64,9 +65,9 @@ struct Geo {
   static constexpr int kMiscLat = kArena;         // [NC] current latent row
   static constexpr int kMiscEps = kMiscLat + NC;
   static constexpr int kMiscG = kMiscEps + NC;    // [S][E] <= 320
-  static constexpr int kMiscRed1 = kMiscG + 320;  // [kWaves][64]
-  static constexpr int kMiscRed2 = kMiscRed1 + kWaves * 64;
-  static constexpr int kMiscTape = kMiscRed2 + kWaves * 64;  // [kMaxOps][12] ints: the step program (+ its length)
+  static constexpr int kMiscRed1 = kMiscG + 320;  // [kWaves][NC] cross-wave exchange slots (per wave and column)
+  static constexpr int kMiscRed2 = kMiscRed1 + kWaves * NC;
+  static constexpr int kMiscTape = kMiscRed2 + kWaves * NC;  // [kMaxOps][12] ints: the step program (+ its length)
   static constexpr int kLdsFloats = kMiscTape + 1024;
 };
 static_assert(Geo<64>::kLdsFloats * 4 <= 160 * 1024, "LDS budget (1 WG/CU)");
@@ -554,8 +555,10 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
 // Ends with a barrier.  alias: dst overlaps src -> all reads complete (barrier) before any store.
 // Output widths are 16 x {1, 2, 4, 8, 12, 16} rows (validate() enforces it).
 // (Tried and dropped: running the <= 64-channel levels column-parallel, one wave per n-tile with no
-// barriers inside the level.  Those phases are bound by per-wave issue, not by the barriers: with
-// half the waves active every op took 1.7-2x longer.)
+// barriers inside the level: those phases are bound by per-wave issue, not by the barriers, and with
+// half the waves active every op took 1.7-2x longer.  And the opposite, 8 waves per 32-column tile
+// with the statistics of a wide group exchanged between wave pairs: correct, but at 128 VGPRs per
+// wave the k-loops spill and the launch was 5-7 % slower than with 4 waves.)
 template <int NC, int L>
 __device__ __forceinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, const float *src, int cin, int ktaps,
                                           float *dst, int cout, bool alias, int act = 0,
@@ -608,7 +611,7 @@ __device__ __forceinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, co
 
 // ----------------------------------------------------------- LayerNorm ----
 // dst = LN_channels(src) * g  (or res += LN(src) * g when res != null).  Row slot = wave*kRP + sub
-// (8 slots in both geometries), rows slot + 8 i.
+// (kSlots = kWaves * kRP of them), rows slot + kSlots i.
 template <int NC, int ITERS>
 __device__ __forceinline__ void layer_norm_rows(const Ctx &c, const float *src, float *dst, float *res, int C,
                                                 int g_off) {
@@ -621,37 +624,37 @@ __device__ __forceinline__ void layer_norm_rows(const Ctx &c, const float *src, 
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
-    const int row = slot + 8 * i;
+    const int row = slot + GG::kSlots * i;
     const float x = s3[swz<NC>(row < C ? row : 0, n)];
     gv[i] = g[row < C ? row : 0];
     v[i] = row < C ? x : 0.f;
     sum += v[i];
   }
   if (GG::kRP == 2) sum = half_sum(sum);
-  red1[c.wave * 64 + c.lane] = sum;
+  red1[c.wave * NC + n] = sum;
   __syncthreads();
   float tot = 0.f;
 #pragma unroll
-  for (int q = 0; q < GG::kWaves; ++q) tot += red1[q * 64 + c.lane];
+  for (int q = 0; q < GG::kWaves; ++q) tot += red1[q * NC + n];
   const float mean = tot / (float)C;
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
-    const int row = slot + 8 * i;
+    const int row = slot + GG::kSlots * i;
     const float d = row < C ? v[i] - mean : 0.f;
     sq += d * d;
   }
   if (GG::kRP == 2) sq = half_sum(sq);
-  red2[c.wave * 64 + c.lane] = sq;
+  red2[c.wave * NC + n] = sq;
   __syncthreads();
   float vt = 0.f;
 #pragma unroll
-  for (int q = 0; q < GG::kWaves; ++q) vt += red2[q * 64 + c.lane];
+  for (int q = 0; q < GG::kWaves; ++q) vt += red2[q * NC + n];
   const float rstd = __builtin_amdgcn_rsqf(vt / (float)C + 1e-5f);
   lds_f *d3 = (lds_f *)dst, *r3 = (lds_f *)res;
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
-    const int row = slot + 8 * i;
+    const int row = slot + GG::kSlots * i;
     if (row < C) {
       const float y = (v[i] - mean) * rstd * gv[i];
       const int a = swz<NC>(row, n);
@@ -666,7 +669,7 @@ template <int NC>
 __device__ __forceinline__ void layer_norm_pass(const Ctx &c, const float *src, float *dst, float *res, int C, int g_off) {
   if (c.skip & 2) return;
   C = __builtin_amdgcn_readfirstlane(C);
-  const int it = (C + 7) / 8;
+  const int it = (C + Geo<NC>::kSlots - 1) / Geo<NC>::kSlots;
   if (it <= 1) layer_norm_rows<NC, 1>(c, src, dst, res, C, g_off);
   else if (it <= 2) layer_norm_rows<NC, 2>(c, src, dst, res, C, g_off);
   else if (it <= 4) layer_norm_rows<NC, 4>(c, src, dst, res, C, g_off);
@@ -683,7 +686,8 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
   using GG = Geo<NC>;
   constexpr int WPH = GG::kWaves / 2;       // waves per head
   const int n = c.lane & (NC - 1), sub = c.lane / NC, sbase = n & ~(L - 1);
-  const int hl = c.wave / WPH, part = (c.wave % WPH) * GG::kRP + sub, e0 = 8 * part;
+  constexpr int CH = kDimHead / (WPH * GG::kRP);  // channels of a head per lane: 8 (4 at 8 waves)
+  const int hl = c.wave / WPH, part = (c.wave % WPH) * GG::kRP + sub, e0 = CH * part;
   const int qrow0 = hl * kDimHead, krow0 = 64 + hl * kDimHead, vrow0 = 128 + hl * kDimHead;
   const lds_f *q3 = (const lds_f *)qkv;
   lds_f *o3 = (lds_f *)o_rows;
@@ -691,25 +695,25 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
     // softmax statistics and the 4x4 matrix A = softmax_n(k)^T softmax_d(q) are combined over
     // the parts by a lane swap (row slots) and one exchange through LDS (waves)
     float *red1 = c.lds + GG::kMiscRed1, *red2 = c.lds + GG::kMiscRed2;
-    lds_f *part_a = (lds_f *)qkv;  // q rows are dead after phase 1: [kWaves][4][64] partial A
-    float q[8];
+    lds_f *part_a = (lds_f *)qkv;  // q rows are dead after phase 1: [kWaves][4][NC] partial A
+    float q[CH];
     float qmax = -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < CH; ++i) {
       q[i] = q3[swz<NC>(qrow0 + e0 + i, n)];
       qmax = fmaxf(qmax, q[i]);
     }
-    f32x4 kv[8];
+    f32x4 kv[CH];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kv[i] = *(const lds_f4 *)(q3 + swz<NC>(krow0 + e0 + i, sbase));
+    for (int i = 0; i < CH; ++i) kv[i] = *(const lds_f4 *)(q3 + swz<NC>(krow0 + e0 + i, sbase));
     if (GG::kRP == 2) qmax = half_max(qmax);
-    red1[c.wave * 64 + c.lane] = qmax;
+    red1[c.wave * NC + n] = qmax;
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < WPH; ++w) qmax = fmaxf(qmax, red1[(hl * WPH + w) * 64 + c.lane]);
+    for (int w = 0; w < WPH; ++w) qmax = fmaxf(qmax, red1[(hl * WPH + w) * NC + n]);
     float qsum = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < CH; ++i) {
       const float e = fast_exp(q[i] - qmax);
       qsum += e;
       const float km = fmaxf(fmaxf(kv[i].x, kv[i].y), fmaxf(kv[i].z, kv[i].w));
@@ -723,29 +727,29 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
       a0 = half_sum(a0); a1 = half_sum(a1);
       a2 = half_sum(a2); a3 = half_sum(a3);
     }
-    red2[c.wave * 64 + c.lane] = qsum;
-    part_a[(c.wave * 4 + 0) * 64 + c.lane] = a0;
-    part_a[(c.wave * 4 + 1) * 64 + c.lane] = a1;
-    part_a[(c.wave * 4 + 2) * 64 + c.lane] = a2;
-    part_a[(c.wave * 4 + 3) * 64 + c.lane] = a3;
-    f32x4 vv[8];
+    red2[c.wave * NC + n] = qsum;
+    part_a[(c.wave * 4 + 0) * NC + n] = a0;
+    part_a[(c.wave * 4 + 1) * NC + n] = a1;
+    part_a[(c.wave * 4 + 2) * NC + n] = a2;
+    part_a[(c.wave * 4 + 3) * NC + n] = a3;
+    f32x4 vv[CH];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) vv[i] = *(const lds_f4 *)(q3 + swz<NC>(vrow0 + e0 + i, sbase));
+    for (int i = 0; i < CH; ++i) vv[i] = *(const lds_f4 *)(q3 + swz<NC>(vrow0 + e0 + i, sbase));
     __syncthreads();
     qsum = 0.f; a0 = a1 = a2 = a3 = 0.f;
 #pragma unroll
     for (int w = 0; w < WPH; ++w) {
       const int ww = hl * WPH + w;
-      qsum += red2[ww * 64 + c.lane];
-      a0 += part_a[(ww * 4 + 0) * 64 + c.lane];
-      a1 += part_a[(ww * 4 + 1) * 64 + c.lane];
-      a2 += part_a[(ww * 4 + 2) * 64 + c.lane];
-      a3 += part_a[(ww * 4 + 3) * 64 + c.lane];
+      qsum += red2[ww * NC + n];
+      a0 += part_a[(ww * 4 + 0) * NC + n];
+      a1 += part_a[(ww * 4 + 1) * NC + n];
+      a2 += part_a[(ww * 4 + 2) * NC + n];
+      a3 += part_a[(ww * 4 + 3) * NC + n];
     }
     const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(qsum);  // dim_head ** -0.5 / sum
     a0 *= sc; a1 *= sc; a2 *= sc; a3 *= sc;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < CH; ++i)
       o3[swz<NC>(hl * kDimHead + e0 + i, n)] = vv[i].x * a0 + vv[i].y * a1 + vv[i].z * a2 + vv[i].w * a3;
     __syncthreads();
   } else {
@@ -777,7 +781,7 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
 #pragma unroll
       for (int i = 0; i < L; ++i) A[i] += kv[i] * f;
     }
-    for (int e = e0; e < e0 + 8; ++e) {
+    for (int e = e0; e < e0 + CH; ++e) {
       float acc = 0.f;
 #pragma unroll
       for (int i = 0; i < L; ++i) acc += q3[swz<NC>(vrow0 + e, sbase + i)] * A[i];
@@ -1020,14 +1024,14 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       float *red1 = lds + GG::kMiscRed1;
       const int n = c.lane & (NC - 1), slot = c.wave * GG::kRP + c.lane / NC;
       float part = 0.f;
-      for (int row = slot; row < CF; row += 8) part += a.weights[d.final_w + row] * X[swz<NC>(row, n)];
+      for (int row = slot; row < CF; row += GG::kSlots) part += a.weights[d.final_w + row] * X[swz<NC>(row, n)];
       if (GG::kRP == 2) part = half_sum(part);
-      red1[c.wave * 64 + c.lane] = part;
+      red1[c.wave * NC + n] = part;
       __syncthreads();
       if (c.tid < NC) {
         float e = a.weights[d.final_b];
 #pragma unroll
-        for (int q = 0; q < GG::kWaves; ++q) e += red1[q * 64 + c.tid];
+        for (int q = 0; q < GG::kWaves; ++q) e += red1[q * NC + c.tid];
         epsr[c.tid] = e;
         if (a.sched_kind != GLDM_SCHED_NONE) {
           const int s = c.tid / L, l = c.tid % L;
@@ -1183,7 +1187,7 @@ int validate(const gldm_r1d_desc *d) {
   if (!d) return GLDM_ERR_INVALID_ARG;
   if (d->seq_len != 4 && d->seq_len != 16) return GLDM_ERR_UNSUPPORTED;
   if (d->n_levels < 1 || d->n_levels > GLDM_R1D_MAX_LEVELS || 12 * d->n_levels + 2 > kMaxOps) return GLDM_ERR_UNSUPPORTED;
-  const int nc = engine_nc(), waves = nc / 8;
+  const int nc = engine_nc(), waves = 4;
   const int S = nc / d->seq_len;
   if (d->emb_dim <= 0 || (d->emb_dim & 15) || S * d->emb_dim > 320) return GLDM_ERR_UNSUPPORTED;
   if (d->groups != 4 || waves != 4) return GLDM_ERR_UNSUPPORTED;  // GroupNorm lives in the conv epilogue
