@@ -35,7 +35,8 @@ __host__ __device__ inline int brick_row_stride(int r) {  // dwords per channel 
   return p;
 }
 
-template <int MT, int NTW>
+// JN: k-steps of 4 input channels per tap and 16-channel block that hold real channels (Cin <= 4: 1, else 4)
+template <int MT, int NTW, int JN>
 __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float *__restrict__ x,
                                                                     const float *__restrict__ wp,
                                                                     const float *__restrict__ bias, int cin, int cout,
@@ -88,28 +89,31 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
       lds[ci * bvp + rem] = v;
     }
     __syncthreads();
-    // ---- 27 taps x 4 k-steps of MFMA; weights one tap ahead
+    // ---- 27 taps x JN k-steps of MFMA; weights one tap ahead, B fragments (LDS) one k-step ahead
     f32x4 a_cur[MT], a_nxt[MT];
-    const int jn = (min(cin - cb * 16, 16) + 3) >> 2;  // k-steps of 4 channels that hold real channels (Cin = 3: one)
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) a_cur[mi] = wv[((size_t)mi * kblocks + cb) * 64];
+    float bf[NTW], bn[NTW];
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) bf[ni] = l3[obase[ni]];  // tap 0, k-step 0
     for (int tap = 0; tap < 27; ++tap) {
       const int tn = tap + 1 < 27 ? tap + 1 : tap;
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) a_nxt[mi] = wv[((size_t)mi * kblocks + tn * cblocks + cb) * 64];
-      const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-      const int toff = (dx * 6 + dy) * zp + dz;
+      const int toff = ((tap / 9) * 6 + (tap / 3) % 3) * zp + tap % 3;
+      const int tnoff = ((tn / 9) * 6 + (tn / 3) % 3) * zp + tn % 3;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j >= jn) break;
-        float bf[NTW];
+      for (int j = 0; j < JN; ++j) {
+        const int noff = j + 1 < JN ? toff + 4 * (j + 1) * bvp : tnoff;  // the read after the last one is redundant
 #pragma unroll
-        for (int ni = 0; ni < NTW; ++ni) bf[ni] = l3[obase[ni] + toff + 4 * j * bvp];
+        for (int ni = 0; ni < NTW; ++ni) bn[ni] = l3[obase[ni] + noff];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NTW; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mi][j], bf[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) bf[ni] = bn[ni];
       }
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) a_cur[mi] = a_nxt[mi];
@@ -275,18 +279,18 @@ __global__ __launch_bounds__(256) void devoxelize_fused_kernel(const float *__re
   }
 }
 
-template <int MT, int NTW>
-int launch_conv(const float *x, const float *wp, const float *bias, int b, int cin, int cout, int r, float *y,
+template <int MT, int NTW, int JN>
+int launch_conv_jn(const float *x, const float *wp, const float *bias, int b, int cin, int cout, int r, float *y,
                 float *partial, hipStream_t s) {
   const size_t lds_bytes = (size_t)16 * brick_row_stride(r) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_k3_kernel<MT, NTW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_k3_kernel<MT, NTW, JN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr = true;
   }
   const int bpr = r / kBrick;
-  hipLaunchKernelGGL((conv3d_k3_kernel<MT, NTW>), dim3(bpr * bpr, b), dim3(kConvThreads), lds_bytes, s, x, wp, bias,
+  hipLaunchKernelGGL((conv3d_k3_kernel<MT, NTW, JN>), dim3(bpr * bpr, b), dim3(kConvThreads), lds_bytes, s, x, wp, bias,
                      cin, cout, r, y, partial);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
@@ -312,6 +316,14 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ y, co
 GLDM_API long long gldm_conv3d_partial_floats(int b, int cout, int r) {
   if (b <= 0 || cout <= 0 || r <= 0 || r % kBrick) return -1;
   return (long long)b * (r / kBrick) * (r / kBrick) * cout * 2;
+}
+
+template <int MT, int NTW>
+int launch_conv(const float *x, const float *wp, const float *bias, int b, int cin, int cout, int r, float *y,
+                float *partial, hipStream_t s) {
+  // a 3-channel input (the first voxel conv) has one real k-step per tap: skip the three of padding
+  return cin <= 4 ? launch_conv_jn<MT, NTW, 1>(x, wp, bias, b, cin, cout, r, y, partial, s)
+                  : launch_conv_jn<MT, NTW, 4>(x, wp, bias, b, cin, cout, r, y, partial, s);
 }
 
 GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *bias, int b, int cin, int cout, int r,
