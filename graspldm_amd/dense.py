@@ -1,13 +1,19 @@
-"""Dense layers of the PVCNN encoder (k=1 convs, 3x3x3 voxel convs, GroupNorm,
-Swish) on the GPU.
-
-Round-1 state: these run as PyTorch-ROCm device ops (rocBLAS / MIOpen) on CUDA
-tensors; the f32-MFMA GEMM / implicit-GEMM kernels that replace them live in
-csrc/ as they land (see DESIGN.md "Kernels").  Never a CPU path: CPU tensors are
-rejected like everywhere else in this package.
+"""Dense layers of the PVCNN encoder that run as plain library GEMMs: k=1 convs (bias-free GEMM +
+the fused gldm_bias_act epilogue) and Linear over points.  The 3x3x3 voxel convs, GroupNorm+Swish, SE and
+devoxelize are hand-written kernels (voxel.py / csrc/voxel_conv.hip); `conv3d_gn_swish` below is only the
+path for voxel shapes those kernels are not instantiated for.  Never a CPU path: CPU tensors are rejected
+like everywhere else in this package.
 """
-import torch
-import torch.nn.functional as F
+import os
+
+# The k = 1 convolutions go to MIOpen, whose default "find" benchmarks every solver (including a naive
+# reference kernel) on the first call of each new shape: ~7 s of GPU time for the encoder's shapes.  The fast
+# mode picks the same rocBLAS GEMM solver here without the search.  Set before MIOpen initialises; a value
+# the user exported wins.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 
 
 def _need_cuda(x, name="input"):
