@@ -820,10 +820,118 @@ struct RunArgs {
 // down conv).  It is written once per workgroup into LDS (12 ints per op) and interpreted by a switch
 // inside the step loop, so every phase body exists once, inlined, with registers allocated across the
 // whole kernel: no calls, no callee-save traffic and no spilled kernel state between phases.
-enum { OP_CONV = 1, OP_LN = 3, OP_ATT = 4 };
+enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4 };
 constexpr int kOpInts = 12, kMaxOps = 84;  // 84 * 12 = 1008 ints; the op count lives in int 1023
 // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9
 constexpr int kFlagAlias = 1 << 8;
+
+// ResnetBlock of a 4-channel level with 4-position samples (the first level of the latent denoiser) on the
+// VALU of ONE wave, in registers: as two MFMA ops it is two padded 16x16 tiles and two long epilogues for
+// 48 MACs per output.  lane = (channel pair h, column n): every lane keeps all 4 input channels of its column
+// and produces output channels 2h, 2h+1.  Taps come from the neighbouring lanes of the quad (= the sample),
+// GroupNorm (one channel per group) is a quad reduction, the two channel pairs meet through a permlane swap.
+// Weights are read in their packed MFMA-fragment order: conv W[co][ci][tap] at ((ci * 16 + co) * 4 + tap),
+// scale/shift Linear W[row][e] at (((e & 3) * 16 + row) * 4 + (e >> 2)).
+template <int NC>
+__device__ __forceinline__ void resblock4_valu(const Ctx &c, const int (&o)[kOpInts], int E) {
+  using GG = Geo<NC>;
+  if (c.wave != 0) return;
+  const int n = c.lane & 31, h = c.lane >> 5, l = n & 3;
+  const bool has_l = l != 0, has_r = l != 3;
+  lds_f *X = (lds_f *)(c.lds + GG::kBufX);
+  const lds_f *G = (const lds_f *)(c.lds + GG::kMiscG) + (n >> 2) * E;
+  const float *w = c.w;
+  const int c1_w = o[1], c1_b = o[2], n1_w = o[3], n1_b = o[4], c2_w = o[5], c2_b = o[6], n2_w = o[7], n2_b = o[8],
+            ss_w = o[9], ss_b = o[10];
+  // ---- every parameter of the block is requested up front (one L2 round trip for all of them)
+  f32x4 wss[4][2][2], wc1[4][2], wc2[4][2];
+  float bss[2][2], bc1[2], bc2[2], g1[2], b1[2], g2[2], b2[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int co = 2 * h + k;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      wss[kq][k][0] = *reinterpret_cast<const f32x4 *>(w + ss_w + (kq * 16 + co) * 4);      // scale row co
+      wss[kq][k][1] = *reinterpret_cast<const f32x4 *>(w + ss_w + (kq * 16 + 4 + co) * 4);  // shift row 4 + co
+      wc1[kq][k] = *reinterpret_cast<const f32x4 *>(w + c1_w + (kq * 16 + co) * 4);         // kq = input channel
+      wc2[kq][k] = *reinterpret_cast<const f32x4 *>(w + c2_w + (kq * 16 + co) * 4);
+    }
+    bss[k][0] = w[ss_b + co]; bss[k][1] = w[ss_b + 4 + co];
+    bc1[k] = w[c1_b + co]; bc2[k] = w[c2_b + co];
+    g1[k] = w[n1_w + co]; b1[k] = w[n1_b + co]; g2[k] = w[n2_w + co]; b2[k] = w[n2_b + co];
+  }
+  float x[4];
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci) x[ci] = X[swz<NC>(ci, n)];
+  // ---- scale / shift of my two channels: rows 2h + k (scale, the +1 is in the packed bias) and 4 + 2h + k (shift)
+  float sc[2], sh[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    sc[k] = bss[k][0];
+    sh[k] = bss[k][1];
+  }
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq) {
+    f32x4 gq = f32x4{0.f, 0.f, 0.f, 0.f};  // G[4 j + kq], j = 0..3 (E = 16: the whole embedding)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gq[j] = 4 * j + kq < E ? G[4 * j + kq] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc[k] += wss[kq][k][0][j] * gq[j];
+        sh[k] += wss[kq][k][1][j] * gq[j];
+      }
+  }
+  auto conv3 = [&](const float (&in)[4], const f32x4 (&wc)[4][2], const float (&bc)[2], float (&out)[2]) {
+    float lft[4], rgt[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const float a = dpp_mov<0x90>(in[ci]), b = dpp_mov<0xF9>(in[ci]);  // quad_perm [0,0,1,2] / [1,2,3,3]
+      lft[ci] = has_l ? a : 0.f;
+      rgt[ci] = has_r ? b : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float acc = bc[k];
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        acc += wc[ci][k].x * lft[ci];
+        acc += wc[ci][k].y * in[ci];
+        acc += wc[ci][k].z * rgt[ci];
+      }
+      out[k] = acc;
+    }
+  };
+  auto gn_act = [&](float (&v)[2], const float (&gw)[2], const float (&gb)[2], bool ss) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float m = group_sum<4>(v[k]) * 0.25f;
+      const float d = v[k] - m;
+      const float rs = __builtin_amdgcn_rsqf(group_sum<4>(d * d) * 0.25f + 1e-5f);
+      float y = d * rs * gw[k] + gb[k];
+      if (ss) y = y * sc[k] + sh[k];
+      v[k] = silu(y);
+    }
+  };
+  auto gather4 = [&](const float (&mine)[2], float (&all)[4]) {  // channels 0,1 live in half 0, channels 2,3 in half 1
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine[k]), __float_as_uint(mine[k]), false, false);
+      all[k] = __uint_as_float(r[0]);      // [lo, lo]: half 0's value in both halves
+      all[2 + k] = __uint_as_float(r[1]);  // [hi, hi]
+    }
+  };
+  float y[2], ya[4], z[2];
+  conv3(x, wc1, bc1, y);
+  gn_act(y, g1, b1, !(c.skip & 16));
+  gather4(y, ya);
+  conv3(ya, wc2, bc2, z);
+  gn_act(z, g2, b2, false);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) X[swz<NC>(2 * h + k, n)] = x[2 * h + k] + z[k];
+}
+
 
 // GroupNorm rides in the conv epilogue: the rows of a group must sit inside one wave's accumulators
 __host__ __device__ __forceinline__ bool gn_fusable(int C, int groups) {
@@ -843,7 +951,12 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
     o[8] = a8; o[9] = a9; o[10] = a10; o[11] = a11;
   };
   constexpr int X = GG::kBufX, H = GG::kBufH, Y = GG::kBufY, O = GG::kBufO, QKV = GG::kBufQKV;
-  auto resblock = [&](const gldm_r1d_resblock &rb, int C) {
+  auto resblock = [&](const gldm_r1d_resblock &rb, int C, bool last_of_pair) {
+    if (C == 4 && d.seq_len == 4 && NC == 32) {  // one-wave VALU form; the barrier comes after the second block
+      emit(OP_RES4, rb.c1_w, rb.c1_b, rb.n1_w, rb.n1_b, rb.c2_w, rb.c2_b, rb.n2_w, rb.n2_b, rb.ss_w, rb.ss_b,
+           last_of_pair ? 1 : 0);
+      return;
+    }
     emit(OP_CONV, rb.c1_w, rb.c1_b, X, H, C, C, 3 | (1 << 9), rb.n1_w, rb.n1_b, rb.ss_w, rb.ss_b);
     emit(OP_CONV, rb.c2_w, rb.c2_b, H, X, C, C, 3 | (2 << 9), rb.n2_w, rb.n2_b, -1, 0);  // X += act(GN(conv(H)))
   };
@@ -852,8 +965,8 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
   for (int lv = 0; lv < GLDM_R1D_MAX_LEVELS; ++lv) {
     if (lv < d.n_levels) {
       const int C = d.dims[lv], Cn = d.dims[lv + 1];
-      resblock(d.rb[2 * lv], C);
-      resblock(d.rb[2 * lv + 1], C);
+      resblock(d.rb[2 * lv], C, false);
+      resblock(d.rb[2 * lv + 1], C, true);
       const gldm_r1d_level &v = d.lv[lv];
       emit(OP_LN, X, Y, -1, C, v.ln_g);
       emit(OP_CONV, v.qkv_w[0], -1, Y, QKV, C, 192, 1);
@@ -867,7 +980,7 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
   }
 #pragma unroll
   for (int lv = 1; lv <= GLDM_R1D_MAX_LEVELS; ++lv)
-    if (lv == d.n_levels) resblock(d.rb[2 * lv], d.dims[lv]);
+    if (lv == d.n_levels) resblock(d.rb[2 * lv], d.dims[lv], true);
   return n;
 }
 
@@ -899,6 +1012,10 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
         conv_gemm<NC, L>(c, o[1], o[2], c.lds + o[3], o[5], o[7] & 255, c.lds + o[4], o[6], (o[7] & kFlagAlias) != 0, 0, g);
         break;
       }
+      case OP_RES4:
+        if (!(c.skip & 8)) resblock4_valu<NC>(c, o, E);
+        if (o[11]) __syncthreads();
+        break;
       case OP_LN:
         layer_norm_pass<NC>(c, c.lds + o[1], o[2] >= 0 ? c.lds + o[2] : nullptr, o[3] >= 0 ? c.lds + o[3] : nullptr,
                             o[4], o[5]);
@@ -1263,7 +1380,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   const int rc = L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s);
   if (stamp) {
     static long long host[kMaxOps + 2];
-    static const char *names[] = {"", "CONV", "", "LN", "ATT"};
+    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT"};
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(host, dstamps, sizeof(host), hipMemcpyDeviceToHost);
     // the tape is rebuilt on the host only to label the stamps
@@ -1274,7 +1391,10 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
       printf("op %3d %-4s C=%3d cout=%3d k=%d : %7lld clk\n", op, names[type], C, cout, taps, host[op + 1] - host[op]);
       ++op;
     };
-    auto resblock = [&](int C) { line(1, C, C, 3); line(1, C, C, 3); };
+    auto resblock = [&](int C) {
+      if (C == 4 && a.d.seq_len == 4) line(2, C, C, 3);
+      else { line(1, C, C, 3); line(1, C, C, 3); }
+    };
     for (int lv = 0; lv < a.d.n_levels; ++lv) {
       const int C = dims[lv];
       resblock(C); resblock(C);
