@@ -691,7 +691,46 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
   const int qrow0 = hl * kDimHead, krow0 = 64 + hl * kDimHead, vrow0 = 128 + hl * kDimHead;
   const lds_f *q3 = (const lds_f *)qkv;
   lds_f *o3 = (lds_f *)o_rows;
-  if constexpr (L == 4) {
+  if constexpr (L == 4 && NC == 32 && GG::kWaves == 4) {
+    // wave = (head of the pair, 16-column half); lane = (column, part): 8 of the head's 32 channels.  The softmax
+    // statistics and the 4 x 4 matrix A = softmax_n(k)^T softmax_d(q) combine over the parts with permlane swaps
+    // inside the wave: no LDS exchange and no barrier but the final one.
+    const int h2 = c.wave >> 1, nn = 16 * (c.wave & 1) + (c.lane & 15), pt = c.lane >> 4, d0 = 8 * pt, sb = nn & ~3;
+    const int qr = h2 * kDimHead + d0, kr = 64 + h2 * kDimHead + d0, vr = 128 + h2 * kDimHead + d0;
+    float q[8];
+    float qmax = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      q[i] = q3[swz<NC>(qr + i, nn)];
+      qmax = fmaxf(qmax, q[i]);
+    }
+    f32x4 kv[8], vv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kv[i] = *(const lds_f4 *)(q3 + swz<NC>(kr + i, sb));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vv[i] = *(const lds_f4 *)(q3 + swz<NC>(vr + i, sb));
+    qmax = half_max(row_pair_max(qmax));
+    float qsum = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float e = fast_exp(q[i] - qmax);
+      qsum += e;
+      const float km = fmaxf(fmaxf(kv[i].x, kv[i].y), fmaxf(kv[i].z, kv[i].w));
+      const float k0 = fast_exp(kv[i].x - km), k1 = fast_exp(kv[i].y - km), k2 = fast_exp(kv[i].z - km),
+                  k3 = fast_exp(kv[i].w - km);
+      const float f = e * __builtin_amdgcn_rcpf(k0 + k1 + k2 + k3);
+      a0 += k0 * f; a1 += k1 * f; a2 += k2 * f; a3 += k3 * f;
+    }
+    qsum = half_sum(row_pair_sum(qsum));
+    a0 = half_sum(row_pair_sum(a0)); a1 = half_sum(row_pair_sum(a1));
+    a2 = half_sum(row_pair_sum(a2)); a3 = half_sum(row_pair_sum(a3));
+    const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(qsum);  // dim_head ** -0.5 / sum
+    a0 *= sc; a1 *= sc; a2 *= sc; a3 *= sc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      o3[swz<NC>(h2 * kDimHead + d0 + i, nn)] = vv[i].x * a0 + vv[i].y * a1 + vv[i].z * a2 + vv[i].w * a3;
+    __syncthreads();
+  } else if constexpr (L == 4) {
     // softmax statistics and the 4x4 matrix A = softmax_n(k)^T softmax_d(q) are combined over
     // the parts by a lane swap (row slots) and one exchange through LDS (waves)
     float *red1 = c.lds + GG::kMiscRed1, *red2 = c.lds + GG::kMiscRed2;
