@@ -151,7 +151,7 @@ def main():
         # memory-side bytes of one launch from the committed PMC passes (tools/pmc_denoise.sh: FETCH_SIZE, doubled
         # per the gfx950 16-B/lane rule, + WRITE_SIZE); only quoted for the workload they were collected on
         traffic = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_denoise_pmc.json")
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01f_denoise_pmc.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             if pmc.get("n_latents") == B * G and pmc.get("steps") == S:
