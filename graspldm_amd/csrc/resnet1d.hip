@@ -247,6 +247,81 @@ __device__ __forceinline__ void gemm_fast_pf(const Ctx &c, const float *__restri
   }
 }
 
+// k = 3 convs, tap-major: inside a 16-channel block the three taps are swept one after the other
+// (4 k-steps each), and the moment a tap's sweep has issued its MFMAs its fragment registers are
+// refilled with the NEXT block's fragments of that tap.  Every weight load then has exactly one
+// block of MFMAs (48 at 2 x 2 tiles) to arrive, with ONE set of fragment registers and never more
+// than a block's worth of loads in flight per wave: the double-buffered form kept up to two, and
+// a long weight stream queued in the CU's vector-memory path is what delays the co-resident
+// workgroup's short phases.
+template <int NC, int L, int MT, int NT>
+__device__ __forceinline__ void gemm_fast_tap3(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0, int nt0,
+                                               const float *src, f32x4 (&acc)[MT][NT]) {
+  const int col = c.lane & 15, kq = c.lane >> 4;
+  const int kblocks = 3 * cblocks;
+  gf4p wv = (gf4p)(reinterpret_cast<const f32x4 *>(wp) + c.lane);
+  int boff[4][NT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) boff[j][ni] = swz<NC>(4 * j + kq, 16 * (nt0 + ni) + col);
+  f32x4 a[3][MT];
+  float b[2][4][NT];
+  f32x4 side[2][MT][NT];  // tap 0 and tap 2 partial results (tap 1 goes to acc)
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) side[t][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const lds_f *src3 = (const lds_f *)src;
+  auto load_b = [&](int buf, int cb) {
+    const lds_f *s = src3 + cb * 16 * NC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) b[buf][j][ni] = s[boff[j][ni]];
+  };
+  const int last = cblocks - 1;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) a[t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks) * 64];
+  load_b(0, 0);
+  for (int cb0 = 0; cb0 < cblocks; cb0 += 2) {  // two blocks per trip: the B double buffer alternates statically
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int cb = cb0 + u;
+      const int nb = cb + 1 < last ? cb + 1 : last;  // clamped: the loads stay unconditional
+      load_b(1 - u, nb);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+              f32x4 &d = t == 1 ? acc[mi][ni] : side[t >> 1][mi][ni];
+              d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][mi][j], b[u][j][ni], d, 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) a[t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks + nb) * 64];
+      }
+    }
+  }
+  const bool keepL = (col & (L - 1)) != 0, keepR = (col & (L - 1)) != (L - 1);
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[mi][ni][r] += tap_left<L>(side[0][mi][ni][r], keepL) + tap_right<L>(side[1][mi][ni][r], keepR);
+}
+
 template <int NC, int L, int TAPS, int MT, int NT>
 __device__ __forceinline__ void gemm_fast(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0, int nt0,
                                           const float *src, f32x4 (&acc)[MT][NT]) {
@@ -254,6 +329,12 @@ __device__ __forceinline__ void gemm_fast(const Ctx &c, const float *__restrict_
 #define GLDM_PFMAX6 2
 #endif
   constexpr int PFMAX = (MT * TAPS > 6) ? 2 : (MT * TAPS > 4 ? GLDM_PFMAX6 : 4);  // register budget
+  if constexpr (TAPS == 3) {
+    if ((cblocks & 1) == 0) {
+      gemm_fast_tap3<NC, L, MT, NT>(c, wp, cblocks, mt0, nt0, src, acc);
+      return;
+    }
+  }
   if (PFMAX == 4 && (cblocks & 3) == 0) gemm_fast_pf<NC, L, TAPS, MT, NT, PFMAX>(c, wp, cblocks, mt0, nt0, src, acc);
   else if ((cblocks & 1) == 0) gemm_fast_pf<NC, L, TAPS, MT, NT, 2>(c, wp, cblocks, mt0, nt0, src, acc);
   else gemm_fast_pf<NC, L, TAPS, MT, NT, 1>(c, wp, cblocks, mt0, nt0, src, acc);
