@@ -20,6 +20,8 @@ Fixtures hold inputs and expected outputs only (data, no reference source).
   schema_*.json            state-dict key -> (shape, dtype) of the reference modules
   G8 sa_module.npz         PointNetSAModule on one cloud (SSG SA1/SA2 shapes)
      pointnet2_ssg.npz     PointNet2SSG forward on one cloud (every 8th point kept)
+     pvcnn2.npz            PVCNN2 forward on one cloud (every 16th point kept); `python -m oracle.make_golden pvcnn2`
+                           writes only this one
 """
 import os
 import sys
@@ -165,8 +167,28 @@ def main():
     synthetic.load_synthetic_weights(ssg, seed=3)
     _schema("schema_pointnet2_ssg.json", ssg)
     _save("pointnet2_ssg.npz", coords=cloud, out=ssg(cloud)[:, :, ::8])
+    pvcnn2_golden(cloud)
     print("golden fixtures written to", OUT)
 
 
+@torch.no_grad()
+def pvcnn2_golden(cloud=None):
+    """G8: PVCNN2 (set abstraction + PVConv + feature propagation, pvcnn_base.py:147-279) on one cloud."""
+    from grasp_ldm.models.modules.ext.pvcnn.pvcnn_base import PVCNN2
+    if cloud is None:
+        pcs, _ = synthetic.synthetic_batch(2, 1024)
+        cloud = pcs[:1].transpose(1, 2).contiguous() * 0.05 / 0.12
+    net = PVCNN2().eval()
+    synthetic.load_synthetic_weights(net, seed=4)
+    _schema("schema_pvcnn2.json", net)
+    _save("pvcnn2.npz", coords=cloud, out=net(cloud)[:, :, ::16])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pvcnn2":  # add this one fixture without rewriting the others
+        os.makedirs(OUT, exist_ok=True)
+        torch.set_num_threads(8)
+        ref_import.install_shims()
+        pvcnn2_golden()
+    else:
+        main()

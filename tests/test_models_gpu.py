@@ -126,6 +126,20 @@ def test_g8_pointnet2_ssg_golden():
     assert _err(out[:, :, ::8], g["out"]) < 1e-4
 
 
+def test_g8_pvcnn2_golden():
+    """PVCNN2 (SA with PVConv voxel branches + feature propagation, pvcnn_base.py:147-279) against the output of the
+    reference's own Python graph (oracle/make_golden.py, CPU backend shim)."""
+    from graspldm_amd.pvcnn import PVCNN2
+    from graspldm_amd.synthetic import synthetic_state_dict
+    g = load_golden("pvcnn2.npz")
+    m = PVCNN2()
+    m.load_state_dict(synthetic_state_dict(load_schema("schema_pvcnn2.json"), seed=4), strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        out = m(g["coords"].cuda())
+    assert out.shape[1] == 64 and _err(out[:, :, ::16], g["out"]) < 1e-4, _err(out[:, :, ::16], g["out"])
+
+
 def test_tmrp_to_H_module(ldm):
     from graspldm_amd.rotations import tmrp_to_H
     g = load_golden("tmrp_to_H.npz")
