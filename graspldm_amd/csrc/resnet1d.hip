@@ -25,8 +25,11 @@
 //   few 16-channel blocks ahead; B operands are unconditional, batched LDS reads.  k = 3 convs
 //   keep one accumulator set per tap on UNSHIFTED columns and apply the halo shift once to the
 //   result tiles (lane shifts inside the 16-lane rows of the C/D layout), so the k-loop is
-//   loads + MFMA only.  GroupNorm / LayerNorm / softmax run with lane = (row slot, column):
-//   rows are read conflict-free and statistics reduce by wave shuffles.
+//   loads + MFMA only (tap-major: a tap's fragment registers are refilled right after its sweep).
+//   GroupNorm, the time/condition scale-shift, SiLU and the residual add live in the conv epilogue
+//   (statistics over the wave's own accumulators); LayerNorm / softmax run with lane = (row slot,
+//   column) and reduce with DPP / permlane swaps.  The step is a tape of ~48 ops in LDS, interpreted
+//   by a switch with every phase inlined (see run_tape).
 //   LinearAttention at n = L is reassociated:  out = V (K^T Q)  (an L x L matrix per sample
 //   and head) instead of (V K^T) Q: 8x fewer FLOPs, same math.
 #include <hip/hip_runtime.h>

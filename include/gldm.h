@@ -147,8 +147,8 @@ typedef struct gldm_r1d_desc {
   int32_t cond_rows;    /* R: rows of the conditioning latent (3), 1 if 2-D       */
   int32_t groups;       /* GroupNorm groups (resnet_block_groups)                 */
   int32_t init_w, init_b; /* init_conv [C0][7], [C0]                              */
-  int32_t ss_rows;      /* 2 * max(dims): rows of the per-workgroup scale/shift
-                           scratch                                                */
+  int32_t ss_rows;      /* 2 * max(dims) (unused since ABI 2: the scale/shift rows are
+                           computed in the conv epilogue; kept for layout)        */
   gldm_r1d_resblock rb[GLDM_R1D_MAX_RESBLOCKS]; /* 2 per level, then final        */
   gldm_r1d_level lv[GLDM_R1D_MAX_LEVELS];
   int32_t final_w, final_b; /* final_conv [dims[n_levels]], [1]                   */
@@ -172,7 +172,9 @@ enum gldm_sched_kind { GLDM_SCHED_NONE = 0, GLDM_SCHED_DDIM = 1, GLDM_SCHED_DDPM
 int gldm_r1d_cond_embed(const float *z_cond /*[n_cond,R,Dc]*/, const float *w /*[E,Dc]*/, const float *b /*[E]*/,
                         int n_cond, int rows, int dc, int e, float *cemb /*[n_cond,R,E]*/, gldm_stream_t stream);
 
-/* Bytes of scratch gldm_denoise / gldm_decode need for n_samples. */
+/* Bytes of scratch gldm_denoise / gldm_decode need for n_samples (a token amount today: a step
+ * stays on chip; -1 if the descriptor is not supported: groups must be 4, widths powers of two
+ * in {4, 16, 32, 64, 128, 256}, at most 128 on levels with attention, emb_dim % 16 == 0). */
 long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples);
 
 /* ref: grasp_ldm/models/diffusion/gaussian_diffusion.py:232-277 (sample loop:
