@@ -29,6 +29,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP
 PEAK_HBM_GBS = 8000.0          # HBM3E peak, spec
 DENOISER_FLOP_PER_LATENT_STEP = 7_589_120   # SURVEY.md Appendix B (matches torch flop counter)
 DECODER_FLOP_PER_GRASP = 30.7e6
+CPU_BASELINE_CLOUDS = 128                   # bounded sample of the same workload for the CPU leg
 ENCODER_FLOP_PER_CLOUD = 8.115e9            # the reference graph (shipped fpc config, N = 1024)
 # executed: conv_downscale (1536 -> 768) and out_layer[0] (768 -> 3) are folded into one 1536 -> 3 GEMM
 ENCODER_FLOP_EXECUTED_PER_CLOUD = 8.115e9 - 2 * 768 * 1536 * 1024 - 2 * 3 * 768 * 1024 + 2 * 3 * 1536 * 1024
@@ -219,17 +220,17 @@ def main():
         # ---- CPU baseline: the torch-CPU oracle on this box's host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            # separate CPU-only process (bounded: 32 clouds x G grasps, full S steps, <= 16 threads:
+            # separate CPU-only process (bounded: 128 clouds x G grasps, full S steps = ~15 s, <= 16 threads:
             # the oracle's ~110 small ops per step do not scale past a few cores)
             import subprocess
             threads = min(os.cpu_count() or 1, 16)
-            cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--clouds", "32", "--grasps", str(G), "--points", str(N),
+            cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--clouds", str(CPU_BASELINE_CLOUDS), "--grasps", str(G), "--points", str(N),
                    "--ddim-steps", str(S), "--threads", str(threads)]
             try:
                 r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
                 rec = json.loads(r.stdout.strip().splitlines()[-1])
                 cpu = dict(value=rec["grasps"] / rec["seconds"], unit="grasps/s", cores=rec["threads"], kind="port",
-                           sample=f"32 clouds x {G} grasps, N={N}, {S} DDIM steps, torch-CPU oracle "
+                           sample=f"{CPU_BASELINE_CLOUDS} clouds x {G} grasps, N={N}, {S} DDIM steps, torch-CPU oracle "
                                   f"(oracle/torch_ref.py + oracle/point_ops.c), {rec['seconds']:.1f} s of "
                                   f"{os.cpu_count()} host cores' box")
             except Exception as e:  # noqa: BLE001
@@ -241,7 +242,7 @@ def main():
                                         "(BASELINE.json configs[2]; configs[3] at 8 GPUs)",
                                clouds_per_gpu=B, grasps_per_cloud=G, points=N, ddim_steps=S,
                                encoder="PVCNNEncoder (shipped fpc config)", parallelism=f"cloud-sharded x{world}",
-                               weights="synthetic recipe seed 0"),
+                               weights="synthetic recipe seed 0", streams=args.streams),
                    roofline=roof, cpu_baseline=cpu, kernels=kernels)
     if world > 1:
         dist.barrier()
