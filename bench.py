@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--clouds-per-gpu", type=int, default=256)
     ap.add_argument("--grasps", type=int, default=20)
     ap.add_argument("--points", type=int, default=1024)
-    ap.add_argument("--ddim-steps", type=int, default=100)
+    ap.add_argument("--ddim-steps", type=int, default=100, help="inference steps (DDIM, or DDPM with --scheduler ddpm)")
+    ap.add_argument("--scheduler", choices=["ddim", "ddpm"], default="ddim",
+                    help="ddpm with --ddim-steps 1000 --points 4096 --grasps 200 is BASELINE.json configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps alternate over (2: batch k+1's encoder overlaps batch k's denoise tail)")
@@ -82,7 +84,7 @@ def main():
     from graspldm_amd.synthetic import synthetic_batch
 
     B, G, N, S = args.clouds_per_gpu, args.grasps, args.points, args.ddim_steps
-    ldm = build_fpc_ldm(n_points=N, scheduler="ddim", device=dev)
+    ldm = build_fpc_ldm(n_points=N, scheduler=args.scheduler, device=dev)
     ldm.set_inference_timesteps(S)
     uniq = min(B, 32)   # 32 distinct synthetic objects per rank, tiled to B (resident in HBM)
     pcs_u, metas_u = synthetic_batch(uniq, N, first_index=rank * uniq)
@@ -152,8 +154,10 @@ def main():
         z = ldm.vae_model.encode_pc(pcs)
         cemb = eng.cond_embed(z)
         ts, coef = ldm.diffusion_model._schedule(dev)
-        from graspldm_amd.r1d_pack import SCHED_DDIM
-        dn = lambda: eng.denoise(x_T, cemb, G, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
+        from graspldm_amd.r1d_pack import SCHED_DDIM, SCHED_DDPM
+        kind = SCHED_DDIM if args.scheduler == "ddim" else SCHED_DDPM
+        noise = torch.randn((ts.numel(), B * G, 1, 4), device=dev) if kind == SCHED_DDPM else None
+        dn = lambda: eng.denoise(x_T, cemb, G, timesteps=ts, sched_kind=kind, coef=coef, step_noise=noise)
         dn()
         t_den = event_time(dn, 3)
         flop = B * G * S * DENOISER_FLOP_PER_LATENT_STEP
@@ -165,7 +169,7 @@ def main():
             pmc = json.load(open(pmc_path))
             if pmc.get("n_latents") == B * G and pmc.get("steps") == S:
                 traffic = pmc["fetch_bytes_corrected"] + pmc["write_bytes"]
-        roof = dict(kernel="r1d_kernel<32, 4> (gldm_denoise: %d DDIM steps fused)" % S, bound="mfma",
+        roof = dict(kernel="r1d_kernel<32, 4> (gldm_denoise: %d %s steps fused)" % (S, args.scheduler.upper()), bound="mfma",
                     achieved=flop / t_den / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=flop / t_den / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
                     algorithmic_flop_per_launch=flop, avg_launch_ms=t_den * 1e3,
@@ -177,8 +181,9 @@ def main():
         lat = dn().squeeze(-2)
         t_dec = event_time(lambda: dec(lat, z, samples_per_cond=G), 3)
         kernels = [dict(kernel="PVCNNEncoder.forward (all launches)", bound="mfma", avg_ms=t_enc * 1e3,
-                        achieved=B * ENCODER_FLOP_EXECUTED_PER_CLOUD / t_enc / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=B * ENCODER_FLOP_EXECUTED_PER_CLOUD / t_enc / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        achieved=(B * ENCODER_FLOP_EXECUTED_PER_CLOUD / t_enc / 1e12) if N == 1024 else None,
+                        peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=(B * ENCODER_FLOP_EXECUTED_PER_CLOUD / t_enc / 1e12 / PEAK_F32_MFMA_TFLOPS) if N == 1024 else None,
                         note="executed FLOP (head convs folded); the reference graph has %.3f GFLOP per cloud"
                              % (ENCODER_FLOP_PER_CLOUD / 1e9)),
                    dict(kernel="r1d_kernel<32, 16> (gldm_decode)", bound="mfma", avg_ms=t_dec * 1e3,
@@ -219,7 +224,7 @@ def main():
                             hbm_bytes_avoided=B * 4 * (Cs + 3) * Ms * Us))
         # ---- CPU baseline: the torch-CPU oracle on this box's host cores, bounded sample
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.scheduler == "ddim":
             # separate CPU-only process (bounded: 128 clouds x G grasps, full S steps = ~15 s, <= 16 threads:
             # the oracle's ~110 small ops per step do not scale past a few cores)
             import subprocess
@@ -235,10 +240,10 @@ def main():
                                   f"{os.cpu_count()} host cores' box")
             except Exception as e:  # noqa: BLE001
                 cpu = dict(value=None, unit="grasps/s", cores=threads, kind="port", sample=f"failed: {e!r}"[:200])
-        out = dict(metric="grasps/sec whole-node (1024-pt cloud, 100 DDIM steps)", value=grasps_per_s,
+        out = dict(metric="grasps/sec whole-node (%d-pt cloud, %d %s steps)" % (N, S, args.scheduler.upper()), value=grasps_per_s,
                    unit="grasps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=f"LDM mode, {B} synthetic {N}-pt clouds per GPU x {G} grasps, {S} DDIM steps "
+                   config=dict(workload=f"LDM mode, {B} synthetic {N}-pt clouds per GPU x {G} grasps, {S} {args.scheduler.upper()} steps "
                                         "(BASELINE.json configs[2]; configs[3] at 8 GPUs)",
                                clouds_per_gpu=B, grasps_per_cloud=G, points=N, ddim_steps=S,
                                encoder="PVCNNEncoder (shipped fpc config)", parallelism=f"cloud-sharded x{world}",
