@@ -9,7 +9,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libgldm_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GldmError(RuntimeError):
@@ -34,7 +34,7 @@ _SIGNATURES = {
     "gldm_r1d_cond_embed": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "gldm_denoise": [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gldm_decode": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
-    "gldm_pose_epilogue": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "gldm_pose_epilogue": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gldm_conv3d_k3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_groupnorm_swish": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "gldm_se_gate": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],

@@ -548,7 +548,7 @@ int ilog2_ceil(int v) {
 
 // =========================================================== C ABI =========
 
-GLDM_API int gldm_abi_version(void) { return 2; }
+GLDM_API int gldm_abi_version(void) { return 3; }
 
 GLDM_API const char *gldm_status_string(int status) {
   switch (status) {
@@ -679,10 +679,12 @@ GLDM_API int gldm_sa_group(const float *points, const float *centers, const floa
   // 16 centres per block: every thread owns one 16-byte slot of each channel row's 4 KiB run
   // (u = 64); measured best of {4, 8, 16, 32} on MI355X (tools/bench_point_ops.py).
   int cpb = 16;
+#ifdef GLDM_DEBUG_KNOBS
   {
-    const char *e = getenv("GLDM_SA_CPB");  // tuning knob (diagnostic)
+    const char *e = getenv("GLDM_SA_CPB");  // tuning knob (diagnostic builds only)
     if (e) cpb = atoi(e);
   }
+#endif
   while (cpb > 1 && (size_t)cpb * u * sizeof(int32_t) > 32 * 1024) cpb >>= 1;
   const size_t fixed = (size_t)cpb * u * sizeof(int32_t) + (size_t)3 * cpb * sizeof(float);
   dim3 grid(ceil_div(m, cpb), b);

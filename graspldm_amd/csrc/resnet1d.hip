@@ -41,6 +41,16 @@
 
 #define GLDM_API extern "C" __attribute__((visibility("default")))
 
+// Diagnostic knobs (phase skipping, per-op cycle stamps, workgroup stagger) exist only in builds made
+// with -DGLDM_DEBUG_KNOBS (make EXTRA=-DGLDM_DEBUG_KNOBS); the shipped kernels contain none of them.
+#ifdef GLDM_DEBUG_KNOBS
+#define GLDM_SKIP(c, bit) ((c).skip & (bit))
+#define GLDM_STAMPS(p) (p)
+#else
+#define GLDM_SKIP(c, bit) false
+#define GLDM_STAMPS(p) ((long long *)nullptr)
+#endif
+
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -647,7 +657,7 @@ template <int NC, int L>
 __device__ __forceinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, const float *src, int cin, int ktaps,
                                           float *dst, int cout, bool alias, int act = 0,
                                           const GnEpilogue &g = GnEpilogue{0, 0, 0, -1, 0, 0, 0, 0, nullptr}) {
-  if (c.skip & 8) return;
+  if (GLDM_SKIP(c, 8)) return;
   const float *wp = c.w + w_off;
   const float *bias = b_off >= 0 ? c.w + b_off : nullptr;
   const int mtiles = (cout + 15) >> 4;
@@ -751,7 +761,7 @@ __device__ __forceinline__ void layer_norm_rows(const Ctx &c, const float *src, 
 
 template <int NC>
 __device__ __forceinline__ void layer_norm_pass(const Ctx &c, const float *src, float *dst, float *res, int C, int g_off) {
-  if (c.skip & 2) return;
+  if (GLDM_SKIP(c, 2)) return;
   C = __builtin_amdgcn_readfirstlane(C);
   const int it = (C + Geo<NC>::kSlots - 1) / Geo<NC>::kSlots;
   if (it <= 1) layer_norm_rows<NC, 1>(c, src, dst, res, C, g_off);
@@ -766,7 +776,7 @@ __device__ __forceinline__ void layer_norm_pass(const Ctx &c, const float *src, 
 // The 32 channels of a head are split in 4 parts of 8 over (waves of the head) x (row slots).
 template <int NC, int L>
 __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *o_rows) {
-  if (c.skip & 4) return;
+  if (GLDM_SKIP(c, 4)) return;
   using GG = Geo<NC>;
   constexpr int WPH = GG::kWaves / 2;       // waves per head
   const int n = c.lane & (NC - 1), sub = c.lane / NC, sbase = n & ~(L - 1);
@@ -1047,7 +1057,7 @@ __device__ __forceinline__ void resblock4_valu(const Ctx &c, const int (&o)[kOpI
   };
   float y[2], ya[4], z[2];
   conv3(x, wc1, bc1, y);
-  gn_act(y, g1, b1, !(c.skip & 16));
+  gn_act(y, g1, b1, !GLDM_SKIP(c, 16));
   gather4(y, ya);
   conv3(ya, wc2, bc2, z);
   gn_act(z, g2, b2, false);
@@ -1130,13 +1140,13 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
     else __builtin_amdgcn_s_setprio(3);
     switch (o[0]) {
       case OP_CONV: {
-        const int mode = (c.skip & 1) ? 0 : (o[7] >> 9) & 3;
-        const GnEpilogue g{mode, o[8], o[9], (c.skip & 16) ? -1 : o[10], o[11], E, o[6], o[6] / 4, c.lds + o[4]};
+        const int mode = GLDM_SKIP(c, 1) ? 0 : (o[7] >> 9) & 3;
+        const GnEpilogue g{mode, o[8], o[9], GLDM_SKIP(c, 16) ? -1 : o[10], o[11], E, o[6], o[6] / 4, c.lds + o[4]};
         conv_gemm<NC, L>(c, o[1], o[2], c.lds + o[3], o[5], o[7] & 255, c.lds + o[4], o[6], (o[7] & kFlagAlias) != 0, 0, g);
         break;
       }
       case OP_RES4:
-        if (!(c.skip & 8)) resblock4_valu<NC>(c, o, E);
+        if (!GLDM_SKIP(c, 8)) resblock4_valu<NC>(c, o, E);
         if (o[11]) __syncthreads();
         break;
       case OP_LN:
@@ -1202,10 +1212,12 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   if (c.tid == 0) tape[1023] = build_tape<NC>(d, tape);
   __syncthreads();
   const int n_ops = __builtin_amdgcn_readfirstlane(tape[1023]);
+#ifdef GLDM_DEBUG_KNOBS
   if (a.stagger_ticks > 0 && ((blockIdx.x / a.n_cus) & 1)) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < a.stagger_ticks) __builtin_amdgcn_s_sleep(32);
   }
+#endif
   // ---- latent row for this tile
   if (c.tid < NC) {
     const int s = c.tid / L, l = c.tid % L;
@@ -1223,9 +1235,9 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   __syncthreads();
 
   for (int step = 0; step < a.n_steps; ++step) {
-    if (a.stamps && blockIdx.x == 0 && c.tid == 0) a.stamps[kMaxOps + 1] = (long long)__builtin_readcyclecounter();
+    if (GLDM_STAMPS(a.stamps) && blockIdx.x == 0 && c.tid == 0) a.stamps[kMaxOps + 1] = (long long)__builtin_readcyclecounter();
     // ---- G[s][e] = sum_r silu(temb[t][e] + cemb[cond][r][e])
-    if (!(c.skip & 32))
+    if (!GLDM_SKIP(c, 32))
     for (int i = c.tid; i < S * E; i += GG::kThreads) {
       const int s = i / E, e = i - s * E;
       const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
@@ -1241,7 +1253,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     }
     // ---- init conv (k = 7, one input channel); the barrier below also publishes G
     const int C0 = d.dims[0];
-    if (!(c.skip & 64))
+    if (!GLDM_SKIP(c, 64))
     for (int i = c.tid; i < C0 * NC; i += GG::kThreads) {
       const int ch = i / NC, n = i - ch * NC;
       const int l = n & (L - 1), base = n - l;
@@ -1256,11 +1268,11 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     }
     __syncthreads();
 
-    run_tape<NC, L>(c, tape, n_ops, E, blockIdx.x == 0 ? a.stamps : nullptr);
-    if (a.stamps && blockIdx.x == 0 && c.tid == 0) a.stamps[n_ops] = (long long)__builtin_readcyclecounter();
+    run_tape<NC, L>(c, tape, n_ops, E, blockIdx.x == 0 ? GLDM_STAMPS(a.stamps) : nullptr);
+    if (GLDM_STAMPS(a.stamps) && blockIdx.x == 0 && c.tid == 0) a.stamps[n_ops] = (long long)__builtin_readcyclecounter();
 
     // ---- final 1x1 conv to one channel: eps[n] = b + sum_c w[c] X[c][n]
-    if (!(c.skip & 128)) {
+    if (!GLDM_SKIP(c, 128)) {
       float *red1 = lds + GG::kMiscRed1;
       const int n = c.lane & (NC - 1), slot = c.wave * GG::kRP + c.lane / NC;
       float part = 0.f;
@@ -1489,14 +1501,20 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   const int tiles = tl.full_tiles + tl.tail_tiles;
   RunArgs a = a_in;
   a.full_tiles = tl.full_tiles; a.tail_tiles = tl.tail_tiles; a.tail_samples = tl.tail_samples;
+  a.n_cus = cu_count();
+#ifdef GLDM_DEBUG_KNOBS
+  // diagnostic builds only (make EXTRA=-DGLDM_DEBUG_KNOBS): phase skipping, a start offset for the
+  // second workgroup of a CU, and per-op cycle stamps.  The shipped library reads no environment.
   {
     const char *e = getenv("GLDM_R1D_SKIP");
     a.skip = e ? atoi(e) : 0;
     const char *g = getenv("GLDM_R1D_STAGGER_US");
     a.stagger_ticks = g ? atoi(g) * 100 : 0;
-    a.n_cus = cu_count();
   }
-  const bool stamp = getenv("GLDM_R1D_STAMP") != nullptr;  // diagnostic: blocks, copies and prints
+  const bool stamp = getenv("GLDM_R1D_STAMP") != nullptr;  // blocks, copies and prints
+#else
+  const bool stamp = false;
+#endif
   static long long *dstamps = nullptr;
   if (stamp && !dstamps) (void)hipMalloc(&dstamps, (kMaxOps + 2) * sizeof(long long));
   a.stamps = stamp ? dstamps : nullptr;
@@ -1586,10 +1604,12 @@ GLDM_API int gldm_decode(const gldm_r1d_desc *desc, const float *weights, const 
 }
 
 GLDM_API int gldm_pose_epilogue(const float *tmrp, const float *logit, const float *grasp_mean,
-                                const float *grasp_std, int n, int grasps_per_cloud, float *H, float *tmrp_unnorm,
-                                float *confidence, gldm_stream_t stream) {
-  if (!tmrp || !grasp_mean || !grasp_std || !H || !tmrp_unnorm || n <= 0 || grasps_per_cloud <= 0)
+                                const float *grasp_std, int n, int grasps_per_cloud, int n_clouds, float *H,
+                                float *tmrp_unnorm, float *confidence, gldm_stream_t stream) {
+  if (!tmrp || !grasp_mean || !grasp_std || !H || !tmrp_unnorm || n <= 0 || grasps_per_cloud <= 0 || n_clouds <= 0)
     return GLDM_ERR_INVALID_ARG;
+  // every grasp's cloud row (i / grasps_per_cloud) must exist in mean/std [n_clouds, 6]
+  if ((long long)n_clouds * grasps_per_cloud < (long long)n) return GLDM_ERR_INVALID_ARG;
   if (confidence && !logit) return GLDM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(pose_epilogue_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      tmrp, logit, grasp_mean, grasp_std, n, grasps_per_cloud, H, tmrp_unnorm, confidence);

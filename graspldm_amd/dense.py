@@ -59,23 +59,22 @@ def pointwise_conv(x, conv):
     return _gemm_bias_act(x.float(), conv.weight.reshape(conv.weight.shape[0], -1), conv.bias, False)
 
 
-_FOLDED = {}
-
-
 def pointwise_conv_bn_relu(x, conv, bn):
     """relu(BN_eval(conv(x))) with BN folded into the weights: y = relu(W' x + b').  The folded pair is
     computed once per (weights, statistics) version, not per call."""
     _need_cuda(x)
-    key = (conv.weight.data_ptr(), conv.weight._version, bn.weight._version, bn.bias._version,
-           bn.running_mean._version, bn.running_var._version, str(x.device))
-    hit = _FOLDED.get(id(conv))
+    from ._cache import params_key, publish
+    src = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv.bias] if conv.bias is not None else [])
+    key = params_key(src, x.device)
+    hit = conv.__dict__.get("_gldm_folded")  # lives and dies with the module
     if hit is None or hit[0] != key:
         s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
         w = (conv.weight.reshape(conv.weight.shape[0], -1) * s.view(-1, 1)).contiguous()
         cb = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
         b = ((cb - bn.running_mean) * s + bn.bias).contiguous()
         hit = (key, w, b)
-        _FOLDED[id(conv)] = hit
+        conv.__dict__["_gldm_folded"] = hit
+        publish(x.device)
     return _gemm_bias_act(x.float(), hit[1], hit[2], True)
 
 

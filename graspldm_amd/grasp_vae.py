@@ -37,7 +37,8 @@ class ConditionalGraspPoseDecoder(nn.Module):
         self._engine, self._key = None, None
 
     def _get_engine(self, device, rows):
-        key = (str(device), rows) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        from ._cache import params_key, publish
+        key = params_key(self.parameters(), device, rows)
         if self._engine is None or self._key != key:
             from .r1d import R1dEngine, pack_resnet1d
             sd = {k: v.detach().float().cpu() for k, v in self.state_dict().items()}
@@ -47,6 +48,7 @@ class ConditionalGraspPoseDecoder(nn.Module):
                                        tmrp_w=sd["tmrp.weight"], tmrp_b=sd["tmrp.bias"],
                                        cls_w=sd["class_logits.weight"], cls_b=sd["class_logits.bias"]))
             self._engine, self._key = R1dEngine(packed, device), key
+            publish(device)
         return self._engine
 
     @torch.no_grad()

@@ -97,13 +97,19 @@ class _InferenceBase:
 
     def _results(self, pc, metas, tmrp, cls_logit, num_pcs, num_grasps, all_steps=()):
         metas = {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in metas.items()}
-        mean, std = metas["grasp_mean"].reshape(-1, 6), metas["grasp_std"].reshape(-1, 6)
-        if mean.shape[0] == 1 and num_pcs > 1:
-            mean, std = mean.expand(num_pcs, 6), std.expand(num_pcs, 6)
+        # mean [B,6] and std [1,6] (normalize_input and the dataset both build them so) broadcast independently
+        mean, std = metas["grasp_mean"], metas["grasp_std"]
         H, un, conf = pose_epilogue(tmrp, cls_logit, mean, std, num_grasps)
+        steps_H = []
+        if all_steps:
+            if num_pcs > 1:  # tools/inference.py:631-634
+                raise NotImplementedError("Batched grasps for all diffusion steps are not implemented")
+            for step in all_steps:  # [tmrp [G,6], logit [G,1]] on the CPU (grasp_ldm.py:223-227)
+                Hs, _, _ = pose_epilogue(step[0].to(self.device), None, mean, std, num_grasps)
+                steps_H.append(Hs.view(1, num_grasps, 4, 4).cpu())
         return dict(grasps=H.view(num_pcs, num_grasps, 4, 4), grasp_tmrp=un.view(num_pcs, num_grasps, 6),
                     confidence=conf.view(num_pcs, num_grasps, 1), qualities=None, pc=unnormalize_pc(pc, metas),
-                    all_steps_grasps=list(all_steps))
+                    all_steps_grasps=steps_H)
 
     def infer(self, data_idx=None, num_grasps=10, visualize=False, condition_type=Conditioning.UNCONDITIONAL,
               conditioning=None, **kwargs):
@@ -164,9 +170,12 @@ class InferenceLDM(_InferenceBase):
         batch = (pc.unsqueeze(0) if pc.ndim == 2 else pc).to(self.device)
         if self.num_inference_steps is not None:
             self.model.set_inference_timesteps(self.num_inference_steps)
+        if return_intermediate and batch.shape[0] > 1:  # the reference raises after sampling; fail before the work
+            raise NotImplementedError("Batched grasps for all diffusion steps are not implemented")
+        extra = {k: kwargs[k] for k in ("step_noise",) if k in kwargs}
         (tmrp, logit), steps = self.model.generate_grasps(batch, num_grasps=num_grasps,
-                                                          return_intermediate=return_intermediate, x_T=x_T)
-        return self._results(batch, metas, tmrp, logit, batch.shape[0], num_grasps)
+                                                          return_intermediate=return_intermediate, x_T=x_T, **extra)
+        return self._results(batch, metas, tmrp, logit, batch.shape[0], num_grasps, all_steps=steps)
 
     def infer_on_pointcloud(self, pc, num_grasps=10, return_intermediate=False):
         pcn, metas = self.normalize_input(pc.to(self.device))

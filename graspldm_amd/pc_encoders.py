@@ -49,8 +49,8 @@ class PVCNNEncoder(nn.Module):
         [out_channels x C] GEMM over the points instead of a 2 C^2/2 FLOP-per-point one.  Folded in f64 once per
         weight version."""
         cd, o0 = self.conv_downscale, self.out_layer[0]
-        key = (cd.weight.data_ptr(), cd.weight._version, cd.bias._version, o0.weight.data_ptr(), o0.weight._version,
-               o0.bias._version)
+        from ._cache import params_key, publish
+        key = params_key([cd.weight, cd.bias, o0.weight, o0.bias], cd.weight.device)
         hit = self.__dict__.get("_head_cache")
         if hit is None or hit[0] != key:
             wo, wd = o0.weight[:, :, 0].double(), cd.weight[:, :, 0].double()
@@ -58,6 +58,7 @@ class PVCNNEncoder(nn.Module):
             b = (wo @ cd.bias.double() + o0.bias.double()).float().contiguous()
             hit = (key, w, b)
             self.__dict__["_head_cache"] = hit
+            publish(cd.weight.device)
         return hit[1], hit[2]
 
     def load_ckpt_and_freeze(self, ckpt_path, fine_tune=False):

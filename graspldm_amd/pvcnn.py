@@ -191,12 +191,14 @@ class PointNetSAModule(nn.Module):
         [B, 3+C, M, U] tensor is never materialised."""
         from .sa_pack import SaMlpPlan
         plans = self.__dict__.setdefault("_plans", {})
-        key = tuple((p.data_ptr(), p._version) for p in mlp.state_dict(keep_vars=True).values()) + (str(coords.device),)
+        from ._cache import params_key, publish
+        key = params_key(mlp.state_dict(keep_vars=True).values(), coords.device)
         plan = plans.get(g)
         if plan is None or plan.key_dev != key:
             plan = SaMlpPlan(mlp, coords.device)
             plan.key_dev = key
             plans[g] = plan
+            publish(coords.device)
         feats = features.contiguous() if features is not None and features.shape[1] > 0 else None
         idx = ball_query(centers, coords, grouper.radius, grouper.num_neighbors)
         return plan.run(coords.contiguous(), centers.contiguous(), feats, idx)
@@ -312,10 +314,13 @@ class PVConv(nn.Module):
             # hand-written path: implicit-GEMM conv3d on f32 MFMA, GN+Swish, SE gate folded into the
             # devoxelize pass together with the point-branch add
             plan = self.__dict__.get("_voxel_plan")
-            key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs) + (str(vox.device),)
+            from ._cache import params_key, publish
+            key = params_key([c.weight for c in convs], vox.device)
             if plan is None or plan.key != key:
                 plan = voxel.VoxelBranchPlan(convs, vox.device)
+                plan.key = key
                 self.__dict__["_voxel_plan"] = plan
+                publish(vox.device)
             return voxel.run(plan, convs, norms, se, vox, norm_coords, pf, self.resolution), coords
         h = dense.conv3d_gn_swish(vox, convs[0], norms[0])
         h = dense.conv3d_gn_swish(h, convs[1], norms[1])

@@ -73,15 +73,35 @@ class R1dEngine:
         return tmrp, logit
 
 
+def _per_cloud_rows(t, n_clouds, name):
+    """[6] / [1,6] / [n_clouds,6] -> contiguous f32 [n_clouds,6] (the reference broadcasts a
+    [1,6] std against a [B,6] mean through unsqueeze(-2): tools/inference.py:64-94)."""
+    t = t.reshape(-1, 6).float()
+    if t.shape[0] == 1 and n_clouds > 1:
+        t = t.expand(n_clouds, 6)
+    if t.shape[0] != n_clouds:
+        raise RuntimeError(f"{name} has {t.shape[0]} rows; expected 1 or {n_clouds} (one per cloud)")
+    return t.contiguous()
+
+
 def pose_epilogue(tmrp, logit, grasp_mean, grasp_std, grasps_per_cloud):
-    """unnormalise + tmrp_to_H + sigmoid in one launch (tools/inference.py:628-647)."""
+    """unnormalise + tmrp_to_H + sigmoid in one launch (tools/inference.py:628-647).
+    grasp_mean / grasp_std: [n_clouds,6] or broadcastable [1,6] / [6], independently."""
     n = tmrp.shape[0]
     dev = tmrp.device
+    gpc = int(grasps_per_cloud)
+    if gpc <= 0 or n % gpc:
+        raise RuntimeError(f"{n} grasps do not split into clouds of {gpc}")
+    n_clouds = n // gpc
+    # every pointer handed to the launch stays referenced by a local until the call returns
+    tm = tmrp.contiguous().float()
+    lg = logit.contiguous().float() if logit is not None else None
+    gm = _per_cloud_rows(grasp_mean.to(dev), n_clouds, "grasp_mean")
+    gs = _per_cloud_rows(grasp_std.to(dev), n_clouds, "grasp_std")
     H = torch.empty((n, 4, 4), dtype=torch.float32, device=dev)
     un = torch.empty((n, 6), dtype=torch.float32, device=dev)
-    conf = torch.empty((n, 1), dtype=torch.float32, device=dev) if logit is not None else None
+    conf = torch.empty((n, 1), dtype=torch.float32, device=dev) if lg is not None else None
     with torch.cuda.device(dev):
-        L.call("gldm_pose_epilogue", L.ptr(tmrp.contiguous()), L.ptr(logit.contiguous()) if logit is not None else None,
-               L.ptr(grasp_mean.contiguous().float()), L.ptr(grasp_std.contiguous().float()), n, int(grasps_per_cloud),
+        L.call("gldm_pose_epilogue", L.ptr(tm), L.ptr(lg), L.ptr(gm), L.ptr(gs), n, gpc, n_clouds,
                L.ptr(H), L.ptr(un), L.ptr(conf), L.current_stream(dev))
     return H, un, conf

@@ -122,7 +122,8 @@ class _ResNet1DBase(nn.Module):
 
     # ---- engine plumbing
     def _param_key(self, device):
-        return (str(device), self.max_timesteps) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        from ._cache import params_key
+        return params_key(self.parameters(), device, self.max_timesteps)
 
     def engine(self, device, decoder=None, prefix=""):
         key = self._param_key(device)
@@ -134,6 +135,8 @@ class _ResNet1DBase(nn.Module):
                                    cond_rows=getattr(self, "cond_rows", 3))
             self._engine = R1dEngine(packed, device)
             self._engine_key = key
+            from ._cache import publish
+            publish(device)
         return self._engine
 
     def _cond_rows_of(self, z_cond):

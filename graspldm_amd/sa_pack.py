@@ -51,7 +51,6 @@ class SaMlpPlan:
         arr = ctypes.c_int32 * n
         self.cin_pad, self.cout, self.w_off, self.b_off = arr(*cin_pad), arr(*cout), arr(*w_off), arr(*b_off)
         self.cout_last = cout[-1]
-        self.key = tuple((p.data_ptr(), p._version) for p in shared_mlp.state_dict(keep_vars=True).values())
 
     def run(self, points, centers, features, idx):
         b, _, n = points.shape

@@ -27,7 +27,7 @@ class VoxelBranchPlan:
 
     def __init__(self, convs, device):
         self.w = [pack_conv3d(c.weight).to(device) for c in convs]
-        self.key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs) + (str(device),)
+        self.key = None  # set by the owner (PVConv.forward) from _cache.params_key
 
 
 def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):

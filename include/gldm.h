@@ -199,10 +199,12 @@ int gldm_decode(const gldm_r1d_desc *desc, const float *weights, const float *ce
                 void *workspace, gldm_stream_t stream);
 
 /* ref: tools/inference.py:64-94,628-647 + grasp_ldm/utils/rotations.py:171-302:
- * un = tmrp*std+mean; H = tmrp_to_H(un); conf = sigmoid(logit).  mean/std are
- * per cloud [n_clouds,6]; grasp i belongs to cloud i / grasps_per_cloud. */
+ * un = tmrp*std+mean; H = tmrp_to_H(un); conf = sigmoid(logit).  mean AND std are
+ * per cloud, [n_clouds,6] each (a caller holding the reference's broadcastable [1,6] std expands
+ * it first); grasp i belongs to cloud i / grasps_per_cloud; n <= n_clouds * grasps_per_cloud is
+ * checked (GLDM_ERR_INVALID_ARG). */
 int gldm_pose_epilogue(const float *tmrp /*[n,6]*/, const float *logit /*[n]*/, const float *grasp_mean,
-                       const float *grasp_std, int n, int grasps_per_cloud, float *H /*[n,4,4]*/,
+                       const float *grasp_std, int n, int grasps_per_cloud, int n_clouds, float *H /*[n,4,4]*/,
                        float *tmrp_unnorm /*[n,6]*/, float *confidence /*[n]*/, gldm_stream_t stream);
 
 /* ref: grasp_ldm/models/modules/ext/pvcnn/modules/pointnet.py:100-111 (PointNetSAModule.forward

@@ -256,3 +256,62 @@ def test_ppc_config_z16_latent_against_oracle():
     sched.set_timesteps(20)
     etm, elg = R.ldm_generate(sd, pcs, 5, sched, R.pvcnn_block_spec(0.75, 0.75), n_dims=16, x_T=x_T)
     assert _err(tm, etm) < 1e-4 and _err(lg, elg) < 1e-4, (_err(tm, etm), _err(lg, elg))
+
+
+def test_infer_on_pointcloud_batched_metas_contract(ldm):
+    """normalize_input (tools/inference.py:570-591) returns grasp_mean [B,6] and grasp_std [1,6]: both must
+    broadcast per cloud exactly like unnormalize_grasps' unsqueeze(-2) (tools/inference.py:64-94)."""
+    from graspldm_amd.inference import InferenceLDM
+    from graspldm_amd.synthetic import synthetic_batch
+    from oracle import torch_ref as R
+    pcs, _ = synthetic_batch(2, 1024)
+    raw = pcs * 0.05 + torch.tensor([[0.3, -0.2, 0.7], [-0.4, 0.1, 0.2]]).unsqueeze(1)  # metres, off-centre
+    inf = InferenceLDM(model=ldm, num_inference_steps=10, device="cuda:0")
+    pcn, metas = inf.normalize_input(raw.cuda())
+    assert metas["grasp_mean"].shape == (2, 6) and metas["grasp_std"].shape == (1, 6)
+    x_T = torch.randn(6, 1, 4, generator=torch.Generator().manual_seed(3))
+    out = inf.generate_grasps(pcn, metas, num_grasps=3, x_T=x_T)
+    (tm, lg), _ = ldm.generate_grasps(pcn, num_grasps=3, x_T=x_T)
+    cpu_metas = {k: v.cpu() for k, v in metas.items() if isinstance(v, torch.Tensor)}
+    exp = R.pose_epilogue(tm.cpu(), lg.cpu(), cpu_metas, 2, 3)
+    assert _err(out["grasps"], exp["grasps"]) < 1e-6
+    assert _err(out["grasp_tmrp"], exp["grasp_tmrp"]) < 1e-6
+    assert _err(out["confidence"], exp["confidence"]) < 1e-6
+    # cloud 1 really uses ITS mean: translations differ from cloud 0's by about the mean offset
+    assert (out["grasps"][1, :, :3, 3].mean(0) - out["grasps"][0, :, :3, 3].mean(0)).abs().max() > 0.2
+    assert _err(out["pc"], raw) < 1e-5
+
+
+def test_pose_epilogue_noncontiguous_and_shape_checks():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from graspldm_amd.r1d import pose_epilogue
+    from oracle import torch_ref as R
+    g = torch.Generator().manual_seed(11)
+    tm, lg = torch.randn(8, 6, generator=g), torch.randn(8, 1, generator=g)
+    mean = torch.randn(6, 4, generator=g).t()            # [4,6] non-contiguous view
+    std = (torch.rand(1, 12, generator=g) + 0.5)[:, ::2]  # [1,6] strided
+    H, un, conf = pose_epilogue(tm.cuda(), lg.cuda(), mean.cuda(), std.cuda(), 2)
+    exp = R.pose_epilogue(tm, lg, dict(grasp_mean=mean, grasp_std=std), 4, 2)
+    assert _err(H.view(4, 2, 4, 4), exp["grasps"]) < 1e-6 and _err(un.view(4, 2, 6), exp["grasp_tmrp"]) < 1e-6
+    with pytest.raises(RuntimeError):
+        pose_epilogue(tm.cuda(), lg.cuda(), mean[:3].cuda(), std.cuda(), 2)   # 3 rows for 4 clouds
+    with pytest.raises(RuntimeError):
+        pose_epilogue(tm.cuda(), lg.cuda(), mean.cuda(), std.cuda(), 3)       # 8 grasps do not split by 3
+
+
+def test_return_intermediate_all_steps(ldm):
+    """tools/inference.py:628-641: 50 probes, each tmrp_to_H(unnormalize_grasps(step[0])) -> [1,G,4,4]."""
+    from graspldm_amd.inference import InferenceLDM
+    from graspldm_amd.synthetic import synthetic_batch
+    pcs, metas = synthetic_batch(1, 1024)
+    inf = InferenceLDM(model=ldm, num_inference_steps=10, device="cuda:0")
+    x_T = torch.randn(4, 1, 4, generator=torch.Generator().manual_seed(5))
+    out = inf.generate_grasps(pcs, metas, num_grasps=4, return_intermediate=True, x_T=x_T)
+    steps = out["all_steps_grasps"]
+    assert len(steps) == 50 and steps[0].shape == (1, 4, 4, 4) and not steps[0].is_cuda
+    assert _err(out["grasps"], steps[-1]) < 1e-6          # last probe = the final latent decoded
+    assert (steps[0] - steps[-1]).abs().max() > 1e-3       # first probe decodes x_T
+    pcs2, metas2 = synthetic_batch(2, 1024)
+    with pytest.raises(NotImplementedError):
+        inf.generate_grasps(pcs2, metas2, num_grasps=4, return_intermediate=True)

@@ -1,3 +1,5 @@
+# Needs a diagnostic build of the library: `make -C graspldm_amd/csrc clean all EXTRA=-DGLDM_DEBUG_KNOBS`
+# (the shipped build reads no environment variable: GLDM_R1D_SKIP is compiled out).
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''

@@ -1,4 +1,7 @@
 """Sweep the phase offset between the two co-resident workgroups of a CU (GLDM_R1D_STAGGER_US)."""
+# Needs a diagnostic build of the library: `make -C graspldm_amd/csrc clean all EXTRA=-DGLDM_DEBUG_KNOBS`
+# (the shipped build reads no environment variable: GLDM_R1D_STAGGER_US is compiled out).
+
 import os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
 for us in [int(v) for v in sys.argv[1:]] or [0, 50, 100, 150, 200, 250]:
