@@ -60,6 +60,7 @@ typedef const __attribute__((address_space(1))) f32x4 *gf4p;  // plain global_lo
 
 constexpr int kHeads = 4, kDimHead = 32, kHidden = kHeads * kDimHead;  // LinearAttention defaults
 constexpr int kMaxC = 256;
+constexpr int kMaxSegs = 64;  // tiles (+ one spliced step segment) a persistent workgroup can be given
 
 // Geometry and LDS map (floats) of one workgroup.  X: block input / residual stream, H: scratch.
 template <int NC>
@@ -81,7 +82,8 @@ struct Geo {
   static constexpr int kMiscRed1 = kMiscG + 320;  // [kWaves][NC] cross-wave exchange slots (per wave and column)
   static constexpr int kMiscRed2 = kMiscRed1 + kWaves * NC;
   static constexpr int kMiscTape = kMiscRed2 + kWaves * NC;  // [kMaxOps][12] ints: the step program (+ its length)
-  static constexpr int kLdsFloats = kMiscTape + 1024;
+  static constexpr int kMiscSegs = kMiscTape + 1024;         // [kMaxSegs][4] ints: this workgroup's (tile, s0, s1) list
+  static constexpr int kLdsFloats = kMiscSegs + 256;
 };
 static_assert(Geo<64>::kLdsFloats * 4 <= 160 * 1024, "LDS budget (1 WG/CU)");
 static_assert(Geo<32>::kLdsFloats * 4 * 2 <= 160 * 1024, "LDS budget (2 WG/CU)");
@@ -925,6 +927,29 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
 }
 
 // ---------------------------------------------------------- the network ----
+// Step-segment hand-off between workgroups (a tile whose steps are split over a chain of slots).
+// The whole state of a tile between two steps is its latent row: NC floats.  Each float travels as ONE
+// naturally aligned 8-byte granule {value, tag} written by one write-through (agent-scope) store and
+// polled with agent-scope loads: a granule is never torn, so no fence, flag or ordering between
+// granules is needed (MI355X_MICROARCH.md, "R2's granule").  tag = (launch epoch, step count) is
+// unique per launch and step; the zero-initialised workspace holds tag 0, which no hand-off uses.
+struct ChainHdr { unsigned ticket, done, epoch, error; };
+constexpr int kChainHdrBytes = 256;
+__device__ __forceinline__ unsigned chain_tag(unsigned epoch, int step) { return (epoch << 12) | (unsigned)step; }
+__device__ __forceinline__ void chain_give(unsigned long long *g, float v, unsigned tag) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float chain_take(unsigned long long *g, unsigned tag, unsigned *error) {
+  unsigned long long x = 0;
+  for (int spin = 0; spin < (1 << 22); ++spin) {  // bounded: ~2 s; a healthy wait is a few ms at most
+    x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
+    __builtin_amdgcn_s_sleep(16);
+  }
+  __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // gldm_r1d_workspace_error()
+  return __uint_as_float((unsigned)x);
+}
+
 struct RunArgs {
   gldm_r1d_desc d;
   const float *weights;
@@ -943,7 +968,10 @@ struct RunArgs {
   float *out1;            // decode: logit [n]
   float *ws;              // unused (ABI)
   int skip;               // diagnostic phase-skip mask (GLDM_R1D_SKIP env; 0 in production)
-  int full_tiles, tail_tiles, tail_samples;
+  // Work distribution (make_plan): `slots` persistent workgroups; slot p owns tiles p, p + slots, ... (`rounds` of
+  // them) for all steps; each of the `left_tiles` tiles beyond the whole rounds is cut into `chain` step segments of
+  // `seglen` steps that consecutive slots run one after the other, handing the latent on through the workspace.
+  int slots, rounds, left_tiles, chain, seglen;
   int stagger_ticks, n_cus;  // start offset (100 MHz ticks) of the second workgroup of a CU
   long long *stamps;         // diagnostic (GLDM_R1D_STAMP): cycle counter at every op of the last step, block 0
 };
@@ -1188,16 +1216,6 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   constexpr int S = NC / L;
   Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
         a.skip, GG::kNT};
-  // Tiles: the first `full_tiles` workgroups own S samples each; the remainder of the batch is
-  // spread over `tail_tiles` workgroups of `tail_samples` (one live 16-column n-tile) so the last
-  // round of workgroups is not full-width tiles on a fraction of the CUs.
-  // the short tail tiles are dispatched first (blockIdx < tail_tiles): each then shares its CU with a full
-  // tile from the start instead of running alone at the end
-  const int tile = (int)blockIdx.x < a.tail_tiles ? a.full_tiles + (int)blockIdx.x : (int)blockIdx.x - a.tail_tiles;
-  const bool is_tail = tile >= a.full_tiles;
-  const int samp0 = is_tail ? a.full_tiles * S + (tile - a.full_tiles) * a.tail_samples : tile * S;
-  c.nta = (is_tail && a.tail_samples * L <= 16) ? 1 : GG::kNT;
-  const int nsamp = is_tail ? a.tail_samples : S;  // samples this workgroup owns
   const int E = d.emb_dim, R = d.cond_rows;
   float *lat = lds + GG::kMiscLat, *epsr = lds + GG::kMiscEps, *G = lds + GG::kMiscG;
   float *X = lds + GG::kBufX;
@@ -1209,21 +1227,64 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   for (int i = c.tid; i < GG::kLdsFloats; i += GG::kThreads) lds[i] = 0.f;  // dead columns must stay finite
   __syncthreads();
   int *tape = reinterpret_cast<int *>(lds + GG::kMiscTape);
-  if (c.tid == 0) tape[1023] = build_tape<NC>(d, tape);
+  ChainHdr *hdr = reinterpret_cast<ChainHdr *>(a.ws);
+  unsigned long long *state = reinterpret_cast<unsigned long long *>(a.ws) + kChainHdrBytes / 8;
+  const bool chained = a.left_tiles > 0 && a.chain > 1;
+  if (c.tid == 0) {
+    tape[1023] = build_tape<NC>(d, tape);
+    // Slot = order of arrival, not blockIdx: a slot only ever waits for the slot before it, which has
+    // then already started, so the hand-offs cannot deadlock whatever the dispatch order or residency.
+    tape[1022] = chained ? (int)__hip_atomic_fetch_add(&hdr->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                         : (int)blockIdx.x;
+    tape[1021] = chained ? (int)hdr->epoch : 0;  // written by the previous launch on this workspace
+  }
   __syncthreads();
   const int n_ops = __builtin_amdgcn_readfirstlane(tape[1023]);
+  const int slot = __builtin_amdgcn_readfirstlane(tape[1022]);
+  const unsigned epoch = (unsigned)__builtin_amdgcn_readfirstlane(tape[1021]);
 #ifdef GLDM_DEBUG_KNOBS
   if (a.stagger_ticks > 0 && ((blockIdx.x / a.n_cus) & 1)) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < a.stagger_ticks) __builtin_amdgcn_s_sleep(32);
   }
 #endif
-  // ---- latent row for this tile
+  // ---- this slot's program: its own tiles for all steps, with (at most) one step segment of a left-over tile
+  // spliced in at the step at which the previous slot of the chain delivers it.  Built once, by one thread,
+  // into LDS (like the op tape): the step loop keeps no scheduling state in registers.
+  int *segs = reinterpret_cast<int *>(lds + GG::kMiscSegs);
+  if (c.tid == 0) {
+    const int N = a.n_steps;
+    const int cj = slot / a.chain, ci = slot - cj * a.chain;
+    const bool has_left = a.left_tiles > 0 && cj < a.left_tiles && ci * a.seglen < N;
+    const int cut = has_left ? ci * a.seglen : 0;
+    int n = 0;
+    auto put = [&](int tile, int s0, int s1) {
+      segs[4 * n] = tile; segs[4 * n + 1] = s0; segs[4 * n + 2] = s1;
+      ++n;
+    };
+    if (cut > 0) put(slot, 0, cut);  // own tile 0 runs in two parts around the spliced segment
+    if (has_left) put(a.rounds * a.slots + cj, cut, min(N, cut + a.seglen));
+    put(slot, cut, N);
+    for (int r = 1; r < a.rounds; ++r) put(r * a.slots + slot, 0, N);
+    segs[4 * kMaxSegs - 1] = n;
+  }
+  __syncthreads();
+  const int nseg = __builtin_amdgcn_readfirstlane(segs[4 * kMaxSegs - 1]);
+  for (int sg = 0; sg < nseg; ++sg) {
+  const int tile = __builtin_amdgcn_readfirstlane(segs[4 * sg]);
+  const int s0 = __builtin_amdgcn_readfirstlane(segs[4 * sg + 1]), s1 = __builtin_amdgcn_readfirstlane(segs[4 * sg + 2]);
+  const int N = a.n_steps;
+  const int samp0 = tile * S;
+  const int nsamp = min(S, a.n_samples - samp0);  // samples this tile holds (the batch's last tile may be short)
+  c.nta = (nsamp * L <= 16) ? 1 : GG::kNT;
+  // ---- latent row for this tile: from the input (first step) or from the slot that ran the steps before s0
   if (c.tid < NC) {
     const int s = c.tid / L, l = c.tid % L;
     const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
     float v;
-    if (has_in) {
+    if (s0 > 0) {
+      v = chain_take(state + (size_t)tile * NC + c.tid, chain_tag(epoch, s0), &hdr->error);
+    } else if (has_in) {
       const float *wi = a.weights + d.in_w + l * d.latent_dim;
       v = a.weights[d.in_b + l];
       for (int q = 0; q < d.latent_dim; ++q) v += wi[q] * a.x_in[(size_t)gi * d.latent_dim + q];
@@ -1234,7 +1295,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   }
   __syncthreads();
 
-  for (int step = 0; step < a.n_steps; ++step) {
+  for (int step = s0; step < s1; ++step) {
     if (GLDM_STAMPS(a.stamps) && blockIdx.x == 0 && c.tid == 0) a.stamps[kMaxOps + 1] = (long long)__builtin_readcyclecounter();
     // ---- G[s][e] = sum_r silu(temb[t][e] + cemb[cond][r][e])
     if (!GLDM_SKIP(c, 32))
@@ -1299,8 +1360,10 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     }
   }
 
-  // ---- outputs
-  if (!has_head) {
+  // ---- outputs of the segment: the result after the last step, else the latent for the next slot of the chain
+  if (s1 < N) {
+    if (c.tid < NC) chain_give(state + (size_t)tile * NC + c.tid, lat[c.tid], chain_tag(epoch, s1));
+  } else if (!has_head) {
     if (c.tid < NC) {
       const int s = c.tid / L, l = c.tid % L;
       const int gi = samp0 + s;
@@ -1319,6 +1382,16 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
         if (r < 6) a.out0[(size_t)gi * 6 + r] = acc;
         else a.out1[gi] = acc;
       }
+    }
+  }
+  __syncthreads();  // lat / epsr are rewritten by the next segment
+  }  // segments
+  if (chained && c.tid == 0) {  // the last workgroup to finish re-arms the header for the next launch
+    const unsigned done = __hip_atomic_fetch_add(&hdr->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(&hdr->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&hdr->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&hdr->epoch, (epoch + 1u) & 0xFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1451,8 +1524,6 @@ int validate(const gldm_r1d_desc *d) {
   return GLDM_OK;
 }
 
-struct Tiling { int full_tiles, tail_tiles, tail_samples; };
-
 int cu_count() {
   static int cus = 0;
   if (!cus) {
@@ -1464,22 +1535,32 @@ int cu_count() {
   return cus;
 }
 
-Tiling make_tiling(int n_samples, int L, int nc) {
-  const int cus = cu_count();
-  const int slots = cus * (nc == 32 ? 2 : 1);     // workgroups resident at once
-  const int S = nc / L, unit = 16 / L, nt = nc / 16;  // samples per tile / per 16-column n-tile
+// Work plan of one launch.  `slots` = workgroups resident at once (two 32-column tiles per CU).  A batch of
+// up to `slots` tiles is one workgroup per tile.  A larger one runs `slots` persistent workgroups: each owns
+// `rounds` whole tiles, and the `left` tiles beyond the whole rounds are NOT run as a last, partly empty
+// round (5120 latents = 640 tiles on 512 slots would take two rounds for 1.25 rounds of work): each is cut
+// along the step axis into `chain` segments that a group of `chain` consecutive slots runs in turn, so every
+// slot ends up with (nearly) the same number of tile-steps.
+struct Plan { int grid, slots, rounds, left, chain, seglen; };
+
+Plan make_plan(int n_samples, int n_steps, int L, int nc) {
+  const int slots = cu_count() * (nc == 32 ? 2 : 1);
+  const int S = nc / L;
   const int tiles = (n_samples + S - 1) / S;
-  Tiling t{tiles, 0, 0};
-  if (tiles <= slots || tiles % slots == 0) return t;
-  const int full = (tiles / slots) * slots;
-  const int left = n_samples - full * S;          // < slots * S samples for the last round of workgroups
-  const int units = (left + unit - 1) / unit;
-  const int upt = (units + slots - 1) / slots;    // n-tiles per tail workgroup
-  if (upt >= nt) return t;
-  t.full_tiles = full;
-  t.tail_samples = upt * unit;
-  t.tail_tiles = (left + t.tail_samples - 1) / t.tail_samples;
-  return t;
+  Plan p{tiles, slots, 1, 0, 1, n_steps};
+  if (tiles <= slots) return p;
+  if (tiles / slots + 2 > kMaxSegs) { p.grid = -1; return p; }  // more tiles per workgroup than its list holds
+  p.grid = slots;
+  p.rounds = tiles / slots;
+  p.left = tiles - p.rounds * slots;
+  if (p.left > 0) {
+    int g = slots / p.left;
+    if (g > 8) g = 8;             // a hand-off is ~3 us; finer cuts buy nothing
+    if (g > n_steps) g = n_steps;
+    p.chain = g < 1 ? 1 : g;
+    p.seglen = (n_steps + p.chain - 1) / p.chain;
+  }
+  return p;
 }
 
 template <int NC, int L>
@@ -1497,10 +1578,11 @@ int launch_one(const RunArgs &a, int tiles, hipStream_t s) {
 
 int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   const int L = a_in.d.seq_len, nc = engine_nc();
-  const Tiling tl = make_tiling(a_in.n_samples, L, nc);
-  const int tiles = tl.full_tiles + tl.tail_tiles;
+  const Plan pl = make_plan(a_in.n_samples, a_in.n_steps, L, nc);
+  const int tiles = pl.grid;
+  if (tiles <= 0) return GLDM_ERR_UNSUPPORTED;  // > ~250 k samples in one launch: split the batch
   RunArgs a = a_in;
-  a.full_tiles = tl.full_tiles; a.tail_tiles = tl.tail_tiles; a.tail_samples = tl.tail_samples;
+  a.slots = pl.slots; a.rounds = pl.rounds; a.left_tiles = pl.left; a.chain = pl.chain; a.seglen = pl.seglen;
   a.n_cus = cu_count();
 #ifdef GLDM_DEBUG_KNOBS
   // diagnostic builds only (make EXTRA=-DGLDM_DEBUG_KNOBS): phase skipping, a start offset for the
@@ -1562,7 +1644,10 @@ GLDM_API int gldm_r1d_cond_embed(const float *z_cond, const float *w, const floa
 
 GLDM_API long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples) {
   if (validate(desc) != GLDM_OK || n_samples <= 0) return -1;
-  return 256;  // the engine keeps everything on chip; the argument stays in the ABI
+  // header + one 8-byte hand-off granule per activation column of every tile (see ChainHdr)
+  const int S = engine_nc() / desc->seq_len;
+  const long long tiles = (n_samples + S - 1) / S;
+  return kChainHdrBytes + tiles * engine_nc() * 8;
 }
 
 GLDM_API int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,

@@ -31,8 +31,13 @@ class R1dEngine:
         key = torch.cuda.current_stream(self.device).cuda_stream
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
-            ws = self._ws[key] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            # zeroed once (contract of gldm_r1d_workspace_bytes); the library re-arms it after every launch
+            ws = self._ws[key] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
         return ws
+
+    def workspace_errors(self):
+        """Sum of the hand-off error words of every workspace (0 unless a bounded wait expired); synchronises."""
+        return int(sum(int(ws[12:16].view(torch.int32).item()) for ws in self._ws.values()))
 
     def cond_embed(self, z_cond):
         """input_emb_layers (Linear + SiLU) on [n, R, Dc] (or [n, Dc]) -> [n, R, E]."""

@@ -172,9 +172,17 @@ enum gldm_sched_kind { GLDM_SCHED_NONE = 0, GLDM_SCHED_DDIM = 1, GLDM_SCHED_DDPM
 int gldm_r1d_cond_embed(const float *z_cond /*[n_cond,R,Dc]*/, const float *w /*[E,Dc]*/, const float *b /*[E]*/,
                         int n_cond, int rows, int dc, int e, float *cemb /*[n_cond,R,E]*/, gldm_stream_t stream);
 
-/* Bytes of scratch gldm_denoise / gldm_decode need for n_samples (a token amount today: a step
- * stays on chip; -1 if the descriptor is not supported: groups must be 4, widths powers of two
- * in {4, 16, 32, 64, 128, 256}, at most 128 on levels with attention, emb_dim % 16 == 0). */
+/* Bytes of workspace gldm_denoise / gldm_decode need for n_samples (-1 if the descriptor is not
+ * supported: groups must be 4, widths powers of two in {4, 16, 32, 64, 128, 256}, at most 128 on levels
+ * with attention, emb_dim % 16 == 0).  A step stays on chip; the workspace carries only the
+ * work-distribution header (GLDM_R1D_WS_*: 256 bytes) and one 8-byte {latent value, tag} hand-off
+ * granule per activation column, used when a batch does not fill whole rounds of workgroups and the
+ * left-over tiles are split along the step axis over several workgroups.
+ * Contract: the caller ZEROES the workspace once, when it allocates it; a workspace is used by one
+ * launch at a time (launches on the same stream may share it, concurrent streams may not); the
+ * library re-arms it at the end of every launch.  The 32-bit word at byte GLDM_R1D_WS_ERROR is set
+ * to 1 if a hand-off wait ever ran into its (seconds long) bound: outputs of that launch are invalid. */
+#define GLDM_R1D_WS_ERROR 12
 long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples);
 
 /* ref: grasp_ldm/models/diffusion/gaussian_diffusion.py:232-277 (sample loop:
