@@ -30,6 +30,9 @@ _SIGNATURES = {
     "gldm_avg_voxelize_forward": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gldm_trilinear_devoxelize_forward": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gldm_voxel_coords": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
+    "gldm_farthest_points_euclid": [_vp, _i, _i, _i, _vp, _vp],
+    "gldm_normalize_cloud": [_vp, _i, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp],
+    "gldm_gather_points": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "gldm_sa_group": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "gldm_r1d_cond_embed": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "gldm_denoise": [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -151,7 +151,12 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return v;
 }
 
-template <int kThreads, int kPerThread>
+// kRule 0: the reference's CUDA kernel (sampling.cu:86-167): coords [3][n], squared distances, start 1e38.
+// kRule 1: the reference's host-side greedy sampler PointCloudHelpers.farthest_points
+//          (grasp_ldm/utils/pointcloud_helpers.py:160-217, used by regularize_pc_point_count :124-158):
+//          points [n][3], EUCLIDEAN distance sqrt((dx^2 + dy^2) + dz^2) in f32 (numpy's summation order),
+//          start 1e7, np.argmax tie rule = lowest index.
+template <int kThreads, int kPerThread, int kRule>
 __global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__ coords, int n, int m,
                                                        int32_t *__restrict__ out) {
   extern __shared__ float s_xyz[];  // [3][n]
@@ -160,16 +165,20 @@ __global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__
   coords += (size_t)b * 3 * n;
   out += (size_t)b * m;
   const int tid = threadIdx.x;
-  for (int i = tid; i < 3 * n; i += kThreads) s_xyz[i] = coords[i];
+  if (kRule == 0) {
+    for (int i = tid; i < 3 * n; i += kThreads) s_xyz[i] = coords[i];
+  } else {
+    for (int i = tid; i < 3 * n; i += kThreads) s_xyz[(i % 3) * n + i / 3] = coords[i];
+  }
   float x[kPerThread], y[kPerThread], z[kPerThread], dist[kPerThread];
 #pragma unroll
   for (int q = 0; q < kPerThread; ++q) {
     const int k = tid + q * kThreads;
     const bool ok = k < n;
-    x[q] = ok ? coords[k] : 0.f;
-    y[q] = ok ? coords[k + n] : 0.f;
-    z[q] = ok ? coords[k + 2 * n] : 0.f;
-    dist[q] = 1e38f;
+    x[q] = ok ? coords[kRule == 0 ? k : 3 * k] : 0.f;
+    y[q] = ok ? coords[kRule == 0 ? k + n : 3 * k + 1] : 0.f;
+    z[q] = ok ? coords[kRule == 0 ? k + 2 * n : 3 * k + 2] : 0.f;
+    dist[q] = kRule == 0 ? 1e38f : 1e7f;
   }
   if (tid == 0) out[0] = 0;
   __syncthreads();
@@ -183,10 +192,11 @@ __global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__
     for (int q = 0; q < kPerThread; ++q) {
       const int k = tid + q * kThreads;
       if (k < n) {
-        const float d = (x[q] - x1) * (x[q] - x1) + (y[q] - y1) * (y[q] - y1) + (z[q] - z1) * (z[q] - z1);
+        float d = (x[q] - x1) * (x[q] - x1) + (y[q] - y1) * (y[q] - y1) + (z[q] - z1) * (z[q] - z1);
+        if (kRule == 1) d = __fsqrt_rn(d);
         const float d2 = d < dist[q] ? d : dist[q];
         dist[q] = d2;
-        const unsigned int tie = ~(((unsigned int)(k & 511) << 22) | (unsigned int)k);
+        const unsigned int tie = kRule == 0 ? ~(((unsigned int)(k & 511) << 22) | (unsigned int)k) : ~(unsigned int)k;
         const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | tie;
         best = key > best ? key : best;
       }
@@ -595,11 +605,71 @@ GLDM_API int gldm_gather_features_forward(const float *features, const int32_t *
 }
 
 namespace {
-template <int kThreads, int kPerThread>
+template <int kThreads, int kPerThread, int kRule>
 int launch_fps(const float *coords, int b, int n, int m, int32_t *out, hipStream_t s) {
-  hipLaunchKernelGGL((fps_kernel<kThreads, kPerThread>), dim3(b), dim3(kThreads), (size_t)3 * n * sizeof(float),
+  hipLaunchKernelGGL((fps_kernel<kThreads, kPerThread, kRule>), dim3(b), dim3(kThreads), (size_t)3 * n * sizeof(float),
                      s, coords, n, m, out);
   return launch_status();
+}
+template <int kRule>
+int dispatch_fps(const float *coords, int b, int n, int m, int32_t *out_idx, hipStream_t s) {
+  if (n <= 64) return launch_fps<64, 1, kRule>(coords, b, n, m, out_idx, s);
+  if (n <= 128) return launch_fps<128, 1, kRule>(coords, b, n, m, out_idx, s);
+  if (n <= 256) return launch_fps<256, 1, kRule>(coords, b, n, m, out_idx, s);
+  if (n <= 512) return launch_fps<512, 1, kRule>(coords, b, n, m, out_idx, s);
+  if (n <= 1024) return launch_fps<1024, 1, kRule>(coords, b, n, m, out_idx, s);
+  if (n <= 2048) return launch_fps<1024, 2, kRule>(coords, b, n, m, out_idx, s);
+  if (n <= 4096) return launch_fps<1024, 4, kRule>(coords, b, n, m, out_idx, s);
+  return launch_fps<1024, 8, kRule>(coords, b, n, m, out_idx, s);
+}
+
+// Raw-cloud front end: centre + scale a sensor cloud [n][3] (tools/inference.py:570-591 normalize_input) and
+// gather rows of it by index (point-count regularisation).  The mean is accumulated in f64 in a fixed tree.
+constexpr int kNcBlock = 256;
+struct Vec3 { float v[3]; };
+__global__ __launch_bounds__(kNcBlock) void normalize_cloud_kernel(const float *__restrict__ pc, int n, Vec3 shift,
+                                                                   Vec3 scale, float *__restrict__ out,
+                                                                   float *__restrict__ mean_out) {
+  __shared__ double s_sum[3][kNcBlock / kWave];
+  __shared__ float s_mean[3];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  pc += (size_t)b * 3 * n;
+  out += (size_t)b * 3 * n;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int k = tid; k < n; k += kNcBlock)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) acc[a] += (double)pc[3 * k + a];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double v = acc[a];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    if ((tid & 63) == 0) s_sum[a][tid >> 6] = v;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    double v = 0.0;
+    for (int w = 0; w < kNcBlock / kWave; ++w) v += s_sum[tid][w];
+    const float m = (float)(v / (double)n);
+    s_mean[tid] = m;
+    mean_out[(size_t)b * 3 + tid] = m;
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * n; i += kNcBlock) {
+    const int a = i % 3;
+    const float sh = a == 0 ? shift.v[0] : (a == 1 ? shift.v[1] : shift.v[2]);
+    const float sc = a == 0 ? scale.v[0] : (a == 1 ? scale.v[1] : scale.v[2]);
+    out[i] = ((pc[i] - s_mean[a]) - sh) / sc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ pc, const int32_t *__restrict__ idx,
+                                                          int n, int m, float *__restrict__ out) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * m) return;
+  const int j = i / 3, a = i - 3 * j;
+  out[(size_t)b * 3 * m + i] = pc[((size_t)b * n + idx[(size_t)b * m + j]) * 3 + a];
 }
 }  // namespace
 
@@ -608,15 +678,33 @@ GLDM_API int gldm_furthest_point_sampling(const float *coords, int b, int n, int
   if (!coords || !out_idx || b <= 0 || n <= 0 || m < 0) return GLDM_ERR_INVALID_ARG;
   if (m == 0) return GLDM_OK;
   if (n > 1024 * kFpsMaxPerThread) return GLDM_ERR_UNSUPPORTED;
-  hipStream_t s = as_stream(stream);
-  if (n <= 64) return launch_fps<64, 1>(coords, b, n, m, out_idx, s);
-  if (n <= 128) return launch_fps<128, 1>(coords, b, n, m, out_idx, s);
-  if (n <= 256) return launch_fps<256, 1>(coords, b, n, m, out_idx, s);
-  if (n <= 512) return launch_fps<512, 1>(coords, b, n, m, out_idx, s);
-  if (n <= 1024) return launch_fps<1024, 1>(coords, b, n, m, out_idx, s);
-  if (n <= 2048) return launch_fps<1024, 2>(coords, b, n, m, out_idx, s);
-  if (n <= 4096) return launch_fps<1024, 4>(coords, b, n, m, out_idx, s);
-  return launch_fps<1024, 8>(coords, b, n, m, out_idx, s);
+  return dispatch_fps<0>(coords, b, n, m, out_idx, as_stream(stream));
+}
+
+GLDM_API int gldm_farthest_points_euclid(const float *points, int b, int n, int m, int32_t *out_idx,
+                                         gldm_stream_t stream) {
+  if (!points || !out_idx || b <= 0 || n <= 0 || m < 0 || m > n) return GLDM_ERR_INVALID_ARG;
+  if (m == 0) return GLDM_OK;
+  if (n > 1024 * kFpsMaxPerThread) return GLDM_ERR_UNSUPPORTED;
+  return dispatch_fps<1>(points, b, n, m, out_idx, as_stream(stream));
+}
+
+GLDM_API int gldm_normalize_cloud(const float *pc, int b, int n, float shift_x, float shift_y, float shift_z,
+                                  float scale_x, float scale_y, float scale_z, float *pc_out, float *mean_out,
+                                  gldm_stream_t stream) {
+  if (!pc || !pc_out || !mean_out || b <= 0 || n <= 0 || scale_x == 0.f || scale_y == 0.f || scale_z == 0.f)
+    return GLDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(normalize_cloud_kernel, dim3(b), dim3(kNcBlock), 0, as_stream(stream), pc, n,
+                     Vec3{{shift_x, shift_y, shift_z}}, Vec3{{scale_x, scale_y, scale_z}}, pc_out, mean_out);
+  return launch_status();
+}
+
+GLDM_API int gldm_gather_points(const float *pc, const int32_t *idx, int b, int n, int m, float *out,
+                                gldm_stream_t stream) {
+  if (!pc || !idx || !out || b <= 0 || n <= 0 || m <= 0) return GLDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(3 * m, 256), b), dim3(256), 0, as_stream(stream), pc, idx, n,
+                     m, out);
+  return launch_status();
 }
 
 GLDM_API int gldm_three_nn_interpolate_forward(const float *points, const float *centers,

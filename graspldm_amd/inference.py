@@ -111,6 +111,41 @@ class _InferenceBase:
                     confidence=conf.view(num_pcs, num_grasps, 1), qualities=None, pc=unnormalize_pc(pc, metas),
                     all_steps_grasps=steps_H)
 
+    def set_normalization_params(self, norm_config):
+        """grasp_ldm/inference/inference_base.py:103-130: pc_shift, grasp_shift, translation_scale, rotation_scale."""
+        get = (lambda k: norm_config[k]) if isinstance(norm_config, dict) else (lambda k: getattr(norm_config, k))
+        for k in ("pc_shift", "grasp_shift", "translation_scale", "rotation_scale"):
+            try:
+                get(k)
+            except (KeyError, AttributeError):
+                raise AssertionError(f"norm_config should have `{k}`")
+        self._norm = dict(pc_shift=get("pc_shift"), grasp_shift=get("grasp_shift"),
+                          pc_scale=get("translation_scale"), mrp_scale=get("rotation_scale"))
+
+    def normalize_input(self, pc):
+        """tools/inference.py:570-591 / inference_base.py:181-212: centre on the mean, divide by the translation
+        scale (0.05 unless set_normalization_params says otherwise), build metas.  One HIP launch."""
+        from .pointcloud import normalize_input
+        kw = getattr(self, "_norm", None) or dict(pc_shift=0.0, pc_scale=PC_STD, mrp_scale=MRP_STD, grasp_shift=None)
+        return normalize_input(pc.to(self.device), **kw)
+
+    def infer_on_pointcloud(self, pc, num_grasps=10, return_intermediate=False, num_points=None,
+                            use_farthest_point=True):
+        """tools/inference.py:658-666 (= generate_on_pointcloud, grasp_ldm/inference/inference_base.py:161-179).
+        `num_points` (additive): first bring every cloud to the encoder's point count
+        (PointCloudHelpers.regularize_pc_point_count; farthest-point selection by default)."""
+        pc = pc.to(self.device)
+        if num_points is not None and pc.shape[-2] != num_points:
+            from .pointcloud import PointCloudHelpers
+            clouds = pc.unsqueeze(0) if pc.ndim == 2 else pc
+            reg = torch.stack([PointCloudHelpers.regularize_pc_point_count(c, num_points, use_farthest_point)
+                               for c in clouds])
+            pc = reg[0] if pc.ndim == 2 else reg
+        pcn, metas = self.normalize_input(pc)
+        return self.generate_grasps(pcn, metas, num_grasps=num_grasps, return_intermediate=return_intermediate)
+
+    generate_on_pointcloud = infer_on_pointcloud
+
     def infer(self, data_idx=None, num_grasps=10, visualize=False, condition_type=Conditioning.UNCONDITIONAL,
               conditioning=None, **kwargs):
         if self.dataset is None:
@@ -150,21 +185,6 @@ class InferenceLDM(_InferenceBase):
         if load_dataset:
             warnings.warn("ACRONYM dataset loading is out of scope; use generate_grasps(pc, metas)")
 
-    PC_MEAN = torch.zeros(3)
-
-    def normalize_input(self, pc):
-        """tools/inference.py:570-591: centre on the mean, divide by 0.05, build metas."""
-        assert pc.ndim in (2, 3)
-        pc = pc.clone()
-        mean = pc.mean(dim=-2)
-        pc = (pc - (mean.unsqueeze(1) if pc.ndim == 3 else mean)) / PC_STD
-        gm = torch.zeros(mean.reshape(-1, 3).shape[0], 6, device=pc.device)
-        gm[:, :3] = mean.reshape(-1, 3)
-        std = torch.tensor([PC_STD] * 3 + [MRP_STD] * 3, device=pc.device).unsqueeze(0)
-        metas = dict(pc_mean=mean.reshape(-1, 3), pc_std=torch.full((1, 3), PC_STD, device=pc.device),
-                     grasp_mean=gm, grasp_std=std, dataset_normalized=True)
-        return pc, metas
-
     @torch.no_grad()
     def generate_grasps(self, pc, metas, num_grasps=10, return_intermediate=False, x_T=None, **kwargs):
         batch = (pc.unsqueeze(0) if pc.ndim == 2 else pc).to(self.device)
@@ -176,10 +196,6 @@ class InferenceLDM(_InferenceBase):
         (tmrp, logit), steps = self.model.generate_grasps(batch, num_grasps=num_grasps,
                                                           return_intermediate=return_intermediate, x_T=x_T, **extra)
         return self._results(batch, metas, tmrp, logit, batch.shape[0], num_grasps, all_steps=steps)
-
-    def infer_on_pointcloud(self, pc, num_grasps=10, return_intermediate=False):
-        pcn, metas = self.normalize_input(pc.to(self.device))
-        return self.generate_grasps(pcn, metas, num_grasps=num_grasps, return_intermediate=return_intermediate)
 
 
 class InferenceVAE(_InferenceBase):

@@ -98,6 +98,29 @@ int gldm_voxel_coords(const float *coords /*[b,3,n]*/, int b, int n, int r, int 
                       float *norm_coords /*[b,3,n]*/, int32_t *vox_coords /*[b,3,n]*/,
                       gldm_stream_t stream);
 
+/* ------------------------------------------------ raw-cloud front end */
+
+/* ref: grasp_ldm/utils/pointcloud_helpers.py:160-217 (PointCloudHelpers.farthest_points with
+ * distance_by_translation_point :219-223, as called by regularize_pc_point_count :124-158): greedy
+ * farthest-point selection on a sensor-layout cloud [b,n,3].  First centre = index 0 (np.argmax of
+ * the all-1e7 start vector), distance = sqrt((dx^2 + dy^2) + dz^2) in f32, ties -> lowest index.
+ * m <= n <= 8192.  Bit-identical indices to the numpy routine on f32 input. */
+int gldm_farthest_points_euclid(const float *points /*[b,n,3]*/, int b, int n, int m,
+                                int32_t *out_idx /*[b,m]*/, gldm_stream_t stream);
+
+/* ref: tools/inference.py:570-591 (InferenceLDM.normalize_input) and
+ * grasp_ldm/inference/inference_base.py:181-212: pc_out = ((pc - mean_points(pc)) - shift) / scale
+ * per axis (shift = _INPUT_PC_SHIFT, scale = _INPUT_PC_SCALE of set_normalization_params :103-130),
+ * mean_out[b,:] = per-cloud mean (f64 accumulation, rounded once). */
+int gldm_normalize_cloud(const float *pc /*[b,n,3]*/, int b, int n, float shift_x, float shift_y, float shift_z,
+                         float scale_x, float scale_y, float scale_z,
+                         float *pc_out /*[b,n,3]*/, float *mean_out /*[b,3]*/, gldm_stream_t stream);
+
+/* out[b,j,:] = pc[b,idx[b,j],:]  (row gather behind every point-count regularisation:
+ * pointcloud_helpers.py:40-71,124-158). */
+int gldm_gather_points(const float *pc /*[b,n,3]*/, const int32_t *idx /*[b,m]*/, int b, int n, int m,
+                       float *out /*[b,m,3]*/, gldm_stream_t stream);
+
 /* ------------------------------------------------------- set abstraction */
 
 /* ref: grasp_ldm/models/modules/ext/pvcnn/modules/ball_query.py:16-34

@@ -184,7 +184,39 @@ def pvcnn2_golden(cloud=None):
     _save("pvcnn2.npz", coords=cloud, out=net(cloud)[:, :, ::16])
 
 
+def front_end_golden():
+    """the reference's own PointCloudHelpers (utils/pointcloud_helpers.py; pure numpy / torch, imported
+    with the trimesh stand-in) on seeded clouds: greedy farthest points, both branches of regularize_pc_point_count
+    (np.random seeded), regularize_pointcloud (torch seeded)."""
+    ref_import.install_shims()
+    from grasp_ldm.utils.pointcloud_helpers import PointCloudHelpers as P
+    out = {}
+    rng = np.random.RandomState(7)
+    cases = [(300, 64), (1500, 1024), (4096, 1024), (2500, 2500)]
+    for i, (n, m) in enumerate(cases):
+        pc = (rng.standard_normal((n, 3)) * np.array([0.08, 0.05, 0.02]) + np.array([0.3, -0.1, 0.6])).astype(np.float32)
+        if i == 0:
+            pc[10:20] = pc[0:10]  # duplicates: zero distances and ties
+        _, centers = P.farthest_points(pc, m, P.distance_by_translation_point, return_center_indexes=True)
+        out[f"fps{i}_pc"], out[f"fps{i}_idx"] = pc, centers.astype(np.int32)
+    pc = out["fps1_pc"]
+    out["reg_fps"] = P.regularize_pc_point_count(pc, 1024, use_farthest_point=True)
+    np.random.seed(11)
+    out["reg_down"] = P.regularize_pc_point_count(pc, 1024, use_farthest_point=False)
+    np.random.seed(12)
+    out["reg_up"] = P.regularize_pc_point_count(out["fps0_pc"], 1024)
+    torch.manual_seed(13)
+    out["regt_up"] = P.regularize_pointcloud(torch.from_numpy(out["fps0_pc"]), 1024).numpy()
+    torch.manual_seed(14)
+    out["regt_down"] = P.regularize_pointcloud(torch.from_numpy(pc), 1024).numpy()
+    _save("front_end.npz", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "front_end":
+        os.makedirs(OUT, exist_ok=True)
+        front_end_golden()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pvcnn2":  # add this one fixture without rewriting the others
         os.makedirs(OUT, exist_ok=True)
         torch.set_num_threads(8)

@@ -1,0 +1,131 @@
+"""Raw-cloud front end: point-count regularisation + normalize_input.
+CPU part: the numpy / torch oracle restatement against vectors captured from the reference's own
+PointCloudHelpers (tests/golden/front_end.npz, `python -m oracle.make_golden front_end`).
+GPU part: the HIP path (gldm_farthest_points_euclid / gldm_gather_points / gldm_normalize_cloud through
+graspldm_amd.pointcloud) against the same vectors: indices and gathered rows bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+N_CASES = 4
+
+
+def test_oracle_farthest_points_matches_reference_vectors():
+    from oracle import front_end as F
+    g = load_golden("front_end.npz")
+    for i in range(N_CASES):
+        pc, idx = g[f"fps{i}_pc"].numpy(), g[f"fps{i}_idx"].numpy()
+        assert np.array_equal(F.farthest_points(pc, len(idx)), idx)
+
+
+def test_oracle_regularize_matches_reference_vectors():
+    from oracle import front_end as F
+    g = load_golden("front_end.npz")
+    pc, small = g["fps1_pc"].numpy(), g["fps0_pc"].numpy()
+    assert np.array_equal(F.regularize_pc_point_count(pc, 1024, True), g["reg_fps"].numpy())
+    np.random.seed(11)
+    assert np.array_equal(F.regularize_pc_point_count(pc, 1024, False), g["reg_down"].numpy())
+    np.random.seed(12)
+    assert np.array_equal(F.regularize_pc_point_count(small, 1024), g["reg_up"].numpy())
+    torch.manual_seed(13)
+    assert torch.equal(F.regularize_pointcloud(torch.from_numpy(small), 1024), g["regt_up"])
+    torch.manual_seed(14)
+    assert torch.equal(F.regularize_pointcloud(torch.from_numpy(pc), 1024), g["regt_down"])
+
+
+def test_front_end_rejects_cpu_tensors():
+    from graspldm_amd import pointcloud as P
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        P.normalize_input(torch.zeros(10, 3))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        P.PointCloudHelpers.regularize_pc_point_count(torch.zeros(10, 3), 4, True)
+
+
+gpu = pytest.mark.gpu
+
+
+@gpu
+def test_farthest_points_golden_bit_exact():
+    from graspldm_amd.pointcloud import PointCloudHelpers as P, farthest_point_indices
+    g = load_golden("front_end.npz")
+    for i in range(N_CASES):
+        pc, idx = g[f"fps{i}_pc"].cuda(), g[f"fps{i}_idx"]
+        got = P.farthest_points(pc, idx.numel(), return_center_indexes=True)
+        assert torch.equal(got.cpu(), idx), i
+    # batched call = per-cloud calls
+    pcs = torch.stack([g["fps1_pc"][:1400], g["fps2_pc"][:1400]]).cuda()
+    both = farthest_point_indices(pcs, 256)
+    for b in range(2):
+        assert torch.equal(both[b], farthest_point_indices(pcs[b], 256)[0])
+
+
+@gpu
+def test_farthest_points_random_clouds_vs_oracle():
+    from oracle import front_end as F
+    from graspldm_amd.pointcloud import farthest_point_indices
+    rng = np.random.RandomState(3)
+    for n, m in [(65, 64), (777, 100), (5000, 300), (8192, 64)]:
+        pc = rng.standard_normal((n, 3)).astype(np.float32)
+        pc[n // 2] = pc[0]  # an exact duplicate of the first centre
+        got = farthest_point_indices(torch.from_numpy(pc).cuda(), m)[0].cpu().numpy()
+        assert np.array_equal(got, F.farthest_points(pc, m)), (n, m)
+
+
+@gpu
+def test_regularize_point_count_golden():
+    from graspldm_amd.pointcloud import PointCloudHelpers as P
+    g = load_golden("front_end.npz")
+    pc, small = g["fps1_pc"].cuda(), g["fps0_pc"].cuda()
+    assert torch.equal(P.regularize_pc_point_count(pc, 1024, True).cpu(), g["reg_fps"])
+    np.random.seed(11)
+    assert torch.equal(P.regularize_pc_point_count(pc, 1024, False).cpu(), g["reg_down"])
+    np.random.seed(12)
+    assert torch.equal(P.regularize_pc_point_count(small, 1024).cpu(), g["reg_up"])
+    torch.manual_seed(13)
+    assert torch.equal(P.regularize_pointcloud(small, 1024).cpu(), g["regt_up"])
+    torch.manual_seed(14)
+    assert torch.equal(P.regularize_pointcloud(pc, 1024).cpu(), g["regt_down"])
+    same = P.regularize_pc_point_count(g["fps3_pc"].cuda(), 2500, True)
+    assert torch.equal(same.cpu(), g["fps3_pc"])
+
+
+@gpu
+def test_normalize_input_vs_oracle():
+    """f32 tolerance 1e-6 on the mean (f64 tree here vs torch's f32 sum), 2e-5 on the scaled cloud (x 20)."""
+    from oracle import front_end as F
+    from graspldm_amd.pointcloud import normalize_input
+    g = torch.Generator().manual_seed(2)
+    pc = torch.randn(3, 1024, 3, generator=g) * 0.07 + torch.tensor([0.4, -0.3, 0.9])
+    exp_pc, exp_m = F.normalize_input(pc)
+    got_pc, got_m = normalize_input(pc.cuda())
+    assert (got_pc.cpu() - exp_pc).abs().max() < 2e-5
+    for k in ("pc_mean", "pc_std", "grasp_mean", "grasp_std"):
+        assert got_m[k].shape == exp_m[k].shape, k
+        assert (got_m[k].cpu() - exp_m[k]).abs().max() < 1e-6, k
+    one_pc, one_m = normalize_input(pc[1].cuda())
+    assert one_pc.shape == (1024, 3) and torch.equal(one_pc, got_pc[1])
+    assert one_m["pc_mean"].shape == (3,) and one_m["grasp_mean"].shape == (1, 6)
+    assert torch.equal(pc, pc.clone())  # input left untouched
+
+
+@gpu
+def test_generate_on_pointcloud_regularises_and_matches_manual_path(fpc_state_dict):
+    from graspldm_amd.inference import InferenceLDM
+    from graspldm_amd.pointcloud import PointCloudHelpers as P
+    from test_modules_cpu import build_fpc
+    m = build_fpc(scheduler="ddim")
+    m.load_state_dict(fpc_state_dict, strict=True)
+    inf = InferenceLDM(model=m.cuda().eval(), num_inference_steps=5, device="cuda:0")
+    g = load_golden("front_end.npz")
+    raw = g["fps1_pc"].cuda()  # 1500 points, metres
+    torch.manual_seed(4)
+    out = inf.generate_on_pointcloud(raw, num_grasps=3, num_points=1024)
+    reg = P.regularize_pc_point_count(raw, 1024, True)
+    pcn, metas = inf.normalize_input(reg)
+    torch.manual_seed(4)
+    exp = inf.generate_grasps(pcn, metas, num_grasps=3)
+    # not bitwise: the library GEMM behind the encoder's k = 1 convs may pick another kernel on its first call
+    assert (out["grasps"] - exp["grasps"]).abs().max() < 1e-5 and out["grasps"].shape == (1, 3, 4, 4)
+    assert (out["pc"][0] - reg).abs().max() < 1e-6
