@@ -17,7 +17,7 @@ from enum import Enum
 import torch
 
 from .builder import build_model_from_cfg
-from .config import Config
+from .checkpoint import Experiment, fix_state_dict_prefix, load_weights as _load_weights, model_section  # noqa: F401
 from .r1d import pose_epilogue
 
 PC_STD, MRP_STD = 0.05, 0.5
@@ -34,57 +34,10 @@ class ModelType(Enum):
     VAE = "VAE"
 
 
-def fix_state_dict_prefix(state_dict, prefix="model", ignore_all_others=False):
-    """grasp_ldm/utils/torch_utils.py:4-37: strip `model.` / `ema_model.online_model.`."""
-    items = [(k, v) for k, v in state_dict.items() if not ignore_all_others or k.startswith(prefix)]
-    return type(state_dict)((k.partition(f"{prefix}.")[2], v) for k, v in items)
-
-
 def unnormalize_pc(pc, metas):
     if pc.ndim == 2:
         return pc * metas["pc_std"].to(pc.device) + metas["pc_mean"].to(pc.device)
     return pc * metas["pc_std"].unsqueeze(-2).to(pc.device) + metas["pc_mean"].unsqueeze(-2).to(pc.device)
-
-
-class Experiment:
-    """Experiment directory layout: {root}/{name}/{mode}/*.py + {mode}/checkpoints/last.ckpt."""
-
-    def __init__(self, exp_name, exp_out_root="output", modes=("vae", "ddm"), vae_ckpt_path=None,
-                 ddm_ckpt_path=None, **_):
-        self.exp_name = exp_name
-        self.exp_dir = os.path.join(exp_out_root, exp_name)
-        self._modes = list(modes)
-        if not os.path.isdir(self.exp_dir):
-            raise FileNotFoundError(f"No experiment directory `{exp_name}` found in `{exp_out_root}/`")
-        self._config_paths = {m: glob.glob(f"{self.exp_dir}/{m}/*.py") for m in self._modes}
-        manual = dict(vae=vae_ckpt_path, ddm=ddm_ckpt_path)
-        self._ckpt_paths = {}
-        for m in self._modes:
-            path = manual.get(m) if manual.get(m) and os.path.isfile(manual[m]) else f"{self.exp_dir}/{m}/checkpoints/last.ckpt"
-            if not os.path.isfile(path):
-                raise FileNotFoundError(f"For given mode ({m}) in `modes`:Could not find any checkpoint in ckpt path: {path}")
-            self._ckpt_paths[m] = path
-
-    def get_config(self, mode):
-        assert mode in self._modes, f"Could not find mode ({mode}) in experiment modes "
-        return Config.fromfile(self._config_paths[mode][0])
-
-    def get_ckpt_path(self, mode):
-        return self._ckpt_paths[mode]
-
-
-def _load_weights(model, ckpt_path, use_ema_model):
-    sd = torch.load(ckpt_path, map_location="cpu")["state_dict"]
-    prefix = "model" if not use_ema_model else "ema_model.online_model"
-    sd = fix_state_dict_prefix(sd, prefix, ignore_all_others=True)
-    try:
-        model.load_state_dict(sd, strict=True)
-    except Exception as e:
-        msg = "Error while loading state dict: You might be using an incompatible state dict. \n"
-        if use_ema_model:
-            msg += "EMA model is requested but may not be available. Check and set the `use_ema_model` flag appropriately. \n"
-        raise RuntimeError(msg + f"Error: {e}")
-    return model
 
 
 class _InferenceBase:
@@ -174,14 +127,10 @@ class InferenceLDM(_InferenceBase):
         if model is not None:
             self.model = model.to(self.device).eval()
         else:
-            self.experiment = Experiment(exp_name, exp_out_root, modes=["ddm"], ddm_ckpt_path=ddm_ckpt_path)
-            self.config = self.experiment.get_config("ddm")
-            key = "model" if "model" in self.config else "models"  # old configs use `models`
-            if use_fast_sampler:
-                self.config[key]["ddm"]["model"]["args"]["noise_scheduler_type"] = "ddim"
-            m = build_model_from_cfg(self.config[key]["ddm"])
-            m.set_vae_model(build_model_from_cfg(self.config[key]["vae"]))
-            self.model = _load_weights(m, self.experiment.get_ckpt_path("ddm"), use_ema_model).to(self.device).eval()
+            from .checkpoint import load_ldm_from_experiment
+            m, self.config, self.experiment = load_ldm_from_experiment(exp_name, exp_out_root, use_ema_model,
+                                                                        ddm_ckpt_path, use_fast_sampler)
+            self.model = m.to(self.device).eval()
         if load_dataset:
             warnings.warn("ACRONYM dataset loading is out of scope; use generate_grasps(pc, metas)")
 
@@ -207,11 +156,10 @@ class InferenceVAE(_InferenceBase):
         if model is not None:
             self.model = model.to(self.device).eval()
         else:
-            self.experiment = Experiment(exp_name, exp_out_root, modes=["vae"], vae_ckpt_path=vae_ckpt_path)
-            self.config = self.experiment.get_config("vae")
-            key = "model" if "model" in self.config else "models"
-            m = build_model_from_cfg(self.config[key]["vae"])
-            self.model = _load_weights(m, self.experiment.get_ckpt_path("vae"), use_ema_model).to(self.device).eval()
+            from .checkpoint import load_vae_from_experiment
+            m, self.config, self.experiment = load_vae_from_experiment(exp_name, exp_out_root, use_ema_model,
+                                                                        vae_ckpt_path)
+            self.model = m.to(self.device).eval()
 
     @torch.no_grad()
     def generate_grasps(self, pc, metas, num_grasps=10, z_h=None, **kwargs):

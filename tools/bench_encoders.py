@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Encoder shoot-out on one MI355X: the counterpart of the reference's only performance
+harness, `grasp_ldm/models/modules/ext/pvcnn/benchmark.py` (main :491-560: PVCNN vs PVCNN2 vs PointNet2SSG,
+batch sizes 1/4/16/64/256, 1024 points, 3 input channels, scale 0.5/0.5; metrics :31-41,62-145: average /
+p95 / p99 latency over timed iterations after warm-up, samples per second, peak memory, parameter size).
+
+Same models, constructor arguments, input distribution (randn [B,3,N]) and metric definitions, on the HIP
+path; no plots (matplotlib / seaborn are not in this image): a JSON file and a markdown table.  `--shipped`
+adds the encoder the shipped configs really use (PVCNNEncoder, scale 0.75/0.75).
+
+    python tools/bench_encoders.py --out profiles/r02_encoder_shootout.json
+"""
+import argparse
+import gc
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graspldm_amd.pvcnn import PVCNN, PVCNN2, PointNet2SSG  # noqa: E402
+from graspldm_amd.synthetic import load_synthetic_weights  # noqa: E402
+
+
+def measure_inference_time(model, x, num_iterations, warmup_iterations):
+    times = []
+    with torch.inference_mode():
+        for _ in range(warmup_iterations):
+            model(x)
+            torch.cuda.synchronize()
+        for _ in range(num_iterations):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            model(x)
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+    return np.array(times)
+
+
+def benchmark_model(model, batch_sizes, num_points, in_channels, num_iterations, warmup):
+    out = {}
+    param_mb = sum(p.numel() * p.element_size() for p in model.parameters()) / 2 ** 20
+    for b in batch_sizes:
+        torch.cuda.empty_cache()
+        gc.collect()
+        torch.cuda.reset_peak_memory_stats()
+        x = torch.randn(b, in_channels, num_points, device="cuda", dtype=torch.float32)
+        with torch.inference_mode():
+            model(x)
+            torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() / 2 ** 20
+        t = measure_inference_time(model, x, num_iterations, warmup)
+        out[b] = dict(avg_latency_ms=float(t.mean()), p95_latency_ms=float(np.percentile(t, 95)),
+                      p99_latency_ms=float(np.percentile(t, 99)), throughput_samples_per_sec=float(b * 1000 / t.mean()),
+                      peak_memory_mb=float(peak), model_parameters_mb=float(param_mb))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch-sizes", type=int, nargs="+", default=[1, 4, 16, 64, 256])
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--iterations", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shipped", action="store_true", help="also time PVCNNEncoder of the shipped fpc config")
+    ap.add_argument("--out", type=str, default=None)
+    args = ap.parse_args()
+    assert torch.cuda.is_available(), "needs the MI355X"
+    torch.manual_seed(0)
+    models = {
+        "PVCNN": PVCNN(in_channels=3, extra_feature_channels=0, scale_channels=0.5, scale_voxel_resolution=0.5),
+        "PVCNN2": PVCNN2(in_channels=3, extra_feature_channels=0, width_multiplier=0.5, voxel_resolution_multiplier=0.5),
+        "PointNet2": PointNet2SSG(extra_feature_channels=0, width_multiplier=1, voxel_resolution_multiplier=1),
+    }
+    if args.shipped:
+        from graspldm_amd.pc_encoders import PVCNNEncoder
+
+        class _Tr(torch.nn.Module):  # the encoder takes [B,N,3]
+            def __init__(self, m):
+                super().__init__()
+                self.m = m
+
+            def forward(self, x):
+                return self.m(x.transpose(1, 2))
+        models["PVCNNEncoder(fpc)"] = _Tr(PVCNNEncoder(in_features=3, out_features=64, n_points=args.points,
+                                                       scale_channels=0.75, scale_voxel_resolution=0.75,
+                                                       num_blocks=(1, 1, 1, 1), out_channels=3))
+    results = {}
+    for name, m in models.items():
+        load_synthetic_weights(m, seed=0)
+        m = m.cuda().eval()
+        results[name] = benchmark_model(m, args.batch_sizes, args.points, 3, args.iterations, args.warmup)
+        for b, r in results[name].items():
+            print(f"{name:18s} B={b:4d}  avg {r['avg_latency_ms']:8.3f} ms  p95 {r['p95_latency_ms']:8.3f}  "
+                  f"{r['throughput_samples_per_sec']:10.1f} clouds/s  peak {r['peak_memory_mb']:8.1f} MB", flush=True)
+    ref = "PVCNN"
+    lines = ["| Batch Size | Model | Avg Latency (ms) | P95 (ms) | P99 (ms) | Throughput (clouds/s) | Peak Memory (MB) | "
+             "Relative Speedup | Parameters (MB) |", "|---|---|---|---|---|---|---|---|---|"]
+    for b in args.batch_sizes:
+        for name, res in results.items():
+            r = res[b]
+            lines.append(f"| {b} | {name} | {r['avg_latency_ms']:.3f} | {r['p95_latency_ms']:.3f} | {r['p99_latency_ms']:.3f} | "
+                         f"{r['throughput_samples_per_sec']:.1f} | {r['peak_memory_mb']:.1f} | "
+                         f"{results[ref][b]['avg_latency_ms'] / r['avg_latency_ms']:.2f}x | {r['model_parameters_mb']:.1f} |")
+    table = "\n".join(lines)
+    print(table)
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(dict(gpu=torch.cuda.get_device_name(), torch=torch.__version__, points=args.points,
+                           iterations=args.iterations, results=results), f, indent=1)
+        with open(os.path.splitext(args.out)[0] + ".md", "w") as f:
+            f.write(f"# Encoder shoot-out ({torch.cuda.get_device_name()}, {args.points} points, f32, "
+                    f"{args.iterations} timed iterations)\n\n`python tools/bench_encoders.py"
+                    f"{' --shipped' if args.shipped else ''}`; models and metrics as in the reference's "
+                    "ext/pvcnn/benchmark.py.\n\n" + table + "\n")
+
+
+if __name__ == "__main__":
+    main()
