@@ -35,7 +35,7 @@ _SIGNATURES = {
     "gldm_gather_points": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "gldm_sa_group": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "gldm_r1d_cond_embed": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
-    "gldm_denoise": [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "gldm_denoise": [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "gldm_decode": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "gldm_pose_epilogue": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gldm_conv3d_k3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],

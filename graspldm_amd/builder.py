@@ -6,9 +6,10 @@ from .config import ConfigDict, _wrap
 from .diffusion import GaussianDiffusion1D
 from .grasp_ldm import GraspLatentDDM
 from .grasp_vae import GraspCVAE
-from .resnets import ResNet1D, TimeConditionedResNet1D
+from .resnets import ClassTimeConditionedResNet1D, ResNet1D, TimeConditionedResNet1D
 
-DIFFUSION_MODELS = {"GaussianDiffusion1D": GaussianDiffusion1D, "TimeConditionedResNet1D": TimeConditionedResNet1D}
+DIFFUSION_MODELS = {"GaussianDiffusion1D": GaussianDiffusion1D, "TimeConditionedResNet1D": TimeConditionedResNet1D,
+                    "ClassTimeConditionedResNet1D": ClassTimeConditionedResNet1D}
 STANDARD_MODULES = {"ResNet1D": ResNet1D}
 ALL_MODELS = {"GraspCVAE": GraspCVAE, "GraspLatentDDM": GraspLatentDDM, **STANDARD_MODULES, **DIFFUSION_MODELS}
 

@@ -955,6 +955,7 @@ struct RunArgs {
   const float *weights;
   const float *temb;      // [T][E] or null
   const float *cemb;      // [n_cond][R][E]
+  const float *semb;      // [n][E] per-sample embedding added to the time embedding (class conditioning), or null
   int samples_per_cond;
   const float *x_in;      // denoise: [n][L]; decode: z_h [n][D]
   int n_samples;
@@ -1308,6 +1309,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
         const int t = a.sample_t ? a.sample_t[gi] : a.timesteps[step];
         te = a.temb[(size_t)t * E + e];
       }
+      if (a.semb) te += a.semb[(size_t)gi * E + e];  // latent_emb += cls_emb (class_conditioned_resnet.py:99-101)
       float g = 0.f;
       for (int r = 0; r < R; ++r) g += silu(te + ce[r * E]);
       G[s * E + e] = g;
@@ -1653,8 +1655,8 @@ GLDM_API long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_sam
 GLDM_API int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,
                           int samples_per_cond, const float *x_in, int n_samples, const int32_t *timesteps,
                           const int32_t *sample_t, int n_steps, int sched_kind, int clip_sample,
-                          const float *sched_coef, const float *step_noise, float *x_out, void *workspace,
-                          gldm_stream_t stream) {
+                          const float *sched_coef, const float *step_noise, const float *sample_emb, float *x_out,
+                          void *workspace, gldm_stream_t stream) {
   int st = validate(desc);
   if (st != GLDM_OK) return st;
   if (!weights || !cemb || !x_in || !x_out || !workspace || n_samples <= 0 || n_steps <= 0 || samples_per_cond <= 0)
@@ -1665,7 +1667,7 @@ GLDM_API int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const
   if (sched_kind == GLDM_SCHED_NONE && n_steps != 1) return GLDM_ERR_INVALID_ARG;
   RunArgs a{};
   a.d = *desc;
-  a.weights = weights; a.temb = temb; a.cemb = cemb; a.samples_per_cond = samples_per_cond;
+  a.weights = weights; a.temb = temb; a.cemb = cemb; a.semb = sample_emb; a.samples_per_cond = samples_per_cond;
   a.x_in = x_in; a.n_samples = n_samples; a.timesteps = timesteps; a.sample_t = sample_t; a.n_steps = n_steps;
   a.sched_kind = sched_kind; a.clip_sample = clip_sample; a.sched_coef = sched_coef; a.step_noise = step_noise;
   a.out0 = x_out; a.out1 = nullptr; a.ws = reinterpret_cast<float *>(workspace);

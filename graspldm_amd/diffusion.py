@@ -140,15 +140,19 @@ class GaussianDiffusion1D(nn.Module):
         model._cond_rows_of(z_cond)
         eng = model.engine(device)
         cemb = eng.cond_embed(z_cond.to(device))
+        # class-conditioned denoiser: the label travels in kwargs (cls_cond or metas["mode_cls"]) to the model
+        # call in the reference (gaussian_diffusion.py:271); here it becomes one [n, emb] operand of the launch
+        semb = model.class_embedding(kwargs.get("cls_cond"), n=batch_size, metas=kwargs.get("metas")) \
+            if hasattr(model, "class_embedding") else None
         if not return_all:
             x = eng.denoise(x_T, cemb, samples_per_cond, timesteps=ts, sched_kind=kind, clip_sample=self.clip_sample,
-                            coef=coef, step_noise=step_noise)
+                            coef=coef, step_noise=step_noise, sample_emb=semb)
             return x, []
         trace, x = [x_T], x_T
         for i in range(ts.numel()):
             x = eng.denoise(x, cemb, samples_per_cond, timesteps=ts[i:i + 1], sched_kind=kind,
                             clip_sample=self.clip_sample, coef=coef[i:i + 1],
-                            step_noise=None if step_noise is None else step_noise[i:i + 1])
+                            step_noise=None if step_noise is None else step_noise[i:i + 1], sample_emb=semb)
             trace.append(x)
         return x, trace
 

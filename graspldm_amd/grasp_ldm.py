@@ -45,7 +45,10 @@ class GraspLatentDDM(nn.Module):
         Returns ((tmrp [B*G,6], cls_logit [B*G,1]), intermediates)."""
         z_pc = self.vae_model.encode_pc(xyz)
         n = z_pc.shape[0] * num_grasps
-        kwargs.pop("metas", None)  # travels through **kwargs in the reference and is ignored (resnets.py:565)
+        # `metas` travels through **kwargs down to the denoiser call in the reference; TimeConditionedResNet1D
+        # ignores it (resnets.py:565), the class-conditioned one reads metas["mode_cls"] (class_conditioned_resnet.py:73)
+        if not hasattr(self.diffusion_model.model, "class_embedding"):
+            kwargs.pop("metas", None)
         kwargs.setdefault("device", xyz.device)
         out, all_outs = self.diffusion_model.sample(z_cond=z_pc, batch_size=n, return_all=return_intermediate,
                                                     samples_per_cond=num_grasps, **kwargs)

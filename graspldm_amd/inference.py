@@ -99,15 +99,27 @@ class _InferenceBase:
 
     generate_on_pointcloud = infer_on_pointcloud
 
+    def generate_class_conditioned_grasps(self, pc, num_grasps=10, metas=None, data_idx=None, class_label=0, **kwargs):
+        """tools/inference.py:330-364: the label, repeated per grasp, travels in metas["mode_cls"] to the
+        class-conditioned denoiser (ClassTimeConditionedResNet1D).  One cloud, like the reference."""
+        metas = dict(metas)
+        metas["mode_cls"] = torch.LongTensor([class_label]).unsqueeze(0).repeat((num_grasps, 1)).to(
+            self.device, dtype=torch.float32)
+        return self.generate_grasps(pc, metas=metas, num_grasps=num_grasps, **kwargs)
+
     def infer(self, data_idx=None, num_grasps=10, visualize=False, condition_type=Conditioning.UNCONDITIONAL,
               conditioning=None, **kwargs):
         if self.dataset is None:
             raise RuntimeError("no dataset attached: ACRONYM loading is out of scope; call generate_grasps(pc, metas) "
                                "with a dataset-contract item (graspldm_amd.synthetic.normalize_cloud)")
-        if condition_type != Conditioning.UNCONDITIONAL:
-            raise NotImplementedError("class / region conditioned denoisers are not shipped (out of scope)")
+        if condition_type == Conditioning.REGION_CONDITIONED:
+            raise NotImplementedError("region conditioned denoisers are not shipped (out of scope)")
         item = self.dataset[data_idx if data_idx is not None else 0]
-        res = self.generate_grasps(item["pc"], item["metas"], num_grasps=num_grasps, **kwargs)
+        if condition_type == Conditioning.CLASS_CONDITIONED:
+            res = self.generate_class_conditioned_grasps(item["pc"], num_grasps=num_grasps, metas=item["metas"],
+                                                         class_label=conditioning, **kwargs)
+        else:
+            res = self.generate_grasps(item["pc"], item["metas"], num_grasps=num_grasps, **kwargs)
         res["inputs"] = dict(item)
         return res
 
@@ -141,7 +153,9 @@ class InferenceLDM(_InferenceBase):
             self.model.set_inference_timesteps(self.num_inference_steps)
         if return_intermediate and batch.shape[0] > 1:  # the reference raises after sampling; fail before the work
             raise NotImplementedError("Batched grasps for all diffusion steps are not implemented")
-        extra = {k: kwargs[k] for k in ("step_noise",) if k in kwargs}
+        extra = {k: kwargs[k] for k in ("step_noise", "cls_cond") if k in kwargs}
+        if hasattr(self.model.diffusion_model.model, "class_embedding"):
+            extra["metas"] = {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in metas.items()}
         (tmrp, logit), steps = self.model.generate_grasps(batch, num_grasps=num_grasps,
                                                           return_intermediate=return_intermediate, x_T=x_T, **extra)
         return self._results(batch, metas, tmrp, logit, batch.shape[0], num_grasps, all_steps=steps)

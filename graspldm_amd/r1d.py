@@ -52,17 +52,22 @@ class R1dEngine:
         return out
 
     def denoise(self, x_in, cemb, samples_per_cond, timesteps=None, sample_t=None, sched_kind=SCHED_NONE,
-                clip_sample=True, coef=None, step_noise=None):
-        """x_in [n, 1, L] -> x after all steps (or eps when sched_kind == NONE)."""
+                clip_sample=True, coef=None, step_noise=None, sample_emb=None):
+        """x_in [n, 1, L] -> x after all steps (or eps when sched_kind == NONE).  sample_emb [n, E]: per-sample
+        embedding added to the time embedding (class conditioning)."""
         n = x_in.shape[0]
         x_in = x_in.contiguous().float()
+        if sample_emb is not None:
+            sample_emb = sample_emb.reshape(n, -1).contiguous().float()
+            if sample_emb.shape[1] != self.cond_w.shape[0]:
+                raise RuntimeError(f"sample_emb must be [n, {self.cond_w.shape[0]}]")
         out = torch.empty_like(x_in)
         n_steps = 1 if timesteps is None else int(timesteps.numel())
         ws = self._workspace(n)
         with torch.cuda.device(self.device):
             L.call("gldm_denoise", self._desc_ptr(), L.ptr(self.weights), L.ptr(self.temb), L.ptr(cemb),
                    int(samples_per_cond), L.ptr(x_in), n, L.ptr(timesteps), L.ptr(sample_t), n_steps, int(sched_kind),
-                   1 if clip_sample else 0, L.ptr(coef), L.ptr(step_noise), L.ptr(out), L.ptr(ws),
+                   1 if clip_sample else 0, L.ptr(coef), L.ptr(step_noise), L.ptr(sample_emb), L.ptr(out), L.ptr(ws),
                    L.current_stream(self.device))
         return out
 

@@ -209,6 +209,52 @@ class TimeConditionedResNet1D(_ResNet1DBase):
                            sched_kind=SCHED_NONE)
 
 
-__all__ = ["ResNet1D", "TimeConditionedResNet1D", "ResnetBlock", "LinearAttention", "LayerNorm",
+class ClassTimeConditionedResNet1D(TimeConditionedResNet1D):
+    """grasp_ldm/models/modules/class_conditioned_resnet.py:9-122: the time-conditioned denoiser with a class
+    embedding (Linear(1, emb) + SiLU of the class label) added to the time embedding of every sample before the
+    conditioning embedding.  In the fused engine that is one extra [n, emb] operand of gldm_denoise."""
+
+    def __init__(self, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.cls_embed = nn.Sequential(nn.Linear(1, self.emb_dim), nn.SiLU())
+
+    def class_embedding(self, cls_cond=None, n=None, **kwargs):
+        """cls_embed(cls_cond) as [n, emb] (class_conditioned_resnet.py:72-82,99-100).  The label comes from
+        `cls_cond` or, like in the reference, from kwargs["metas"]["mode_cls"]."""
+        if cls_cond is None:
+            metas = kwargs.get("metas")
+            assert metas is not None and "mode_cls" in metas, "Class conditioning tensor is required"
+            cls_cond = metas["mode_cls"]
+        lin = self.cls_embed[0]
+        cls_cond = cls_cond.to(device=lin.weight.device, dtype=torch.float32).unsqueeze(-1).reshape(-1, 1)
+        if not cls_cond.is_cuda:
+            raise RuntimeError("the model must be on the GPU (graspldm_amd has no CPU path)")
+        if n is not None and cls_cond.shape[0] != n:
+            raise RuntimeError(f"class labels for {cls_cond.shape[0]} samples, batch of {n}")
+        from . import _lib as L
+        m = cls_cond.shape[0]
+        out = torch.empty((m, self.emb_dim), dtype=torch.float32, device=cls_cond.device)
+        w, b = lin.weight.detach().contiguous().float(), lin.bias.detach().contiguous().float()
+        with torch.cuda.device(out.device):  # Linear(1, E) + SiLU = the conditioning-embedding kernel with Dc = 1
+            L.call("gldm_r1d_cond_embed", L.ptr(cls_cond.contiguous()), L.ptr(w), L.ptr(b), m, 1, 1, self.emb_dim,
+                   L.ptr(out), L.current_stream(out.device))
+        return out
+
+    @torch.no_grad()
+    def forward(self, x, *, time=None, z_cond=None, x_self_cond=None, cls_cond=None, **kwargs):
+        assert time is not None
+        if not x.is_cuda:
+            raise RuntimeError("x must be a CUDA tensor (graspldm_amd has no CPU path)")
+        tmax = int(time.max())
+        if tmax >= self.max_timesteps:
+            self.max_timesteps = tmax + 1
+        self._cond_rows_of(z_cond)
+        eng = self.engine(x.device)
+        semb = self.class_embedding(cls_cond, n=x.shape[0], **kwargs)
+        return eng.denoise(x, eng.cond_embed(z_cond), 1, sample_t=time.to(torch.int32).contiguous(),
+                           sched_kind=SCHED_NONE, sample_emb=semb)
+
+
+__all__ = ["ResNet1D", "TimeConditionedResNet1D", "ClassTimeConditionedResNet1D", "ResnetBlock", "LinearAttention", "LayerNorm",
            "WeightStandardizedConv2d", "RandomOrLearnedSinusoidalPosEmb"]
 _ = math

@@ -216,12 +216,16 @@ long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples);
  *    sample_t (optional, [n]) then gives a per-sample timestep.
  *  - temb is the host-precomputed time_mlp table [T, E] (resnets.py:517-522).
  *  - sample i is conditioned on cemb[i / samples_per_cond].
- *  - step_noise [n_steps, n, D] is read by DDPM steps with coef[7] != 0. */
+ *  - step_noise [n_steps, n, D] is read by DDPM steps with coef[7] != 0.
+ *  - sample_emb [n, E] (optional) is added to the time embedding of each sample before the
+ *    conditioning embedding: the class embedding of ClassTimeConditionedResNet1D
+ *    (grasp_ldm/models/modules/class_conditioned_resnet.py:43-46,99-101). */
 int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,
                  int samples_per_cond, const float *x_in /*[n,1,L]*/, int n_samples,
                  const int32_t *timesteps /*[n_steps]*/, const int32_t *sample_t, int n_steps,
                  int sched_kind, int clip_sample, const float *sched_coef /*[n_steps,8]*/,
-                 const float *step_noise, float *x_out /*[n,1,L]*/, void *workspace, gldm_stream_t stream);
+                 const float *step_noise, const float *sample_emb, float *x_out /*[n,1,L]*/, void *workspace,
+                 gldm_stream_t stream);
 
 /* ref: grasp_ldm/models/grasp_vae.py:401-436 (ConditionalGraspPoseDecoder.forward:
  * in_layer -> ResNet1D -> tmrp / class_logits heads). */

@@ -212,7 +212,35 @@ def front_end_golden():
     _save("front_end.npz", **out)
 
 
+def class_cond_golden():
+    """the reference's ClassTimeConditionedResNet1D (class_conditioned_resnet.py) with the fpc
+    denoiser arguments, recipe weights (seed 5), 8 samples, labels 0..3, at t = 0, 500, 999."""
+    import json
+    ref_import.install_shims()
+    from grasp_ldm.models.modules.class_conditioned_resnet import ClassTimeConditionedResNet1D
+    m = ClassTimeConditionedResNet1D(dim=4, channels=1, block_channels=(32, 64, 128, 256), input_conditioning_dims=64,
+                                     resnet_block_groups=4, dropout=0.1, is_time_conditioned=True,
+                                     learned_variance=False, learned_sinusoidal_cond=False, random_fourier_features=True)
+    synthetic.load_synthetic_weights(m, seed=5)
+    m.eval()
+    _schema("schema_class_denoiser.json", m)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(8, 1, 4, generator=g)
+    zc = torch.randn(8, 3, 64, generator=g)
+    cls = torch.tensor([0, 1, 2, 3, 3, 2, 1, 0], dtype=torch.float32).reshape(8, 1)
+    ts = [0, 500, 999]
+    with torch.no_grad():
+        eps = torch.stack([m(x, time=torch.full((8,), t, dtype=torch.long), z_cond=zc, cls_cond=cls) for t in ts])
+        via_metas = m(x, time=torch.full((8,), 500, dtype=torch.long), z_cond=zc, metas={"mode_cls": cls})
+    assert torch.equal(via_metas, eps[1])
+    _save("class_denoiser.npz", x=x, z_cond=zc, cls=cls, t=np.array(ts), eps=eps)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "class_cond":
+        os.makedirs(OUT, exist_ok=True)
+        class_cond_golden()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "front_end":
         os.makedirs(OUT, exist_ok=True)
         front_end_golden()

@@ -91,12 +91,16 @@ def time_embedding(sd, p, time):
     return F.linear(F.gelu(h), sd[p + "time_mlp.3.weight"], sd[p + "time_mlp.3.bias"])
 
 
-def resnet1d_forward(sd, p, x, z_cond=None, time=None, groups=4):
+def resnet1d_forward(sd, p, x, z_cond=None, time=None, groups=4, cls_cond=None):
     """TimeConditionedResNet1D.forward (resnets.py:558-616) when `time` is given,
     ResNet1D.forward (resnets.py:373-424) otherwise.  x [B,1,D]; z_cond [B,R,Dc]
-    or [B,Dc]; eval mode (dropout = identity)."""
+    or [B,Dc]; eval mode (dropout = identity).  cls_cond [B,1]: the class-conditioned variant
+    (class_conditioned_resnet.py:48-122): latent_emb += SiLU(Linear(1, emb)(cls_cond))."""
     x = F.conv1d(x, sd[p + "init_conv.weight"], sd[p + "init_conv.bias"], padding=3)
     emb = time_embedding(sd, p, time) if time is not None else None
+    if cls_cond is not None:
+        emb = emb + F.silu(F.linear(cls_cond.reshape(-1, 1).float(), sd[p + "cls_embed.0.weight"],
+                                    sd[p + "cls_embed.0.bias"]))
     if (p + "input_emb_layers.0.weight") in sd:
         ie = F.silu(F.linear(z_cond, sd[p + "input_emb_layers.0.weight"], sd[p + "input_emb_layers.0.bias"]))
         if emb is not None and ie.ndim == 3:
