@@ -337,6 +337,73 @@ __device__ __forceinline__ void gemm_fast_tap3(const Ctx &c, const float *__rest
         acc[mi][ni][r] += tap_left<L>(side[0][mi][ni][r], keepL) + tap_right<L>(side[1][mi][ni][r], keepR);
 }
 
+// ---- position-major k = 3 convs (L = 4 positions, 64-column tiles of 16 samples) ----------------------
+// Column = 16 * position + sample, so a 16-column n-tile is ONE position of all 16 samples and the conv is
+//   out_tile[p] = W1 * X_tile[p] + W0 * X_tile[p - 1] + W2 * X_tile[p + 1]      (tiles outside 0..3 do not exist)
+// The zero-padding products of the sample-major layout (tap 0 on a sample's first position, tap 2 on its last:
+// 2 of every 12 tile-MFMAs) are simply never issued, there are no side accumulators and no halo shift of
+// the results: 10 MFMAs per (m-tile, k-step) instead of 12, straight into the output accumulators.
+// A wave computes out tiles P0 .. P0+NP-1 for MT m-tiles; B tiles PB0 .. PB1 are read once per k-block and
+// shared by the three taps.  Same packed weights as the sample-major path (k = tap * Cin + ci).
+template <int MT, int P0, int NP>
+__device__ __forceinline__ void gemm_pm3(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0,
+                                         const float *src, f32x4 (&acc)[MT][NP]) {
+  constexpr int NC = 64;
+  constexpr int PB0 = P0 > 0 ? P0 - 1 : 0, PB1 = P0 + NP < 4 ? P0 + NP : 3, NB = PB1 - PB0 + 1;
+  const int col = c.lane & 15, kq = c.lane >> 4;
+  const int kblocks = 3 * cblocks;
+  gf4p wv = (gf4p)(reinterpret_cast<const f32x4 *>(wp) + c.lane);
+  int boff[4][NB];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < NB; ++q) boff[j][q] = swz<NC>(4 * j + kq, 16 * (PB0 + q) + col);
+  f32x4 a[3][MT];
+  float b[2][4][NB];
+  const lds_f *src3 = (const lds_f *)src;
+  auto load_b = [&](int buf, int cb) {
+    const lds_f *s = src3 + cb * 16 * NC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < NB; ++q) b[buf][j][q] = s[boff[j][q]];
+  };
+  const int last = cblocks - 1;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) a[t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks) * 64];
+  load_b(0, 0);
+  for (int cb0 = 0; cb0 < cblocks; cb0 += 2) {  // two blocks per trip: the B double buffer alternates statically
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int cb = cb0 + u;
+      const int nb = cb + 1 < last ? cb + 1 : last;  // clamped: the loads stay unconditional
+      load_b(1 - u, nb);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              constexpr int dummy = 0;
+              (void)dummy;
+              const int sp = P0 + p + t - 1;  // source position of this tap for out tile P0 + p
+              if (sp >= 0 && sp <= 3)
+                acc[mi][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][mi][j], b[u][j][sp - PB0 < 0 ? 0 : (sp - PB0 >= NB ? NB - 1 : sp - PB0)],
+                                                                  acc[mi][p], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) a[t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks + nb) * 64];
+      }
+    }
+  }
+}
+
 template <int NC, int L, int TAPS, int MT, int NT>
 __device__ __forceinline__ void gemm_fast(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0, int nt0,
                                           const float *src, f32x4 (&acc)[MT][NT]) {
@@ -647,6 +714,328 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
 
 #undef GLDM_LOAD_GN_PARAMS
 
+constexpr int kOpInts = 12, kMaxOps = 84;  // op tape: 84 * 12 = 1008 ints; the op count lives in int 1023
+
+// =========================================================================================================
+// Position-major engine pieces (L = 4, 64-column tiles = 16 samples x 4 positions, column = 16 * pos + sample,
+// 8 waves, one workgroup per CU).  1x1 convs, LayerNorm and the final 1x1 are layout agnostic and shared with
+// the sample-major engine; what follows are the layout-aware phases.
+// =========================================================================================================
+
+// One wave's share of a k = 3 conv: MT m-tiles x out positions P0..P0+NP-1, with the GroupNorm / scale-shift /
+// SiLU / residual epilogue.  A group's rows no longer sit in one wave (8 waves share 16 m-tiles and the taps
+// tie the 4 position tiles together), so the statistics are combined across waves: every wave reduces its own
+// share to (sum, M2 about its own mean) per sample -- in-lane over its accumulators, permlane swaps over the
+// row quarters -- publishes the pair in LDS, and after ONE barrier merges its partners' pairs with the
+// parallel-variance formula (exact for equal counts, no E[x^2] - m^2 cancellation).
+//   GK 0: partner = the adjacent wave (C = 256: 2 m-tiles per wave, C = 128: 1; all 4 positions)
+//   GK 1: partner = wave ^ 4 (C = 64: one m-tile = one group, positions split in two halves)
+//   GK 2: four waves (one per position) x two groups per m-tile (C = 32: 8 channels per group)
+template <int MT, int P0, int NP, int GK>
+__device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, const float *bias, int mt0,
+                                              const float *src, int cin, float *dst, int cout, bool alias,
+                                              const GnEpilogue &g) {
+  using GG = Geo<64>;
+  constexpr int NC = 64;
+  const int kq = c.lane >> 4, sm = c.lane & 15;
+  f32x4 acc[MT][NP];
+  const bool has_ss = g.ss_w >= 0;
+  const int ekb = g.E >> 4;
+  gf4p wss = (gf4p)(reinterpret_cast<const f32x4 *>(c.w + (has_ss ? g.ss_w : 0)) + c.lane);
+  f32x4 ga[MT], be[MT], sc[MT], sh[MT], a_sc[MT], a_sh[MT];
+  if (g.mode) {  // every epilogue parameter is requested before the k-sweep: its round trip hides behind the GEMM
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int mt = mt0 + mi, row0 = 16 * mt + 4 * kq;
+      ga[mi] = *reinterpret_cast<const f32x4 *>(c.w + g.gamma_off + row0);
+      be[mi] = *reinterpret_cast<const f32x4 *>(c.w + g.beta_off + row0);
+      sc[mi] = f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (has_ss) {
+        const float *sb = c.w + g.ss_b;
+        sc[mi] = *reinterpret_cast<const f32x4 *>(sb + row0);
+        sh[mi] = *reinterpret_cast<const f32x4 *>(sb + g.C + row0);
+        a_sc[mi] = wss[(size_t)mt * ekb * 64];
+        a_sh[mi] = wss[(size_t)((g.C >> 4) + mt) * ekb * 64];
+      }
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + 16 * (mt0 + mi) + 4 * kq);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[mi][p] = bv;
+  }
+  gemm_pm3<MT, P0, NP>(c, wp, cin >> 4, mt0, src, acc);
+  if (!g.mode) {
+    if (alias) __syncthreads();
+    lds_f *d3 = (lds_f *)dst;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) d3[swz<NC>(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm)] = acc[mi][p][r];
+    return;
+  }
+  // ---- this wave's share of the statistics, per sample (= lane & 15)
+  constexpr int kNloc = GK == 2 ? 8 * NP : 16 * MT * NP;  // values behind one published pair
+  constexpr int kParts = GK == 2 ? 4 : 2;
+  float s1 = 0.f;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s1 += acc[mi][p][r];
+  s1 = row_pair_sum(s1);
+  if (GK != 2) s1 = half_sum(s1);
+  const float mloc = s1 * (1.0f / (float)kNloc);
+  float s2 = 0.f;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dx = acc[mi][p][r] - mloc;
+        s2 += dx * dx;
+      }
+  s2 = row_pair_sum(s2);
+  if (GK != 2) s2 = half_sum(s2);
+  lds_f *red1 = (lds_f *)(c.lds + GG::kMiscRed1), *red2 = (lds_f *)(c.lds + GG::kMiscRed2);
+  const int slot = GK == 2 ? (kq >> 1) : 0;
+  if ((kq & (GK == 2 ? 1 : 3)) == 0) {
+    red1[(c.wave * 2 + slot) * 16 + sm] = s1;
+    red2[(c.wave * 2 + slot) * 16 + sm] = s2;
+  }
+  __syncthreads();
+  float tot = 0.f, ps1[kParts], ps2[kParts];
+#pragma unroll
+  for (int q = 0; q < kParts; ++q) {
+    const int pw = GK == 0 ? ((c.wave & ~1) + q) : (GK == 1 ? ((c.wave & 3) + 4 * q) : ((c.wave & 1) + 2 * q));
+    ps1[q] = red1[(pw * 2 + slot) * 16 + sm];
+    ps2[q] = red2[(pw * 2 + slot) * 16 + sm];
+    tot += ps1[q];
+  }
+  const float mean = tot * (1.0f / (float)(kNloc * kParts));
+  float m2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < kParts; ++q) {
+    const float dm = ps1[q] * (1.0f / (float)kNloc) - mean;
+    m2 += ps2[q] + (float)kNloc * dm * dm;
+  }
+  const float rstd = __builtin_amdgcn_rsqf(m2 * (1.0f / (float)(kNloc * kParts)) + 1e-5f);
+  // ---- scale / shift rows of this lane's sample: the same for all positions, once per m-tile
+  if (has_ss) {
+    const lds_f *Gs = (const lds_f *)(c.lds + GG::kMiscG) + sm * g.E;
+    float gb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gb[j] = Gs[4 * j + kq];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_sc[mi][j], gb[j], sc[mi], 0, 0, 0);
+        sh[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_sh[mi][j], gb[j], sh[mi], 0, 0, 0);
+      }
+      for (int kb = 1; kb < ekb; ++kb) {
+        const int mt = mt0 + mi;
+        const f32x4 a2 = wss[((size_t)mt * ekb + kb) * 64], a3 = wss[((size_t)((g.C >> 4) + mt) * ekb + kb) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float bj = Gs[16 * kb + 4 * j + kq];
+          sc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j], bj, sc[mi], 0, 0, 0);
+          sh[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[j], bj, sh[mi], 0, 0, 0);
+        }
+      }
+    }
+  }
+  lds_f *d3 = (lds_f *)(g.mode == 2 ? g.res : dst);
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gsc = rstd * ga[mi][r];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        float y = (acc[mi][p][r] - mean) * gsc + be[mi][r];
+        if (has_ss) y = y * sc[mi][r] + sh[mi][r];
+        y = silu(y);
+        const int a = swz<NC>(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm);
+        d3[a] = g.mode == 2 ? d3[a] + y : y;
+      }
+    }
+}
+
+// Conv1d(4 -> cout, k = 3) of the first level (Cin = 4 is below the MFMA k-block): VALU, lane = column, wave w
+// computes output channels 4w .. 4w+3 (cout = 32).  Weights are wave uniform (scalar loads); fma chain in the
+// MFMA's k order (tap major, channel minor) from the bias.  src may alias dst.
+__device__ __forceinline__ void conv_pm3_cin4(const Ctx &c, const float *wp, const float *bias, const float *src,
+                                              float *dst, int cout, bool alias) {
+  constexpr int NC = 64;
+  const int n = c.lane, p = n >> 4;
+  const lds_f *s3 = (const lds_f *)src;
+  float x[3][4];
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci) {
+    const float l = s3[swz<NC>(ci, p > 0 ? n - 16 : n)], m = s3[swz<NC>(ci, n)], r = s3[swz<NC>(ci, p < 3 ? n + 16 : n)];
+    x[0][ci] = p > 0 ? l : 0.f;
+    x[1][ci] = m;
+    x[2][ci] = p < 3 ? r : 0.f;
+  }
+  float out[4];
+  const int per_wave = 4;
+#pragma unroll
+  for (int k = 0; k < per_wave; ++k) {
+    const int co = __builtin_amdgcn_readfirstlane(c.wave * per_wave + k);
+    const int cc = co < cout ? co : cout - 1;
+    float acc = bias ? bias[cc] : 0.f;
+    const float *wr = wp + (size_t)(cc >> 4) * 256 + (cc & 15) * 4;  // [(ci * 16 + co % 16) * 4 + tap]
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) acc = fmaf(wr[ci * 64 + t], x[t][ci], acc);
+    out[k] = acc;
+  }
+  if (alias) __syncthreads();
+  lds_f *d3 = (lds_f *)dst;
+#pragma unroll
+  for (int k = 0; k < per_wave; ++k) {
+    const int co = c.wave * per_wave + k;
+    if (co < cout) d3[swz<NC>(co, n)] = out[k];
+  }
+}
+
+// ResnetBlock of the 4-channel level on the VALU of one wave: lane = column (16 samples x 4 positions), every
+// lane carries all 4 channels of its column.  Taps come from the lanes 16 below / above (the neighbouring
+// positions of the same sample), GroupNorm (one channel per group) reduces over lanes n ^ 16, n ^ 32.  Every
+// weight is wave uniform (scalar loads: nothing queues in the vector-memory path).
+__device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInts], int E) {
+  using GG = Geo<64>;
+  constexpr int NC = 64;
+  if (c.wave != 0) return;
+  const int n = c.lane, sm = n & 15, p = n >> 4;
+  const bool has_l = p != 0, has_r = p != 3;
+  lds_f *X = (lds_f *)(c.lds + GG::kBufX);
+  const lds_f *G = (const lds_f *)(c.lds + GG::kMiscG) + sm * E;
+  const float *w = c.w;
+  const int c1_w = o[1], c1_b = o[2], n1_w = o[3], n1_b = o[4], c2_w = o[5], c2_b = o[6], n2_w = o[7], n2_b = o[8],
+            ss_w = o[9], ss_b = o[10];
+  float x[4];
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci) x[ci] = X[swz<NC>(ci, n)];
+  float gq[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) gq[e] = e < E ? G[e] : 0.f;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int co = 0; co < 4; ++co) {
+    float a = w[ss_b + co], b = w[ss_b + 4 + co];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // W[row][e] at ((e & 3) * 16 + row) * 4 + (e >> 2), e = 4 j + kq
+        a += w[ss_w + (kq * 16 + co) * 4 + j] * gq[4 * j + kq];
+        b += w[ss_w + (kq * 16 + 4 + co) * 4 + j] * gq[4 * j + kq];
+      }
+    sc[co] = a;
+    sh[co] = b;
+  }
+  auto conv3 = [&](const float (&in)[4], int cw, int cb, float (&out)[4]) {
+    float lft[4], rgt[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const float a = __shfl(in[ci], (n + 48) & 63, 64), b = __shfl(in[ci], (n + 16) & 63, 64);
+      lft[ci] = has_l ? a : 0.f;
+      rgt[ci] = has_r ? b : 0.f;
+    }
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      float acc = w[cb + co];
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {  // W[co][ci][tap] at (ci * 16 + co) * 4 + tap
+        const float *wr = w + cw + (ci * 16 + co) * 4;
+        acc += wr[0] * lft[ci];
+        acc += wr[1] * in[ci];
+        acc += wr[2] * rgt[ci];
+      }
+      out[co] = acc;
+    }
+  };
+  auto gn_act = [&](float (&v)[4], int gw, int gb, bool ss) {
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      const float m = half_sum(row_pair_sum(v[co])) * 0.25f;
+      const float d = v[co] - m;
+      const float rs = __builtin_amdgcn_rsqf(half_sum(row_pair_sum(d * d)) * 0.25f + 1e-5f);
+      float y = d * rs * w[gw + co] + w[gb + co];
+      if (ss) y = y * sc[co] + sh[co];
+      v[co] = silu(y);
+    }
+  };
+  float y[4], z[4];
+  conv3(x, c1_w, c1_b, y);
+  gn_act(y, n1_w, n1_b, true);
+  conv3(y, c2_w, c2_b, z);
+  gn_act(z, n2_w, n2_b, false);
+#pragma unroll
+  for (int co = 0; co < 4; ++co) X[swz<NC>(co, n)] = x[co] + z[co];
+}
+
+// LinearAttention core for one head pair (qkv [192][64] -> 64 rows of o), position-major: wave = (head of the
+// pair, position), lane = (sample, part): 8 of the head's 32 channels at column 16 * position + sample.  The
+// sample's four key / value columns are the same lane's columns in the four position tiles; every reduction
+// over the parts is a permlane swap inside the wave: no LDS exchange, one barrier.
+__device__ __forceinline__ void attention_pair_pm(const Ctx &c, float *qkv, float *o_rows) {
+  constexpr int NC = 64;
+  if (GLDM_SKIP(c, 4)) return;
+  const lds_f *q3 = (const lds_f *)qkv;
+  lds_f *o3 = (lds_f *)o_rows;
+  const int h2 = c.wave >> 2, pq = c.wave & 3, sm = c.lane & 15, pt = c.lane >> 4, d0 = 8 * pt;
+  const int nn = 16 * pq + sm;
+  const int qr = h2 * kDimHead + d0, kr = 64 + h2 * kDimHead + d0, vr = 128 + h2 * kDimHead + d0;
+  float q[8];
+  float qmax = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    q[i] = q3[swz<NC>(qr + i, nn)];
+    qmax = fmaxf(qmax, q[i]);
+  }
+  float kv[8][4], vv[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kv[i][j] = q3[swz<NC>(kr + i, 16 * j + sm)];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vv[i][j] = q3[swz<NC>(vr + i, 16 * j + sm)];
+  qmax = half_max(row_pair_max(qmax));
+  float qsum = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float e = fast_exp(q[i] - qmax);
+    qsum += e;
+    const float km = fmaxf(fmaxf(kv[i][0], kv[i][1]), fmaxf(kv[i][2], kv[i][3]));
+    const float k0 = fast_exp(kv[i][0] - km), k1 = fast_exp(kv[i][1] - km), k2 = fast_exp(kv[i][2] - km),
+                k3 = fast_exp(kv[i][3] - km);
+    const float f = e * __builtin_amdgcn_rcpf(k0 + k1 + k2 + k3);
+    a0 += k0 * f; a1 += k1 * f; a2 += k2 * f; a3 += k3 * f;
+  }
+  qsum = half_sum(row_pair_sum(qsum));
+  a0 = half_sum(row_pair_sum(a0)); a1 = half_sum(row_pair_sum(a1));
+  a2 = half_sum(row_pair_sum(a2)); a3 = half_sum(row_pair_sum(a3));
+  const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(qsum);  // dim_head ** -0.5 / sum
+  a0 *= sc; a1 *= sc; a2 *= sc; a3 *= sc;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    o3[swz<NC>(h2 * kDimHead + d0 + i, nn)] = vv[i][0] * a0 + vv[i][1] * a1 + vv[i][2] * a2 + vv[i][3] * a3;
+  __syncthreads();
+}
+
+
 // dst[cout][NC] = W * im2col(src[cin][NC]) + bias: the waves split the output rows (all n-tiles each).
 // Ends with a barrier.  alias: dst overlaps src -> all reads complete (barrier) before any store.
 // Output widths are 16 x {1, 2, 4, 8, 12, 16} rows (validate() enforces it).
@@ -668,8 +1057,24 @@ __device__ __forceinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, co
 #define GLDM_G3(MT, NT, P, mt0, nt0, on) gemm_passes<NC, L, 3, MT, NT, P>(c, wp, mt0, nt0, on, src, cin, dst, cout, bias, alias, act, g)
 #define GLDM_G1(MT, NT, P, mt0, nt0, on) gemm_passes<NC, L, 1, MT, NT, P>(c, wp, mt0, nt0, on, src, cin, dst, cout, bias, alias, act, g)
   if constexpr (NC == 64) {
-    // 8 waves x 4 n-tiles: the fused set abstraction (1x1 layers only)
-    if (mtiles == 16) GLDM_G1(2, 4, 1, 2 * w, 0, true);
+    if (ktaps == 3) {
+      // position-major engine (L = 4): 8 waves share the m-tiles; the three taps tie the 4 position tiles together
+      if (cin & 15) conv_pm3_cin4(c, wp, bias, src, dst, cout, alias);
+      else if (mtiles == 16) conv_pm3_wave<2, 0, 4, 0>(c, wp, bias, 2 * w, src, cin, dst, cout, alias, g);
+      else if (mtiles == 8) conv_pm3_wave<1, 0, 4, 0>(c, wp, bias, w, src, cin, dst, cout, alias, g);
+      else if (mtiles == 4) {
+        if (w < 4) conv_pm3_wave<1, 0, 2, 1>(c, wp, bias, w & 3, src, cin, dst, cout, alias, g);
+        else conv_pm3_wave<1, 2, 2, 1>(c, wp, bias, w & 3, src, cin, dst, cout, alias, g);
+      } else {  // 2 m-tiles: wave = (m-tile, position)
+        const int pw = w >> 1;
+        if (pw == 0) conv_pm3_wave<1, 0, 1, 2>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
+        else if (pw == 1) conv_pm3_wave<1, 1, 1, 2>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
+        else if (pw == 2) conv_pm3_wave<1, 2, 1, 2>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
+        else conv_pm3_wave<1, 3, 1, 2>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
+      }
+    }
+    // 1x1 layers (layout agnostic): 8 waves x 4 n-tiles; also the fused set abstraction
+    else if (mtiles == 16) GLDM_G1(2, 4, 1, 2 * w, 0, true);
     else if (mtiles == 12) GLDM_G1(3, 2, 1, 3 * (w & 3), 2 * (w >> 2), true);
     else if (mtiles == 8) GLDM_G1(1, 4, 1, w, 0, true);
     else if (mtiles == 4) GLDM_G1(1, 2, 1, w & 3, 2 * (w >> 2), true);
@@ -983,7 +1388,6 @@ struct RunArgs {
 // inside the step loop, so every phase body exists once, inlined, with registers allocated across the
 // whole kernel: no calls, no callee-save traffic and no spilled kernel state between phases.
 enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4 };
-constexpr int kOpInts = 12, kMaxOps = 84;  // 84 * 12 = 1008 ints; the op count lives in int 1023
 // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9
 constexpr int kFlagAlias = 1 << 8;
 
@@ -1114,7 +1518,7 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
   };
   constexpr int X = GG::kBufX, H = GG::kBufH, Y = GG::kBufY, O = GG::kBufO, QKV = GG::kBufQKV;
   auto resblock = [&](const gldm_r1d_resblock &rb, int C, bool last_of_pair) {
-    if (C == 4 && d.seq_len == 4 && NC == 32) {  // one-wave VALU form; the barrier comes after the second block
+    if (C == 4 && d.seq_len == 4) {  // one-wave VALU form; the barrier comes after the second block
       emit(OP_RES4, rb.c1_w, rb.c1_b, rb.n1_w, rb.n1_b, rb.c2_w, rb.c2_b, rb.n2_w, rb.n2_b, rb.ss_w, rb.ss_b,
            last_of_pair ? 1 : 0);
       return;
@@ -1175,7 +1579,10 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
         break;
       }
       case OP_RES4:
-        if (!GLDM_SKIP(c, 8)) resblock4_valu<NC>(c, o, E);
+        if (!GLDM_SKIP(c, 8)) {
+          if constexpr (NC == 64) resblock4_pm(c, o, E);
+          else resblock4_valu<NC>(c, o, E);
+        }
         if (o[11]) __syncthreads();
         break;
       case OP_LN:
@@ -1183,7 +1590,8 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
                             o[4], o[5]);
         break;
       default:
-        attention_pair<NC, L>(c, c.lds + o[1], c.lds + o[2]);
+        if constexpr (NC == 64) attention_pair_pm(c, c.lds + o[1], c.lds + o[2]);
+        else attention_pair<NC, L>(c, c.lds + o[1], c.lds + o[2]);
         break;
     }
   }
@@ -1215,6 +1623,13 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   extern __shared__ float lds[];
   const gldm_r1d_desc &d = a.d;
   constexpr int S = NC / L;
+  // column <-> (sample, position): sample-major tiles (column = sample * L + position) or, for the 64-column
+  // engine of the L = 4 denoiser, position-major ones (column = 16 * position + sample)
+  constexpr bool PM = NC == 64;
+  static_assert(!PM || L == 4, "the position-major engine is built for 4-position latents");
+  auto samp_of = [](int n) { return PM ? (n & 15) : n / L; };
+  auto pos_of = [](int n) { return PM ? (n >> 4) : n % L; };
+  auto col_of = [](int sm, int l) { return PM ? 16 * l + sm : sm * L + l; };
   Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
         a.skip, GG::kNT};
   const int E = d.emb_dim, R = d.cond_rows;
@@ -1280,7 +1695,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   c.nta = (nsamp * L <= 16) ? 1 : GG::kNT;
   // ---- latent row for this tile: from the input (first step) or from the slot that ran the steps before s0
   if (c.tid < NC) {
-    const int s = c.tid / L, l = c.tid % L;
+    const int s = samp_of(c.tid), l = pos_of(c.tid);
     const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
     float v;
     if (s0 > 0) {
@@ -1319,13 +1734,13 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     if (!GLDM_SKIP(c, 64))
     for (int i = c.tid; i < C0 * NC; i += GG::kThreads) {
       const int ch = i / NC, n = i - ch * NC;
-      const int l = n & (L - 1), base = n - l;
+      const int l = pos_of(n), sm = samp_of(n);
       float acc = a.weights[d.init_b + ch];
       const float *wk = a.weights + d.init_w + ch * 7;
 #pragma unroll
       for (int q = 0; q < 7; ++q) {
         const int p = l + q - 3;
-        if (p >= 0 && p < L) acc += wk[q] * lat[base + p];
+        if (p >= 0 && p < L) acc += wk[q] * lat[col_of(sm, p)];
       }
       X[swz<NC>(ch, n)] = acc;
     }
@@ -1349,7 +1764,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
         for (int q = 0; q < GG::kWaves; ++q) e += red1[q * NC + c.tid];
         epsr[c.tid] = e;
         if (a.sched_kind != GLDM_SCHED_NONE) {
-          const int s = c.tid / L, l = c.tid % L;
+          const int s = samp_of(c.tid), l = pos_of(c.tid);
           const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
           const float *cf = a.sched_coef + (size_t)step * GLDM_SCHED_COEF_STRIDE;
           float nz = 0.f;
@@ -1367,7 +1782,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     if (c.tid < NC) chain_give(state + (size_t)tile * NC + c.tid, lat[c.tid], chain_tag(epoch, s1));
   } else if (!has_head) {
     if (c.tid < NC) {
-      const int s = c.tid / L, l = c.tid % L;
+      const int s = samp_of(c.tid), l = pos_of(c.tid);
       const int gi = samp0 + s;
       if (s < nsamp && gi < a.n_samples) a.out0[(size_t)gi * L + l] = a.sched_kind == GLDM_SCHED_NONE ? epsr[c.tid] : lat[c.tid];
     }
@@ -1526,6 +1941,23 @@ int validate(const gldm_r1d_desc *d) {
   return GLDM_OK;
 }
 
+// The position-major 64-column engine (r1d_kernel<64, 4>) serves the latent denoiser of the shipped
+// configurations: 4 positions, no input layer / heads, emb_dim 16, a 4-channel first level and 32..256-channel
+// ones after it.  Anything else runs on the sample-major 32-column engine.
+bool pm_supported(const gldm_r1d_desc *d) {
+#ifdef GLDM_R1D_SAMPLE_MAJOR
+  return false;
+#endif
+  if (d->seq_len != 4 || d->latent_dim != 0 || d->n_head != 0 || d->emb_dim != 16 || d->groups != 4) return false;
+  if (d->dims[0] != 4) return false;
+  for (int i = 1; i <= d->n_levels; ++i) {
+    const int C = d->dims[i];
+    if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false;
+    if (i < d->n_levels && C > 128) return false;
+  }
+  return true;
+}
+
 int cu_count() {
   static int cus = 0;
   if (!cus) {
@@ -1579,7 +2011,8 @@ int launch_one(const RunArgs &a, int tiles, hipStream_t s) {
 }
 
 int launch_r1d(const RunArgs &a_in, hipStream_t s) {
-  const int L = a_in.d.seq_len, nc = engine_nc();
+  const bool pm = pm_supported(&a_in.d);
+  const int L = a_in.d.seq_len, nc = pm ? 64 : engine_nc();
   const Plan pl = make_plan(a_in.n_samples, a_in.n_steps, L, nc);
   const int tiles = pl.grid;
   if (tiles <= 0) return GLDM_ERR_UNSUPPORTED;  // > ~250 k samples in one launch: split the batch
@@ -1602,7 +2035,8 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   static long long *dstamps = nullptr;
   if (stamp && !dstamps) (void)hipMalloc(&dstamps, (kMaxOps + 2) * sizeof(long long));
   a.stamps = stamp ? dstamps : nullptr;
-  const int rc = L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s);
+  const int rc = pm ? launch_one<64, 4>(a, tiles, s)
+                    : (L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s));
   if (stamp) {
     static long long host[kMaxOps + 2];
     static const char *names[] = {"", "CONV", "RES4", "LN", "ATT"};
@@ -1647,9 +2081,10 @@ GLDM_API int gldm_r1d_cond_embed(const float *z_cond, const float *w, const floa
 GLDM_API long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples) {
   if (validate(desc) != GLDM_OK || n_samples <= 0) return -1;
   // header + one 8-byte hand-off granule per activation column of every tile (see ChainHdr)
-  const int S = engine_nc() / desc->seq_len;
+  const int nc = pm_supported(desc) ? 64 : engine_nc();
+  const int S = nc / desc->seq_len;
   const long long tiles = (n_samples + S - 1) / S;
-  return kChainHdrBytes + tiles * engine_nc() * 8;
+  return kChainHdrBytes + tiles * nc * 8;
 }
 
 GLDM_API int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,
