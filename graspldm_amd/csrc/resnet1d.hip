@@ -58,6 +58,27 @@ typedef __attribute__((address_space(3))) float lds_f;   // explicit LDS pointer
 typedef __attribute__((address_space(3))) f32x4 lds_f4;
 typedef const __attribute__((address_space(1))) f32x4 *gf4p;  // plain global_load (vmcnt only)
 
+// Stream of packed weight fragments: fragment i = 64 lanes x 16 bytes at byte offset 1024 i of `wp`.
+// Read with buffer_load_dwordx4 through a wave-uniform descriptor: base in SGPRs, the fragment's byte
+// offset as the SCALAR offset, the lane's 16 bytes as a constant 32-bit vector offset.  A global_load of
+// the same bytes carries a 64-bit address per lane; issuing it between MFMAs costs the SIMD ~60 cycles of
+// matrix issue per instruction (measured: 256x256 k3 conv 84 % -> 95 % of the MFMA-bound time,
+// tools/micro/gemm_pm_rate).  `i` must be wave uniform.
+struct WStream {
+  __amdgpu_buffer_rsrc_t r;
+  int v;
+  __device__ __forceinline__ WStream(const float *wp, int lane) {
+    const unsigned long long a = (unsigned long long)wp;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    r = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7FFFFFFF, 0x00020000);
+    v = lane * 16;
+  }
+  __device__ __forceinline__ f32x4 operator[](size_t i) const {
+    const auto q = __builtin_amdgcn_raw_buffer_load_b128(r, v, (int)(i * 16), 0);
+    return f32x4{__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
+  }
+};
+
 constexpr int kHeads = 4, kDimHead = 32, kHidden = kHeads * kDimHead;  // LinearAttention defaults
 constexpr int kMaxC = 256;
 constexpr int kMaxSegs = 64;  // tiles (+ one spliced step segment) a persistent workgroup can be given
@@ -161,7 +182,7 @@ __device__ __forceinline__ void gemm_fast_pf(const Ctx &c, const float *__restri
   // are clamped instead; the redundant re-loads at the tail are harmless.
   const int col = c.lane & 15, kq = c.lane >> 4;
   const int kblocks = TAPS * cblocks;
-  gf4p wv = (gf4p)(reinterpret_cast<const f32x4 *>(wp) + c.lane);
+  const WStream wv(wp, c.lane);
   int boff[4][NT];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -274,7 +295,7 @@ __device__ __forceinline__ void gemm_fast_tap3(const Ctx &c, const float *__rest
                                                const float *src, f32x4 (&acc)[MT][NT]) {
   const int col = c.lane & 15, kq = c.lane >> 4;
   const int kblocks = 3 * cblocks;
-  gf4p wv = (gf4p)(reinterpret_cast<const f32x4 *>(wp) + c.lane);
+  const WStream wv(wp, c.lane);
   int boff[4][NT];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -352,13 +373,17 @@ __device__ __forceinline__ void gemm_pm3(const Ctx &c, const float *__restrict__
   constexpr int PB0 = P0 > 0 ? P0 - 1 : 0, PB1 = P0 + NP < 4 ? P0 + NP : 3, NB = PB1 - PB0 + 1;
   const int col = c.lane & 15, kq = c.lane >> 4;
   const int kblocks = 3 * cblocks;
-  gf4p wv = (gf4p)(reinterpret_cast<const f32x4 *>(wp) + c.lane);
+  const WStream wv(wp, c.lane);
   int boff[4][NB];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int q = 0; q < NB; ++q) boff[j][q] = swz<NC>(4 * j + kq, 16 * (PB0 + q) + col);
-  f32x4 a[3][MT];
+  // A fragments double buffered over whole 16-channel blocks: block cb + 1's three taps are requested while
+  // block cb's MFMAs issue (one tap's loads in front of each tap sweep), so every weight load has a full
+  // block of this wave's MFMAs (and its SIMD partner's) to arrive.  One workgroup owns the CU here: there is
+  // no co-resident tile whose short phases a deep weight stream could delay.
+  f32x4 a[2][3][MT];
   float b[2][4][NB];
   const lds_f *src3 = (const lds_f *)src;
   auto load_b = [&](int buf, int cb) {
@@ -372,16 +397,35 @@ __device__ __forceinline__ void gemm_pm3(const Ctx &c, const float *__restrict__
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) a[t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks) * 64];
+    for (int mi = 0; mi < MT; ++mi) a[0][t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks) * 64];
   load_b(0, 0);
-  for (int cb0 = 0; cb0 < cblocks; cb0 += 2) {  // two blocks per trip: the B double buffer alternates statically
+#ifdef GLDM_PM_NO_A
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) a[1][t][mi] = a[0][t][mi];
+#endif
+#ifdef GLDM_PM_NO_B
+  load_b(1, 0);
+#endif
+  for (int cb0 = 0; cb0 < cblocks; cb0 += 2) {  // two blocks per trip: both double buffers alternate statically
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int cb = cb0 + u;
       const int nb = cb + 1 < last ? cb + 1 : last;  // clamped: the loads stay unconditional
+#ifndef GLDM_PM_NO_B
       load_b(1 - u, nb);
+#endif
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
+#ifndef GLDM_PM_NO_A
+#pragma unroll
+#ifdef GLDM_PM_SMALL_A
+        for (int mi = 0; mi < MT; ++mi) a[1 - u][t][mi] = wv[(((size_t)(mt0 + mi) * kblocks + t * cblocks + nb) & 3) * 64];
+#else
+        for (int mi = 0; mi < MT; ++mi) a[1 - u][t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks + nb) * 64];
+#endif
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -389,16 +433,12 @@ __device__ __forceinline__ void gemm_pm3(const Ctx &c, const float *__restrict__
           for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-              constexpr int dummy = 0;
-              (void)dummy;
               const int sp = P0 + p + t - 1;  // source position of this tap for out tile P0 + p
               if (sp >= 0 && sp <= 3)
-                acc[mi][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][mi][j], b[u][j][sp - PB0 < 0 ? 0 : (sp - PB0 >= NB ? NB - 1 : sp - PB0)],
+                acc[mi][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t][mi][j], b[u][j][sp - PB0 < 0 ? 0 : (sp - PB0 >= NB ? NB - 1 : sp - PB0)],
                                                                   acc[mi][p], 0, 0, 0);
             }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) a[t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks + nb) * 64];
       }
     }
   }
@@ -427,14 +467,14 @@ template <int NC, int L, int MT, int NT>
 __device__ __forceinline__ void gemm_small(const Ctx &c, const float *__restrict__ wp, int kblocks, int mt0, int nt0,
                                            const float *src, int cin, int ktaps, f32x4 (&acc)[MT][NT]) {
   const int col = c.lane & 15, kq = c.lane >> 4;
-  const f32x4 *wv = reinterpret_cast<const f32x4 *>(wp);
+  const WStream wv(wp, c.lane);
   const lds_f *src3 = (const lds_f *)src;
   int dk = 0, cib = 0;
   const int pad = ktaps == 3 ? 1 : 0;
   for (int kb = 0; kb < kblocks; ++kb) {
     f32x4 a[MT];
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) a[mi] = wv[((size_t)(mt0 + mi) * kblocks + kb) * 64 + c.lane];
+    for (int mi = 0; mi < MT; ++mi) a[mi] = wv[((size_t)(mt0 + mi) * kblocks + kb) * 64];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ci = cib + kq;
@@ -518,7 +558,7 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
   const bool has_ss = g.ss_w >= 0;
   const bool wide = g.C >= 16;  // else C = 4: one m-tile holds scale rows 0..3 (row quarter 0) and shift rows 4..7
   const int ekb = g.E >> 4;
-  gf4p wss = (gf4p)(reinterpret_cast<const f32x4 *>(c.w + (has_ss ? g.ss_w : 0)) + c.lane);
+  const WStream wss(c.w + (has_ss ? g.ss_w : 0), c.lane);
   f32x4 ga[PASSES][MT], be[PASSES][MT], sc0[PASSES][MT], sh0[PASSES][MT], a_sc[PASSES][MT], a_sh[PASSES][MT];
 #define GLDM_LOAD_GN_PARAMS()                                                                                       \
   _Pragma("unroll") for (int p = 0; p < PASSES; ++p) _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) {            \
@@ -741,7 +781,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
   f32x4 acc[MT][NP];
   const bool has_ss = g.ss_w >= 0;
   const int ekb = g.E >> 4;
-  gf4p wss = (gf4p)(reinterpret_cast<const f32x4 *>(c.w + (has_ss ? g.ss_w : 0)) + c.lane);
+  const WStream wss(c.w + (has_ss ? g.ss_w : 0), c.lane);
   f32x4 ga[MT], be[MT], sc[MT], sh[MT], a_sc[MT], a_sh[MT];
   if (g.mode) {  // every epilogue parameter is requested before the k-sweep: its round trip hides behind the GEMM
 #pragma unroll

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(512, 2) void pm_probe(const float *w, int cin, int 
   using GG = Geo<64>;
   extern __shared__ float lds[];
   Ctx c{w, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63, 0, GG::kNT};
-  for (int i = c.tid; i < GG::kLdsFloats; i += GG::kThreads) lds[i] = 0.f;
+  for (int i = c.tid; i < GG::kLdsFloats; i += GG::kThreads) lds[i] = 0.37f * (float)((i * 2654435761u >> 20) & 1023) / 1024.f - 0.18f;
   __syncthreads();
   const long long t0 = __builtin_readcyclecounter();
   for (int i = 0; i < iters; ++i) {
@@ -55,12 +55,31 @@ __global__ __launch_bounds__(512, 2) void pm_probe(const float *w, int cin, int 
   if (c.tid == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+__global__ __launch_bounds__(512, 2) void pm_gn_probe(const float *w, int cin, int cout, int mode, int iters, long long *cycles) {
+  using GG = Geo<64>;
+  extern __shared__ float lds[];
+  Ctx c{w, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63, 0, GG::kNT};
+  for (int i = c.tid; i < GG::kLdsFloats; i += GG::kThreads) lds[i] = 0.37f * (float)((i * 2654435761u >> 20) & 1023) / 1024.f - 0.18f;
+  __syncthreads();
+  const long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+    Ctx cc = c;
+    asm volatile("" : "+v"(cc.tid), "+v"(cc.lane));
+    int ci = cin, co = cout, md = mode;
+    asm volatile("" : "+s"(ci), "+s"(co), "+s"(md));
+    const GnEpilogue g{md, 1 << 19, (1 << 19) + 1024, md == 1 ? (1 << 19) + 4096 : -1, (1 << 19) + 2048, 16, co, co / 4, lds + GG::kBufH};
+    conv_gemm<64, 4>(cc, 0, 1 << 18, lds + GG::kBufX, ci, 3, lds + GG::kBufH, co, false, 0, g);
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  if (c.tid == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 template <int NC, int L>
 __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void sm_probe(const float *w, int cin, int cout, int iters, long long *cycles) {
   using GG = Geo<NC>;
   extern __shared__ float lds[];
   Ctx c{w, lds, (int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, 0, GG::kNT};
-  for (int i = c.tid; i < GG::kLdsFloats; i += GG::kThreads) lds[i] = 0.f;
+  for (int i = c.tid; i < GG::kLdsFloats; i += GG::kThreads) lds[i] = 0.37f * (float)((i * 2654435761u >> 20) & 1023) / 1024.f - 0.18f;
   __syncthreads();
   const long long t0 = __builtin_readcyclecounter();
   for (int i = 0; i < iters; ++i) {
@@ -72,6 +91,14 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void sm_probe(const float *w,
   }
   const long long t1 = __builtin_readcyclecounter();
   if (c.tid == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+double avg_cycles(long long *dcyc, int wgs, int iters) {
+  std::vector<long long> h(wgs);
+  (void)hipMemcpy(h.data(), dcyc, wgs * sizeof(long long), hipMemcpyDeviceToHost);
+  double a = 0;
+  for (auto v : h) a += (double)v;
+  return a / wgs / iters;
 }
 
 float time_launch(void (*launch)(), int reps = 3) {
@@ -91,11 +118,17 @@ float time_launch(void (*launch)(), int reps = 3) {
 int main() {
   float *w; long long *dcyc;
   (void)hipMalloc(&w, (size_t)8 << 20);
-  (void)hipMemset(w, 0, (size_t)8 << 20);
+  {
+    std::vector<float> hw((size_t)2 << 20);
+    unsigned x = 12345u;
+    for (auto &v : hw) { x = x * 1664525u + 1013904223u; v = ((float)(x >> 8) / 16777216.f - 0.5f) * 0.1f; }
+    (void)hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+  }
   (void)hipMalloc(&dcyc, 1024 * sizeof(long long));
   const int iters = 200;
   const size_t lds64 = (size_t)Geo<64>::kLdsFloats * 4, lds32 = (size_t)Geo<32>::kLdsFloats * 4;
   (void)hipFuncSetAttribute((const void *)pm_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+  (void)hipFuncSetAttribute((const void *)pm_gn_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
   (void)hipFuncSetAttribute((const void *)sm_probe<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
   const int shapes[][2] = {{256, 256}, {128, 256}, {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}};
   for (auto &sh : shapes) {
@@ -103,12 +136,21 @@ int main() {
     static int s_cin, s_cout; static const float *s_w; static long long *s_c;
     s_cin = cin; s_cout = cout; s_w = w; s_c = dcyc;
     const float ms_sm = time_launch([] { hipLaunchKernelGGL((sm_probe<32, 4>), dim3(512), dim3(256), (size_t)Geo<32>::kLdsFloats * 4, 0, s_w, s_cin, s_cout, 200, s_c); });
+    const double cyc_sm = avg_cycles(dcyc, 512, iters);
     const float ms_pm = time_launch([] { hipLaunchKernelGGL(pm_probe, dim3(256), dim3(512), (size_t)Geo<64>::kLdsFloats * 4, 0, s_w, s_cin, s_cout, 200, s_c); });
+    const double cyc_pm = avg_cycles(dcyc, 256, iters);
+    double cyc_gn[3];
+    for (int md = 0; md < 3; ++md) {
+      static int s_md; s_md = md;
+      (void)time_launch([] { hipLaunchKernelGGL(pm_gn_probe, dim3(256), dim3(512), (size_t)Geo<64>::kLdsFloats * 4, 0, s_w, s_cin, s_cout, s_md, 200, s_c); }, 1);
+      cyc_gn[md] = avg_cycles(dcyc, 256, iters);
+    }
+    const double ideal10 = (cout / 16) * (3.0 * cin / 4) * 4 * 32.0 / 4 * 10 / 12;
     // MFMA-bound ideal for 64 columns per CU at the sample-major count (12 tile-MFMAs) and at the position-major count (10)
     const double mf12 = (cout / 16) * (3.0 * cin / 4) * 4 * 32.0 / 4 / 2400.0;  // us
     const double us_sm = ms_sm * 1e3 / iters, us_pm = ms_pm * 1e3 / iters;
-    printf("cin=%3d cout=%3d k3 | sample-major 2x32 cols: %7.3f us (%5.1f%% of MFMA peak) | position-major 1x64 cols: %7.3f us (%5.1f%% of peak on the algorithmic FLOP) | speedup %.3f\n",
-           cin, cout, us_sm, 100 * mf12 / us_sm, us_pm, 100 * mf12 / us_pm, us_sm / us_pm);
+    printf("cin=%3d cout=%3d k3 | sample-major 2x32 cols: %7.3f us (%5.1f%% of MFMA peak) | position-major 1x64 cols: %7.3f us (%5.1f%% of peak on the algorithmic FLOP) | speedup %.3f | cycles/call sm %.0f pm %.0f (pm ideal at 10 tile-MFMAs %.0f = %.1f%%) | conv_gemm<64,4> plain %.0f GN %.0f GN+res %.0f\n",
+           cin, cout, us_sm, 100 * mf12 / us_sm, us_pm, 100 * mf12 / us_pm, us_sm / us_pm, cyc_sm, cyc_pm, ideal10, 100 * ideal10 / cyc_pm, cyc_gn[0], cyc_gn[1], cyc_gn[2]);
   }
   return 0;
 }

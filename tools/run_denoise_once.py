@@ -1,6 +1,9 @@
 """One fused denoise launch (n latents, s steps) for counter collection; prints the launch time."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graspldm_amd import _lib
+if os.environ.get("GLDM_LIB"):  # e.g. a diagnostic build: make -C graspldm_amd/csrc EXTRA=-DGLDM_DEBUG_KNOBS BUILD=... OUT=...
+    _lib.LIB_PATH = os.environ["GLDM_LIB"]
 from graspldm_amd.pipeline import build_fpc_ldm
 from graspldm_amd.r1d_pack import SCHED_DDIM
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
