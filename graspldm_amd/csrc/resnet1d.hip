@@ -38,6 +38,7 @@
 #include <stdlib.h>
 
 #include "gldm.h"
+#include "wstream.h"
 
 #define GLDM_API extern "C" __attribute__((visibility("default")))
 
@@ -56,28 +57,6 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) float lds_f;   // explicit LDS pointers: 32-bit ds_* addressing
 typedef __attribute__((address_space(3))) f32x4 lds_f4;
-typedef const __attribute__((address_space(1))) f32x4 *gf4p;  // plain global_load (vmcnt only)
-
-// Stream of packed weight fragments: fragment i = 64 lanes x 16 bytes at byte offset 1024 i of `wp`.
-// Read with buffer_load_dwordx4 through a wave-uniform descriptor: base in SGPRs, the fragment's byte
-// offset as the SCALAR offset, the lane's 16 bytes as a constant 32-bit vector offset.  A global_load of
-// the same bytes carries a 64-bit address per lane; issuing it between MFMAs costs the SIMD ~60 cycles of
-// matrix issue per instruction (measured: 256x256 k3 conv 84 % -> 95 % of the MFMA-bound time,
-// tools/micro/gemm_pm_rate).  `i` must be wave uniform.
-struct WStream {
-  __amdgpu_buffer_rsrc_t r;
-  int v;
-  __device__ __forceinline__ WStream(const float *wp, int lane) {
-    const unsigned long long a = (unsigned long long)wp;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    r = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7FFFFFFF, 0x00020000);
-    v = lane * 16;
-  }
-  __device__ __forceinline__ f32x4 operator[](size_t i) const {
-    const auto q = __builtin_amdgcn_raw_buffer_load_b128(r, v, (int)(i * 16), 0);
-    return f32x4{__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
-  }
-};
 
 constexpr int kHeads = 4, kDimHead = 32, kHidden = kHeads * kDimHead;  // LinearAttention defaults
 constexpr int kMaxC = 256;

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "gldm.h"
+#include "wstream.h"
 
 #define GLDM_API extern "C" __attribute__((visibility("default")))
 
@@ -52,8 +53,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
   const int cblocks = (cin + 15) >> 4, kblocks = 27 * cblocks;
   x += (size_t)b * cin * r3;
   y += (size_t)b * cout * r3;
-  typedef const __attribute__((address_space(1))) f32x4 *gf4p;
-  gf4p wv = (gf4p)(reinterpret_cast<const f32x4 *>(wp) + lane);
+  const WStream wv(wp, lane);  // weight fragments: buffer loads, scalar offsets (see wstream.h)
   const lds_f *l3 = (const lds_f *)lds;
 
   // output voxel of (n-tile, lane column) in brick coordinates; LDS base of its (0,0,0) tap
