@@ -148,7 +148,7 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: the fused denoise loop (r1d_kernel<4>)
+        # ---- roofline of the dominant kernel: the fused denoise loop (r1d_kernel<64, 4>)
         den = ldm.diffusion_model.model
         eng = den.engine(dev)
         z = ldm.vae_model.encode_pc(pcs)
@@ -164,17 +164,21 @@ def main():
         # memory-side bytes of one launch from the committed PMC passes (tools/pmc_denoise.sh: FETCH_SIZE, doubled
         # per the gfx950 16-B/lane rule, + WRITE_SIZE); only quoted for the workload they were collected on
         traffic = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01f_denoise_pmc.json")
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_denoise_pmc.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             if pmc.get("n_latents") == B * G and pmc.get("steps") == S:
                 traffic = pmc["fetch_bytes_corrected"] + pmc["write_bytes"]
-        roof = dict(kernel="r1d_kernel<32, 4> (gldm_denoise: %d %s steps fused)" % (S, args.scheduler.upper()), bound="mfma",
+        roof = dict(kernel="r1d_kernel<64, 4> (gldm_denoise: %d %s steps fused, position-major tiles)" % (S, args.scheduler.upper()),
+                    bound="mfma",
                     achieved=flop / t_den / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=flop / t_den / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
                     algorithmic_flop_per_launch=flop, avg_launch_ms=t_den * 1e3,
                     timing="HIP events around 3 launches on their own (no other stream active); in the pipelined "
-                           "steps the other stream's encoder kernels share the GPU with the launch")
+                           "steps the other stream's encoder kernels share the GPU with the launch",
+                    flop_note="algorithmic FLOP = the reference graph's count (7,589,120 per latent and step, = torch's "
+                              "flop counter, which counts a k=3 conv's zero-padding taps); the position-major engine "
+                              "never issues those padding products (1/6 of the k=3 conv MFMAs)")
         # ---- stage split and the set-abstraction gather (north-star HBM kernel), same run
         t_enc = event_time(lambda: ldm.vae_model.encode_pc(pcs), 3)
         dec = ldm.vae_model.decoder

@@ -13,4 +13,4 @@ run l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run inst SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA
-cd $GRAFT_REPO_ROOT && python3 tools/pmc_summary.py gpurun_out/pmc_$tag
+cd $GRAFT_REPO_ROOT && python3 tools/pmc_summary.py gpurun_out/pmc_$tag gpurun_out/pmc_$tag.json | tee gpurun_out/pmc_$tag.txt

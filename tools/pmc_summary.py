@@ -1,6 +1,10 @@
-"""Sum rocprofv3 counter_collection.csv files of tools/pmc_denoise.sh for the r1d_kernel dispatches."""
-import csv, glob, os, sys
+"""Sum rocprofv3 counter_collection.csv files of tools/pmc_denoise.sh for the r1d_kernel dispatches.
+`python tools/pmc_summary.py gpurun_out/pmc_<tag> [out.json]`: prints per-launch means and, with a second
+argument, writes the JSON that bench.py reads for `roofline.traffic` (FETCH_SIZE doubled per the gfx950
+16-B/lane rule of MI355X_MICROARCH.md, + WRITE_SIZE)."""
+import csv, glob, json, os, re, sys
 root = sys.argv[1]
+allc, kernel = {}, None
 for grp in sorted(os.listdir(root)):
     files = glob.glob(os.path.join(root, grp, "**", "*counter_collection.csv"), recursive=True)
     if not files:
@@ -10,9 +14,22 @@ for grp in sorted(os.listdir(root)):
         for row in csv.DictReader(open(f)):
             if "r1d_kernel" not in row.get("Kernel_Name", ""):
                 continue
+            m = re.search(r"r1d_kernel<[^>]*>", row["Kernel_Name"])
+            kernel = m.group(0) if m else "r1d_kernel"
             k = row["Counter_Name"]
             tot[k] = tot.get(k, 0.0) + float(row["Counter_Value"])
             n[k] = n.get(k, set()) | {row["Dispatch_Id"]}
     for k in sorted(tot):
         d = max(1, len(n[k]))
+        allc[k] = tot[k] / d
         print(f"{grp:8s} {k:28s} {tot[k] / d:16.0f} per launch ({d} launches)")
+if len(sys.argv) > 2:
+    out = dict(kernel=kernel, n_latents=int(os.environ.get("NLAT", "5120")), steps=100)
+    out.update({k: v for k, v in allc.items()})
+    if "FETCH_SIZE" in allc:  # reported in KiB
+        out["fetch_bytes_corrected"] = int(allc["FETCH_SIZE"] * 1024 * 2)
+    if "WRITE_SIZE" in allc:
+        out["write_bytes"] = int(allc["WRITE_SIZE"] * 1024)
+    out["note"] = ("per launch, mean over the launches of tools/run_denoise_once.py (the first one cold); one counter group "
+                   "per rocprofv3 run (tools/pmc_denoise.sh); FETCH_SIZE doubled per the gfx950 16-B/lane rule")
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
