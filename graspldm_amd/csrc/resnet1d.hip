@@ -750,6 +750,9 @@ constexpr int kOpInts = 12, kMaxOps = 84;  // op tape: 84 * 12 = 1008 ints; the 
 //   GK 0: partner = the adjacent wave (C = 256: 2 m-tiles per wave, C = 128: 1; all 4 positions)
 //   GK 1: partner = wave ^ 4 (C = 64: one m-tile = one group, positions split in two halves)
 //   GK 2: four waves (one per position) x two groups per m-tile (C = 32: 8 channels per group)
+#ifndef GLDM_PM_EARLY_PARAMS
+#define GLDM_PM_EARLY_PARAMS(MT) false
+#endif
 template <int MT, int P0, int NP, int GK>
 __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, const float *bias, int mt0,
                                               const float *src, int cin, float *dst, int cout, bool alias,
@@ -762,7 +765,9 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
   const int ekb = g.E >> 4;
   const WStream wss(c.w + (has_ss ? g.ss_w : 0), c.lane);
   f32x4 ga[MT], be[MT], sc[MT], sh[MT], a_sc[MT], a_sh[MT];
-  if (g.mode) {  // every epilogue parameter is requested before the k-sweep: its round trip hides behind the GEMM
+  // Epilogue parameters are requested right after the k-sweep (measured: requesting them before it, live through
+  // the sweep, is 0-10 % slower on the narrow convs and no faster on the wide ones: tools/micro/gemm_pm_rate)
+  auto load_params = [&]() {
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       const int mt = mt0 + mi, row0 = 16 * mt + 4 * kq;
@@ -778,7 +783,9 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
         a_sh[mi] = wss[(size_t)((g.C >> 4) + mt) * ekb * 64];
       }
     }
-  }
+  };
+  constexpr bool kEarly = GLDM_PM_EARLY_PARAMS(MT);
+  if (g.mode && kEarly) load_params();
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -787,6 +794,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
     for (int p = 0; p < NP; ++p) acc[mi][p] = bv;
   }
   gemm_pm3<MT, P0, NP>(c, wp, cin >> 4, mt0, src, acc);
+  if (g.mode && !kEarly) load_params();
   if (!g.mode) {
     if (alias) __syncthreads();
     lds_f *d3 = (lds_f *)dst;
