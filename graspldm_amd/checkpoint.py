@@ -166,20 +166,21 @@ class Experiment:
         return self._ckpt_paths[mode]
 
 
-def load_ldm_from_experiment(exp_name, exp_out_root, use_ema_model=True, ddm_ckpt_path=None, use_fast_sampler=True):
+def load_ldm_from_experiment(exp_name, exp_out_root, use_ema_model=True, ddm_ckpt_path=None, use_fast_sampler=True,
+                             mode="ddm"):
     """InferenceLDM.__init__ + load_model of the reference (tools/inference.py:401-566) up to the weights:
     -> (GraspLatentDDM with its VAE attached, eval mode, on the CPU; config; Experiment).  use_fast_sampler
     switches the scheduler to DDIM before the model is built (:463-471; the reference patches `config.models`,
     which the shipped `model` configs do not have -- here the section that exists is patched)."""
     from .builder import build_model_from_cfg
-    exp = Experiment(exp_name, exp_out_root, modes=["ddm"], ddm_ckpt_path=ddm_ckpt_path)
-    config = exp.get_config("ddm")
+    exp = Experiment(exp_name, exp_out_root, modes=[mode], **{("ddm_ckpt_path" if mode == "ddm" else "elucidated_ckpt_path"): ddm_ckpt_path})
+    config = exp.get_config(mode)
     key = model_section(config)
     if use_fast_sampler:
         config[key]["ddm"]["model"]["args"]["noise_scheduler_type"] = "ddim"
     model = build_model_from_cfg(config[key]["ddm"])
     model.set_vae_model(build_model_from_cfg(config[key]["vae"]))
-    return load_weights(model, exp.get_ckpt_path("ddm"), use_ema_model).eval(), config, exp
+    return load_weights(model, exp.get_ckpt_path(mode), use_ema_model).eval(), config, exp
 
 
 def load_vae_from_experiment(exp_name, exp_out_root, use_ema_model=True, vae_ckpt_path=None):

@@ -83,7 +83,8 @@ struct Geo {
   static constexpr int kMiscRed2 = kMiscRed1 + kWaves * NC;
   static constexpr int kMiscTape = kMiscRed2 + kWaves * NC;  // [kMaxOps][12] ints: the step program (+ its length)
   static constexpr int kMiscSegs = kMiscTape + 1024;         // [kMaxSegs][4] ints: this workgroup's (tile, s0, s1) list
-  static constexpr int kLdsFloats = kMiscSegs + 256;
+  static constexpr int kMiscOld = kMiscSegs + 256;           // [NC] previous step's denoised row (DPM++ 2M)
+  static constexpr int kLdsFloats = kMiscOld + NC;
 };
 static_assert(Geo<64>::kLdsFloats * 4 <= 160 * 1024, "LDS budget (1 WG/CU)");
 static_assert(Geo<32>::kLdsFloats * 4 * 2 <= 160 * 1024, "LDS budget (2 WG/CU)");
@@ -1625,6 +1626,27 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
 }
 
 #pragma clang fp contract(off)
+// DPM-Solver++(2M) step of ElucidatedDiffusion.sample_using_dpmpp (elucidated_diffusion.py:259-313) on one element:
+// denoised = c_skip x + c_out net (:134, optional clamp :137); denoised_d = (1 - gamma) denoised + gamma old (:303);
+// x' = (sigma_next / sigma) x - expm1(-h) denoised_d (:305).  cf = [c_in, c_skip, c_out, 1 - gamma, gamma,
+// sigma_fn(t_next) / sigma_fn(t), expm1(-h), use_old].  Every operation rounds once, in the reference's order.
+__device__ __forceinline__ float dpmpp_update(int clamp, const float *cf, float x, float net, float *old) {
+  const float a = cf[1] * x;
+  const float b = cf[2] * net;
+  float den = a + b;
+  if (clamp) den = fminf(fmaxf(den, -1.0f), 1.0f);
+  float d = den;
+  if (cf[7] != 0.f) {
+    const float p = cf[3] * den;
+    const float q = cf[4] * *old;
+    d = p + q;
+  }
+  *old = den;
+  const float u = cf[5] * x;
+  const float v = cf[6] * d;
+  return u - v;
+}
+
 __device__ __forceinline__ float scheduler_update(int kind, int clip, const float *cf, float x, float eps, float noise) {
   float x0 = (x - cf[0] * eps) / cf[1];
   if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
@@ -1758,6 +1780,9 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     }
     // ---- init conv (k = 7, one input channel); the barrier below also publishes G
     const int C0 = d.dims[0];
+    // DPM++ feeds the network c_in(sigma) * x (elucidated_diffusion.py:127-128)
+    const float in_scale = a.sched_kind == GLDM_SCHED_DPMPP ? a.sched_coef[(size_t)step * GLDM_SCHED_COEF_STRIDE] : 1.0f;
+    const bool scale_in = a.sched_kind == GLDM_SCHED_DPMPP;
     if (!GLDM_SKIP(c, 64))
     for (int i = c.tid; i < C0 * NC; i += GG::kThreads) {
       const int ch = i / NC, n = i - ch * NC;
@@ -1767,7 +1792,11 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
 #pragma unroll
       for (int q = 0; q < 7; ++q) {
         const int p = l + q - 3;
-        if (p >= 0 && p < L) acc += wk[q] * lat[col_of(sm, p)];
+        if (p >= 0 && p < L) {
+          float xv = lat[col_of(sm, p)];
+          if (scale_in) xv = in_scale * xv;
+          acc += wk[q] * xv;
+        }
       }
       X[swz<NC>(ch, n)] = acc;
     }
@@ -1797,7 +1826,8 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
           float nz = 0.f;
           if (a.sched_kind == GLDM_SCHED_DDPM && cf[7] != 0.f && a.step_noise)
             nz = a.step_noise[((size_t)step * a.n_samples + gi) * L + l];
-          lat[c.tid] = scheduler_update(a.sched_kind, a.clip_sample, cf, lat[c.tid], e, nz);
+          if (a.sched_kind == GLDM_SCHED_DPMPP) lat[c.tid] = dpmpp_update(a.clip_sample, cf, lat[c.tid], e, lds + GG::kMiscOld + c.tid);
+          else lat[c.tid] = scheduler_update(a.sched_kind, a.clip_sample, cf, lat[c.tid], e, nz);
         }
       }
       __syncthreads();
@@ -2004,7 +2034,7 @@ int cu_count() {
 // slot ends up with (nearly) the same number of tile-steps.
 struct Plan { int grid, slots, rounds, left, chain, seglen; };
 
-Plan make_plan(int n_samples, int n_steps, int L, int nc) {
+Plan make_plan(int n_samples, int n_steps, int L, int nc, bool allow_chain = true) {
   const int slots = cu_count() * (nc == 32 ? 2 : 1);
   const int S = nc / L;
   const int tiles = (n_samples + S - 1) / S;
@@ -2018,6 +2048,7 @@ Plan make_plan(int n_samples, int n_steps, int L, int nc) {
     int g = slots / p.left;
     if (g > 8) g = 8;             // a hand-off is ~3 us; finer cuts buy nothing
     if (g > n_steps) g = n_steps;
+    if (!allow_chain) g = 1;  // DPM++ carries two rows of state per tile (x and the previous denoised): whole tiles only
     p.chain = g < 1 ? 1 : g;
     p.seglen = (n_steps + p.chain - 1) / p.chain;
   }
@@ -2040,7 +2071,7 @@ int launch_one(const RunArgs &a, int tiles, hipStream_t s) {
 int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   const bool pm = pm_supported(&a_in.d);
   const int L = a_in.d.seq_len, nc = pm ? 64 : engine_nc();
-  const Plan pl = make_plan(a_in.n_samples, a_in.n_steps, L, nc);
+  const Plan pl = make_plan(a_in.n_samples, a_in.n_steps, L, nc, a_in.sched_kind != GLDM_SCHED_DPMPP);
   const int tiles = pl.grid;
   if (tiles <= 0) return GLDM_ERR_UNSUPPORTED;  // > ~250 k samples in one launch: split the batch
   RunArgs a = a_in;

@@ -11,14 +11,16 @@ class GraspLatentDDM(nn.Module):
                  denoising_loss_weight=1, variance_type="fixed_small", elucidated_diffusion=False,
                  beta_start=5e-5, beta_end=5e-2) -> None:
         super().__init__()
-        if elucidated_diffusion:
-            raise NotImplementedError("ElucidatedDiffusion is not enabled by any shipped config (out of scope)")
         self.vae_model = None
-        self.is_elucidated_diffusion = False
-        self.diffusion_model = GaussianDiffusion1D(
-            model=model, n_dims=latent_in_features, num_steps=diffusion_timesteps, loss_type=diffusion_loss,
-            beta_schedule=beta_schedule, beta_start=beta_start, beta_end=beta_end,
-            noise_scheduler_type=noise_scheduler_type, variance_type=variance_type)
+        self.is_elucidated_diffusion = elucidated_diffusion
+        if elucidated_diffusion:  # grasp_ldm.py:58-62
+            from .elucidated import ElucidatedDiffusion
+            self.diffusion_model = ElucidatedDiffusion(net=model, seq_length=latent_in_features)
+        else:
+            self.diffusion_model = GaussianDiffusion1D(
+                model=model, n_dims=latent_in_features, num_steps=diffusion_timesteps, loss_type=diffusion_loss,
+                beta_schedule=beta_schedule, beta_start=beta_start, beta_end=beta_end,
+                noise_scheduler_type=noise_scheduler_type, variance_type=variance_type)
         self.is_conditioned, self.joint_training, self.loss_weight = is_conditioned, joint_training, denoising_loss_weight
         self.is_vae_frozen = False
 
@@ -37,7 +39,10 @@ class GraspLatentDDM(nn.Module):
         self.vae_model.load_state_dict(state_dict, strict=True)
 
     def set_inference_timesteps(self, num_inference_steps):
-        self.diffusion_model.set_inference_timesteps(num_inference_steps)
+        if self.is_elucidated_diffusion:
+            self.diffusion_model.num_sample_steps = int(num_inference_steps)
+        else:
+            self.diffusion_model.set_inference_timesteps(num_inference_steps)
 
     @torch.no_grad()
     def generate_grasps(self, xyz, num_grasps=10, return_intermediate=False, **kwargs):
@@ -47,9 +52,12 @@ class GraspLatentDDM(nn.Module):
         n = z_pc.shape[0] * num_grasps
         # `metas` travels through **kwargs down to the denoiser call in the reference; TimeConditionedResNet1D
         # ignores it (resnets.py:565), the class-conditioned one reads metas["mode_cls"] (class_conditioned_resnet.py:73)
-        if not hasattr(self.diffusion_model.model, "class_embedding"):
-            kwargs.pop("metas", None)
+        denoiser = self.diffusion_model.net if self.is_elucidated_diffusion else self.diffusion_model.model
+        if self.is_elucidated_diffusion or not hasattr(denoiser, "class_embedding"):
+            kwargs.pop("metas", None)  # (the reference forwards it into sample_using_dpmpp, which raises TypeError)
         kwargs.setdefault("device", xyz.device)
+        if self.is_elucidated_diffusion:
+            kwargs.pop("x_T", None)
         out, all_outs = self.diffusion_model.sample(z_cond=z_pc, batch_size=n, return_all=return_intermediate,
                                                     samples_per_cond=num_grasps, **kwargs)
         final = self.vae_model.decoder(out.squeeze(-2), z_pc, samples_per_cond=num_grasps)

@@ -130,18 +130,25 @@ class InferenceLDM(_InferenceBase):
                  use_fast_sampler=True, num_inference_steps=None, augment_pc=False, load_dataset=False,
                  device="cuda:0", model=None):
         super().__init__(device)
-        if use_elucidated:
-            raise NotImplementedError("ElucidatedDiffusion / DPM++ is not enabled by any shipped config")
         self.use_ema_model = use_ema_model
-        self.fast_sampler = "DDIM" if use_fast_sampler else None
-        self.num_inference_steps = (100 if num_inference_steps is None else num_inference_steps) if use_fast_sampler \
-            else num_inference_steps
+        self.ddm_mode = "ddm" if not use_elucidated else "elucidated_ddm"
+        # _setup_ldm_sampler, tools/inference.py:463-490
+        if use_fast_sampler:
+            self.fast_sampler = "DDIM" if not use_elucidated else "DPMPP"
+            default_steps = 100 if not use_elucidated else 32
+            self.num_inference_steps = default_steps if num_inference_steps is None else num_inference_steps
+        else:
+            if use_elucidated:
+                raise NotImplementedError("the elucidated model is sampled with DPM++ only (use_fast_sampler=True): the "
+                                          "stochastic Heun sampler is not built")
+            self.fast_sampler, self.num_inference_steps = None, num_inference_steps
         if model is not None:
             self.model = model.to(self.device).eval()
         else:
             from .checkpoint import load_ldm_from_experiment
-            m, self.config, self.experiment = load_ldm_from_experiment(exp_name, exp_out_root, use_ema_model,
-                                                                        ddm_ckpt_path, use_fast_sampler)
+            m, self.config, self.experiment = load_ldm_from_experiment(
+                exp_name, exp_out_root, use_ema_model, ddm_ckpt_path if not use_elucidated else elucidated_ckpt_path,
+                use_fast_sampler and not use_elucidated, mode=self.ddm_mode)
             self.model = m.to(self.device).eval()
         if load_dataset:
             warnings.warn("ACRONYM dataset loading is out of scope; use generate_grasps(pc, metas)")
@@ -149,12 +156,19 @@ class InferenceLDM(_InferenceBase):
     @torch.no_grad()
     def generate_grasps(self, pc, metas, num_grasps=10, return_intermediate=False, x_T=None, **kwargs):
         batch = (pc.unsqueeze(0) if pc.ndim == 2 else pc).to(self.device)
-        if self.num_inference_steps is not None:
+        extra_sampler = {}
+        if self.fast_sampler == "DPMPP":  # tools/inference.py:607-609
+            extra_sampler = dict(use_dpmpp=True, num_sample_steps=self.num_inference_steps)
+            if "noise" in kwargs:
+                extra_sampler["noise"] = kwargs["noise"]
+        elif self.num_inference_steps is not None:
             self.model.set_inference_timesteps(self.num_inference_steps)
         if return_intermediate and batch.shape[0] > 1:  # the reference raises after sampling; fail before the work
             raise NotImplementedError("Batched grasps for all diffusion steps are not implemented")
         extra = {k: kwargs[k] for k in ("step_noise", "cls_cond") if k in kwargs}
-        if hasattr(self.model.diffusion_model.model, "class_embedding"):
+        extra.update(extra_sampler)
+        denoiser = getattr(self.model.diffusion_model, "model", None) or getattr(self.model.diffusion_model, "net")
+        if hasattr(denoiser, "class_embedding"):
             extra["metas"] = {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in metas.items()}
         (tmrp, logit), steps = self.model.generate_grasps(batch, num_grasps=num_grasps,
                                                           return_intermediate=return_intermediate, x_T=x_T, **extra)

@@ -52,9 +52,10 @@ class R1dEngine:
         return out
 
     def denoise(self, x_in, cemb, samples_per_cond, timesteps=None, sample_t=None, sched_kind=SCHED_NONE,
-                clip_sample=True, coef=None, step_noise=None, sample_emb=None):
+                clip_sample=True, coef=None, step_noise=None, sample_emb=None, temb=None):
         """x_in [n, 1, L] -> x after all steps (or eps when sched_kind == NONE).  sample_emb [n, E]: per-sample
-        embedding added to the time embedding (class conditioning)."""
+        embedding added to the time embedding (class conditioning).  temb [T, E]: time-embedding table to use instead of
+        the engine's integer-timestep one (continuous-time samplers: one row per step)."""
         n = x_in.shape[0]
         x_in = x_in.contiguous().float()
         if sample_emb is not None:
@@ -65,7 +66,8 @@ class R1dEngine:
         n_steps = 1 if timesteps is None else int(timesteps.numel())
         ws = self._workspace(n)
         with torch.cuda.device(self.device):
-            L.call("gldm_denoise", self._desc_ptr(), L.ptr(self.weights), L.ptr(self.temb), L.ptr(cemb),
+            tab = self.temb if temb is None else temb.contiguous().float()
+            L.call("gldm_denoise", self._desc_ptr(), L.ptr(self.weights), L.ptr(tab), L.ptr(cemb),
                    int(samples_per_cond), L.ptr(x_in), n, L.ptr(timesteps), L.ptr(sample_t), n_steps, int(sched_kind),
                    1 if clip_sample else 0, L.ptr(coef), L.ptr(step_noise), L.ptr(sample_emb), L.ptr(out), L.ptr(ws),
                    L.current_stream(self.device))

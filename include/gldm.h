@@ -182,13 +182,18 @@ typedef struct gldm_r1d_desc {
   int32_t n_head;       /* 7                                                      */
 } gldm_r1d_desc;
 
-enum gldm_sched_kind { GLDM_SCHED_NONE = 0, GLDM_SCHED_DDIM = 1, GLDM_SCHED_DDPM = 2 };
+enum gldm_sched_kind { GLDM_SCHED_NONE = 0, GLDM_SCHED_DDIM = 1, GLDM_SCHED_DDPM = 2, GLDM_SCHED_DPMPP = 3 };
 #define GLDM_SCHED_COEF_STRIDE 8
 /* per-step coefficient row (f32, computed on the host exactly like the
  * scheduler library does on 0-dim f32 tensors):
  *   [0] sqrt(1-abar_t) [1] sqrt(abar_t)
  *   DDIM: [2] sqrt(abar_prev) [3] sqrt(1-abar_prev-sigma^2)
- *   DDPM: [4] coef_x0 [5] coef_xt [6] sqrt(variance) [7] 1 if noise is added (t>0) */
+ *   DDPM: [4] coef_x0 [5] coef_xt [6] sqrt(variance) [7] 1 if noise is added (t>0)
+ * GLDM_SCHED_DPMPP (ref: grasp_ldm/models/diffusion/elucidated_diffusion.py:259-313, DPM-Solver++(2M) of
+ * ElucidatedDiffusion; the network sees c_in x and time = c_noise(sigma), so `temb` holds one row per STEP and
+ * timesteps = 0..n_steps-1; clip_sample = the sampler's `clamp`):
+ *   [0] c_in [1] c_skip [2] c_out [3] 1-gamma [4] gamma [5] sigma_fn(t_next)/sigma_fn(t) [6] expm1(-h)
+ *   [7] 1 if the previous step's denoised row is blended in (not on the first step, not when sigma_next = 0) */
 
 /* ref: resnets.py:484-494,587-594 (input_emb_layers = Linear + SiLU on z_cond).
  * cemb[i,r,:] = silu(W z_cond[i,r,:] + b). */

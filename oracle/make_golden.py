@@ -236,7 +236,40 @@ def class_cond_golden():
     _save("class_denoiser.npz", x=x, z_cond=zc, cls=cls, t=np.array(ts), eps=eps)
 
 
+def dpmpp_golden():
+    """the reference's ElucidatedDiffusion.sample_using_dpmpp (pure reference code: elucidated_diffusion.py
+    + resnets.py) around the fpc denoiser with recipe weights (seed 0), 8 latents, 20 steps, with and without clamp."""
+    ref_import.install_shims()
+    from grasp_ldm.models.diffusion.elucidated_diffusion import ElucidatedDiffusion
+    from grasp_ldm.models.modules.resnets import TimeConditionedResNet1D
+    net = TimeConditionedResNet1D(dim=4, channels=1, block_channels=(32, 64, 128, 256), input_conditioning_dims=64,
+                                  resnet_block_groups=4, dropout=0.1, is_time_conditioned=True, learned_variance=False,
+                                  learned_sinusoidal_cond=False, random_fourier_features=True)
+    # the denoiser weights of the full fpc recipe state dict (seed 0), so tests can use their `fpc_state_dict` fixture
+    import json
+    with open(os.path.join(OUT, "schema_fpc_ldm.json")) as f:
+        schema = {k: (tuple(sh), getattr(torch, dt)) for k, (sh, dt) in json.load(f).items()}
+    full = synthetic.synthetic_state_dict(schema, seed=0)
+    pre = "diffusion_model.model."
+    net.load_state_dict({k[len(pre):]: v for k, v in full.items() if k.startswith(pre)}, strict=True)
+    ed = ElucidatedDiffusion(net=net, seq_length=4).eval()
+    zc = _cond(8, 41)
+    out = {"z_cond": zc}
+    for name, clamp in (("plain", False), ("clamp", True)):
+        torch.manual_seed(SEED)
+        noise = torch.randn(8, 1, 4)
+        torch.manual_seed(SEED)
+        x, all_x = ed.sample(use_dpmpp=True, batch_size=8, z_cond=zc, num_sample_steps=20, clamp=clamp, return_all=False)
+        assert torch.equal(all_x[0], ed.sample_schedule(20)[0] * noise)
+        out["noise"], out["x_" + name] = noise, x
+    _save("dpmpp.npz", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "dpmpp":
+        os.makedirs(OUT, exist_ok=True)
+        dpmpp_golden()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "class_cond":
         os.makedirs(OUT, exist_ok=True)
         class_cond_golden()

@@ -118,6 +118,49 @@ def resnet1d_forward(sd, p, x, z_cond=None, time=None, groups=4, cls_cond=None):
     return F.conv1d(x, sd[p + "final_conv.weight"], sd[p + "final_conv.bias"])
 
 
+def dpmpp_sample(sd, p, z_cond, noise, num_sample_steps=20, clamp=False, groups=4, sigma_min=0.002, sigma_max=80,
+                 sigma_data=0.5, rho=7):
+    """ElucidatedDiffusion.sample_using_dpmpp, elucidated_diffusion.py:259-313 (schedule :149-162,
+    preconditioned_network_forward :117-139 with c_skip/c_out/c_in/c_noise :103-115).  noise = the unit-normal
+    draw that the reference scales by sigmas[0] (:281)."""
+    N = num_sample_steps
+    inv_rho = 1 / rho
+    steps = torch.arange(N, dtype=torch.float32)
+    sigmas = (sigma_max ** inv_rho + steps / (N - 1) * (sigma_min ** inv_rho - sigma_max ** inv_rho)) ** rho
+    sigmas = F.pad(sigmas, (0, 1), value=0.0)
+    x = sigmas[0] * noise
+    batch = x.shape[0]
+
+    def precond(xx, sigma):
+        sg = torch.full((batch,), sigma)
+        ps = sg.reshape(-1, 1, 1)
+        c_in = 1 * (ps ** 2 + sigma_data ** 2) ** -0.5
+        c_skip = (sigma_data ** 2) / (ps ** 2 + sigma_data ** 2)
+        c_out = ps * sigma_data * (sigma_data ** 2 + ps ** 2) ** -0.5
+        c_noise = torch.log(sg.clamp(min=1e-20)) * 0.25
+        net = resnet1d_forward(sd, p, c_in * xx, z_cond=z_cond, time=c_noise, groups=groups)
+        out = c_skip * xx + c_out * net
+        return out.clamp(-1.0, 1.0) if clamp else out
+
+    sigma_fn = lambda t: t.neg().exp()
+    t_fn = lambda sigma: sigma.log().neg()
+    old = None
+    for i in range(len(sigmas) - 1):
+        den = precond(x, sigmas[i].item())
+        t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+        h = t_next - t
+        if old is None or sigmas[i + 1] == 0:
+            d = den
+        else:
+            h_last = t - t_fn(sigmas[i - 1])
+            r = h_last / h
+            gamma = -1 / (2 * r)
+            d = (1 - gamma) * den + gamma * old
+        x = (sigma_fn(t_next) / sigma_fn(t)) * x - (-h).expm1() * d
+        old = den
+    return x
+
+
 def decoder_forward(sd, p, z_h, cond, groups=4):
     """ConditionalGraspPoseDecoder.forward, grasp_vae.py:401-436 (no qualities)."""
     h = F.linear(z_h, sd[p + "in_layer.weight"], sd[p + "in_layer.bias"]).unsqueeze(-2)
