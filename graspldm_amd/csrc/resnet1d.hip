@@ -2125,6 +2125,98 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   return rc;
 }
 
+
+// ============================================================== fused pointwise MLP layer ==
+// y[b, :, cols] = act(W x[b, :, cols] + bias) for a k = 1 Conv1d + folded BatchNorm + ReLU of SharedMLP
+// (ext/pvcnn/modules/shared_mlp.py:6-35) in the native [B, C, N] layout, and optionally, on the accumulators
+// before they are stored, the head  z[b, :, cols] = Wh y + bh  (PVCNNEncoder: conv_downscale + out_layer[0]
+// folded, pc_encoders.py:104-111).  With the head fused `y` may be NULL: the encoder's [B, 1536, N] tensor
+// (1.6 GB per 256 clouds) then never reaches HBM.
+// A persistent workgroup of 8 waves takes 32 points of one cloud at a time: the [cin][32] input tile is staged
+// once in LDS (swizzled like the engine's activations) and every wave sweeps its share of the output rows over it
+// with the engine's GEMM core, weights streamed as buffer-load fragments.  The head product uses each 16-row
+// block of y straight from the accumulators as the B operand (lane (kq, col) register r = row 4 kq + r = k-step
+// r of a 16x16x4 MFMA), against head weights packed in that k order; the waves' partial z tiles meet in LDS.
+struct PwArgs {
+  const float *x, *w, *bias, *head_w, *head_b;
+  float *y, *z;
+  int cin, cout, n, relu, hout, tiles_per_cloud, total_tiles;
+};
+
+__global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
+  constexpr int NC = 32;
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Ctx c{a.w, lds, tid, wave, lane, 0, 2};
+  const int col = lane & 15, kq = lane >> 4;
+  const int cblocks = a.cin >> 4, mtiles = a.cout >> 4, mt_per_wave = mtiles >> 3;
+  float *zpart = lds + a.cin * NC;  // [8 waves][16 rows][32 cols]
+  const WStream hw(a.head_w ? a.head_w : a.w, lane);
+  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    const int b = tile / a.tiles_per_cloud, c0 = (tile - b * a.tiles_per_cloud) * NC;
+    __syncthreads();  // the previous tile's readers are done
+    const float *xb = a.x + (size_t)b * a.cin * a.n + c0;
+    for (int i = tid; i < a.cin * 8; i += 512) {
+      const int row = i >> 3, q = i & 7;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + (size_t)row * a.n + 4 * q);
+      *reinterpret_cast<f32x4 *>(lds + swz<NC>(row, 4 * q)) = v;
+    }
+    __syncthreads();
+    f32x4 zacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int ps = 0; ps < mt_per_wave; ps += 2) {
+      const int mt0 = wave * mt_per_wave + ps;
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + 16 * (mt0 + mi) + 4 * kq);
+        acc[mi][0] = bv;
+        acc[mi][1] = bv;
+      }
+      if ((cblocks & 3) == 0) gemm_fast_pf<NC, 4, 1, 2, 2, 4>(c, a.w, cblocks, mt0, 0, lds, acc);
+      else gemm_fast_pf<NC, 4, 1, 2, 2, 2>(c, a.w, cblocks, mt0, 0, lds, acc);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        if (a.relu) {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
+        }
+        if (a.y) {
+          float *yb = a.y + ((size_t)b * a.cout + 16 * (mt0 + mi) + 4 * kq) * a.n + c0 + col;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) __builtin_nontemporal_store(acc[mi][ni][r], yb + (size_t)r * a.n + 16 * ni);
+        }
+        if (a.head_w) {
+          const f32x4 ah = hw[(size_t)(mt0 + mi) * 64];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              zacc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[r], acc[mi][ni][r], zacc[ni], 0, 0, 0);
+        }
+      }
+    }
+    if (a.head_w) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zpart[(wave * 16 + 4 * kq + r) * NC + 16 * ni + col] = zacc[ni][r];
+      __syncthreads();
+      for (int i = tid; i < a.hout * NC; i += 512) {
+        const int row = i / NC, cc = i - row * NC;
+        float v = a.head_b ? a.head_b[row] : 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += zpart[(w8 * 16 + row) * NC + cc];
+        a.z[((size_t)b * a.hout + row) * a.n + c0 + cc] = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 GLDM_API int gldm_r1d_cond_embed(const float *z_cond, const float *w, const float *b, int n_cond, int rows, int dc,
@@ -2193,6 +2285,34 @@ GLDM_API int gldm_pose_epilogue(const float *tmrp, const float *logit, const flo
   if (confidence && !logit) return GLDM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(pose_epilogue_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      tmrp, logit, grasp_mean, grasp_std, n, grasps_per_cloud, H, tmrp_unnorm, confidence);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+
+GLDM_API int gldm_pointwise_mlp(const float *x, const float *w_packed, const float *bias, int b, int cin, int cout,
+                                int n, int relu, const float *head_w_packed, const float *head_bias, int hout,
+                                float *y, float *z, gldm_stream_t stream) {
+  if (!x || !w_packed || !bias || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
+  if (!y && !head_w_packed) return GLDM_ERR_INVALID_ARG;
+  if (head_w_packed && (!z || hout <= 0 || hout > 16)) return GLDM_ERR_INVALID_ARG;
+  if ((cin & 31) || (cout & 255) || (n & 31)) return GLDM_ERR_UNSUPPORTED;  // k-blocks in pairs, 2 m-tiles x 8 waves, 32-point tiles
+  const size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32) * sizeof(float);
+  if (lds_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pointwise_mlp_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  PwArgs a{};
+  a.x = x; a.w = w_packed; a.bias = bias; a.head_w = head_w_packed; a.head_b = head_bias; a.y = y; a.z = z;
+  a.cin = cin; a.cout = cout; a.n = n; a.relu = relu; a.hout = hout;
+  a.tiles_per_cloud = n / 32;
+  a.total_tiles = b * a.tiles_per_cloud;
+  const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
+  int grid = cu_count() * per_cu;
+  if (grid > a.total_tiles) grid = a.total_tiles;
+  hipLaunchKernelGGL(pointwise_mlp_kernel, dim3(grid), dim3(512), lds_bytes, reinterpret_cast<hipStream_t>(stream), a);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 

@@ -47,6 +47,37 @@ def _gemm_bias_act(x, w2d, bias, relu):
     return y.reshape(shape[0], w2d.shape[0], *shape[2:])
 
 
+def pack_head(wh):
+    """[hout <= 16, cout] head weights for gldm_pointwise_mlp: A-fragment order with the k index of every 16-block
+    permuted so that k-step r holds rows {4 kq + r} of a 16-row block of y, the order in which a lane's accumulator
+    registers hold them (k' = 4 (k % 4) + k // 4)."""
+    from .r1d_pack import mfma_a_fragments
+    hout, cout = wh.shape
+    w = torch.zeros(16, cout, dtype=torch.float32)
+    w[:hout] = wh.detach().float().cpu()
+    w = w.view(16, cout // 16, 4, 4).permute(0, 1, 3, 2).reshape(16, cout)   # [.., kq, r] -> [.., r, kq]
+    return mfma_a_fragments(w)
+
+
+def fused_mlp_supported(x, cin, cout):
+    return (x.ndim == 3 and x.is_contiguous() and cin % 32 == 0 and cout % 256 == 0 and x.shape[-1] % 32 == 0
+            and 4 * (32 * cin + 4096) <= 160 * 1024)
+
+
+def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True):
+    """One fused launch: y = act(W x + b) over [B, Cin, N] (hand-written f32-MFMA GEMM, csrc/resnet1d.hip:
+    pointwise_mlp_kernel) and optionally z = Wh y + bh on the accumulators.  head = (packed Wh, bh, hout)."""
+    from . import _lib as L
+    b, cin, n = x.shape
+    y = torch.empty((b, cout, n), dtype=torch.float32, device=x.device) if keep_y or head is None else None
+    z = torch.empty((b, head[2], n), dtype=torch.float32, device=x.device) if head is not None else None
+    with torch.cuda.device(x.device):
+        L.call("gldm_pointwise_mlp", L.ptr(x), L.ptr(w_packed), L.ptr(bias), b, cin, cout, n, int(relu),
+               L.ptr(head[0]) if head else None, L.ptr(head[1]) if head else None, head[2] if head else 0,
+               L.ptr(y), L.ptr(z), L.current_stream(x.device))
+    return y, z
+
+
 def pointwise_gemm(x, w2d, bias):
     """W x + b over [B, Cin, ...] with an explicit (e.g. folded) weight matrix."""
     _need_cuda(x)
@@ -59,23 +90,38 @@ def pointwise_conv(x, conv):
     return _gemm_bias_act(x.float(), conv.weight.reshape(conv.weight.shape[0], -1), conv.bias, False)
 
 
-def pointwise_conv_bn_relu(x, conv, bn):
-    """relu(BN_eval(conv(x))) with BN folded into the weights: y = relu(W' x + b').  The folded pair is
-    computed once per (weights, statistics) version, not per call."""
-    _need_cuda(x)
+def folded_conv_bn(conv, bn, device):
+    """BatchNorm(eval) folded into the k = 1 conv: (W', b', W' packed for gldm_pointwise_mlp or None), on `device`,
+    computed once per (weights, statistics) version and kept on the conv module."""
     from ._cache import params_key, publish
     src = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv.bias] if conv.bias is not None else [])
-    key = params_key(src, x.device)
+    key = params_key(src, device)
     hit = conv.__dict__.get("_gldm_folded")  # lives and dies with the module
     if hit is None or hit[0] != key:
+        from .r1d_pack import mfma_a_fragments
         s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
         w = (conv.weight.reshape(conv.weight.shape[0], -1) * s.view(-1, 1)).contiguous()
         cb = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
         b = ((cb - bn.running_mean) * s + bn.bias).contiguous()
-        hit = (key, w, b)
+        wp = None
+        if w.shape[1] % 32 == 0 and w.shape[0] % 256 == 0:
+            wp = mfma_a_fragments(w.detach().float().cpu()).to(device)
+        hit = (key, w, b, wp)
         conv.__dict__["_gldm_folded"] = hit
-        publish(x.device)
-    return _gemm_bias_act(x.float(), hit[1], hit[2], True)
+        publish(device)
+    return hit[1], hit[2], hit[3]
+
+
+def pointwise_conv_bn_relu(x, conv, bn):
+    """relu(BN_eval(conv(x))) with BN folded into the weights: y = relu(W' x + b').  Wide layers (cin % 32 == 0,
+    cout % 256 == 0) run as ONE hand-written launch (GEMM + bias + ReLU in the native layout); the others as a
+    library GEMM + the fused bias/ReLU pass."""
+    _need_cuda(x)
+    w, b, wp = folded_conv_bn(conv, bn, x.device)
+    x = x.float()
+    if wp is not None and fused_mlp_supported(x, w.shape[1], w.shape[0]):
+        return pointwise_mlp(x, wp, b, w.shape[0], True)[0]
+    return _gemm_bias_act(x, w, b, True)
 
 
 def conv3d_gn_swish(x, conv, gn):

@@ -37,11 +37,42 @@ class PVCNNEncoder(nn.Module):
         if not out.is_cuda:
             raise RuntimeError("pointcloud must be a CUDA tensor (graspldm_amd has no CPU path)")
         x = torch.transpose(out, 1, 2).contiguous()
-        x = self.pvcnn_modules(x, cond=cond)
         w, b = self._folded_head()
-        x = dense.pointwise_gemm(x, w, b)
+        x = self._backbone_and_head(x, cond, w, b)
         x = dense.linear(x, self.out_layer[1])
         return x.squeeze(1) if x.shape[-2] == 1 else x
+
+    def _backbone_and_head(self, x, cond, w, b):
+        """backbone -> head.  When the backbone ends in a wide SharedMLP layer (PVCNN: 768 -> 1536), that layer and the
+        folded head run as ONE launch: the head product is taken on the layer's accumulators and its [B, 1536, N]
+        output (1.6 GB per 256 clouds) is never written."""
+        from .pvcnn import PVCNN, SharedMLP
+        bb = self.pvcnn_modules
+        layers = list(bb.point_features) if isinstance(bb, PVCNN) else []
+        last = layers[-1] if layers else None
+        if isinstance(last, SharedMLP) and len(last.layers) == 3:
+            conv, bn = last.layers[0], last.layers[1]
+            cin, cout = conv.weight.shape[1], conv.weight.shape[0]
+            feats = x[:, : bb.in_channels, :]
+            coords = feats[:, :3, :].contiguous()
+            for layer in layers[:-1]:
+                feats, _ = layer((feats, coords))
+            feats = feats.contiguous().float()
+            if w.shape[0] <= 16 and dense.fused_mlp_supported(feats, cin, cout):
+                _, bf, wp = dense.folded_conv_bn(conv, bn, feats.device)
+                return dense.pointwise_mlp(feats, wp, bf, cout, True, head=self._packed_head(w, b), keep_y=False)[1]
+            feats = last(feats)
+            return dense.pointwise_gemm(feats, w, b)
+        return dense.pointwise_gemm(bb(x, cond=cond), w, b)
+
+    def _packed_head(self, w, b):
+        from ._cache import publish
+        hit = self.__dict__.get("_head_packed")
+        if hit is None or hit[0] is not w:
+            hit = (w, dense.pack_head(w).to(w.device), b.contiguous(), int(w.shape[0]))
+            self.__dict__["_head_packed"] = hit
+            publish(w.device)
+        return hit[1], hit[2], hit[3]
 
     def _folded_head(self):
         """conv_downscale (C -> C/2, k=1) and out_layer[0] (C/2 -> out_channels, k=1) have nothing between them

@@ -259,6 +259,18 @@ int gldm_sa_mlp_forward(const float *points /*[b,3,n]*/, const float *centers /*
                         const int32_t *cin_pad, const int32_t *cout, const int32_t *w_off, const int32_t *b_off,
                         float *out /*[b,cout_last,m]*/, gldm_stream_t stream);
 
+/* ref: grasp_ldm/models/modules/ext/pvcnn/modules/shared_mlp.py:6-35 (Conv1d k = 1 + eval BatchNorm folded + ReLU),
+ * one layer, in the native [b, c, n] layout: y = act(W x + bias).  `w_packed` = the folded weight [cout, cin] in MFMA
+ * A-fragment order (graspldm_amd/r1d_pack.py: mfma_a_fragments).  Optional fused head on the accumulators:
+ * z = Wh y + bh with hout <= 16 rows (grasp_ldm/models/modules/pc_encoders.py:104-111: conv_downscale and out_layer[0]
+ * folded into one [hout x cout] matrix); `head_w_packed` = [16, cout] in A-fragment order with the k index of every
+ * 16-block permuted k' = 4 (k % 4) + k / 4 (graspldm_amd/dense.py: pack_head).  With a head, y may be NULL and the
+ * [b, cout, n] tensor never reaches HBM.  cin % 32 == 0, cout % 256 == 0, n % 32 == 0, 4 (32 cin + 4096) <= 160 KiB. */
+int gldm_pointwise_mlp(const float *x /*[b,cin,n]*/, const float *w_packed, const float *bias /*[cout]*/,
+                       int b, int cin, int cout, int n, int relu,
+                       const float *head_w_packed, const float *head_bias /*[hout] or NULL*/, int hout,
+                       float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
+
 /* ---------------------------------------------------------- voxel branch of PVConv */
 
 /* ref: grasp_ldm/models/modules/ext/pvcnn/modules/pvconv.py:48-66 (nn.Conv3d k=3 p=1 on the
