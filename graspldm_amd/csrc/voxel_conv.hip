@@ -75,18 +75,38 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
     for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = bvv;
   }
 
+  // Staging map, computed once: thread t copies brick elements t, t + 256, ... (< bv <= 4 x 256 for r <= 26) of every
+  // channel; their grid offsets / validity do not depend on the channel, so the per-block staging loop below has
+  // no division in it (the index arithmetic used to cost as much as the block's MFMAs).
+  constexpr int kStageMax = 6;
+  int s_lds[kStageMax], s_glb[kStageMax];
+#pragma unroll
+  for (int q = 0; q < kStageMax; ++q) {
+    const int rem = tid + q * kConvThreads;
+    s_lds[q] = rem < bv ? rem : -1;
+    s_glb[q] = -1;
+    if (rem < bv) {
+      const int ixy = rem / zp, izp = rem - ixy * zp;
+      const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1, gz = izp - 1;
+      if ((unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r && (unsigned)gz < (unsigned)r)
+        s_glb[q] = (gx * r + gy) * r + gz;
+    }
+  }
   for (int cb = 0; cb < cblocks; ++cb) {
     __syncthreads();  // previous block's reads are done
     // ---- stage 16 input channels of the haloed brick (zero outside the grid / past Cin)
-    for (int e = tid; e < 16 * bv; e += kConvThreads) {
-      const int ci = e / bv, rem = e - ci * bv;
-      const int ixy = rem / zp, izp = rem - ixy * zp;
-      const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1, gz = izp - 1;
-      const int ch = cb * 16 + ci;
-      float v = 0.f;
-      if (ch < cin && (unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r && (unsigned)gz < (unsigned)r)
-        v = x[(size_t)ch * r3 + (gx * r + gy) * r + gz];
-      lds[ci * bvp + rem] = v;
+#pragma unroll
+    for (int q = 0; q < kStageMax; ++q) {
+      if (s_lds[q] >= 0) {
+        const float *xc = x + (size_t)(cb * 16) * r3;
+        float *lc = lds + s_lds[q];
+#pragma unroll 4
+        for (int ci = 0; ci < 16; ++ci) {
+          float v = 0.f;
+          if (cb * 16 + ci < cin && s_glb[q] >= 0) v = xc[(size_t)ci * r3 + s_glb[q]];
+          lc[ci * bvp] = v;
+        }
+      }
     }
     __syncthreads();
     // ---- 27 taps x JN k-steps of MFMA; weights one tap ahead, B fragments (LDS) one k-step ahead
@@ -333,6 +353,7 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int mt = (cout + 15) / 16, ntw = r / 4;
   if (r % 4 || (size_t)16 * brick_row_stride(r) * 4 > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
+  if (36 * (r + 2) > 6 * kConvThreads) return GLDM_ERR_UNSUPPORTED;  // staging map: 6 brick elements per thread (r <= 40)
 #define GLDM_CONV_CASE(M, N) \
   if (mt == M && ntw == N) return launch_conv<M, N>(x, w_packed, bias, b, cin, cout, r, y, partial, s)
   GLDM_CONV_CASE(3, 6);   // 48 ch @ 24^3  (shipped fpc/ppc PVCNN encoder)
