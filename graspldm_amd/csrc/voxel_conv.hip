@@ -75,13 +75,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
     for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = bvv;
   }
 
-  // Staging map, computed once: thread t copies brick elements t, t + 256, ... (< bv <= 4 x 256 for r <= 26) of every
-  // channel; their grid offsets / validity do not depend on the channel, so the per-block staging loop below has
-  // no division in it (the index arithmetic used to cost as much as the block's MFMAs).
-  constexpr int kStageMax = 6;
-  int s_lds[kStageMax], s_glb[kStageMax];
+  // Staging map, computed once: thread t copies brick elements t, t + 256, ... (SQ of them) of every channel; their
+  // grid offsets / validity do not depend on the channel, so the per-block staging has no division in it (the index
+  // arithmetic used to cost as much as the block's MFMAs).
+  constexpr int SQ = (36 * (4 * NTW + 2) + kConvThreads - 1) / kConvThreads;  // r = 4 NTW: 4 at r = 24, 2 at r = 12
+  int s_lds[SQ], s_glb[SQ];
 #pragma unroll
-  for (int q = 0; q < kStageMax; ++q) {
+  for (int q = 0; q < SQ; ++q) {
     const int rem = tid + q * kConvThreads;
     s_lds[q] = rem < bv ? rem : -1;
     s_glb[q] = -1;
@@ -92,22 +92,38 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
         s_glb[q] = (gx * r + gy) * r + gz;
     }
   }
+  // The staging is a latency problem (60 KB per block and workgroup, every load a memory round trip), so the NEXT
+  // block's 16 channels x SQ elements are requested before the current block's MFMA loop and only written to LDS
+  // after it: the round trips hide behind 1944 MFMAs per wave.
+  constexpr int kStageCh = JN == 1 ? 4 : 16;  // a <= 4-channel input only ever reads LDS rows 0..3 (one k-step per tap)
+  float stg[SQ][kStageCh];
+  auto stage_load = [&](int cb) {
+    const float *xc = x + (size_t)(cb * 16) * r3;
+#pragma unroll
+    for (int q = 0; q < SQ; ++q)
+#pragma unroll
+      for (int ci = 0; ci < kStageCh; ++ci) {
+        stg[q][ci] = 0.f;
+        if (s_glb[q] >= 0 && cb * 16 + ci < cin) stg[q][ci] = xc[(size_t)ci * r3 + s_glb[q]];
+      }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int q = 0; q < SQ; ++q)
+      if (s_lds[q] >= 0) {
+        float *lc = lds + s_lds[q];
+#pragma unroll
+        for (int ci = 0; ci < kStageCh; ++ci) lc[ci * bvp] = stg[q][ci];
+      }
+  };
+  constexpr bool kPipe = SQ <= 4;  // 64 staged registers beside the accumulators; wider bricks (r = 32) stage in place
+  if (kPipe) stage_load(0);
   for (int cb = 0; cb < cblocks; ++cb) {
     __syncthreads();  // previous block's reads are done
-    // ---- stage 16 input channels of the haloed brick (zero outside the grid / past Cin)
-#pragma unroll
-    for (int q = 0; q < kStageMax; ++q) {
-      if (s_lds[q] >= 0) {
-        const float *xc = x + (size_t)(cb * 16) * r3;
-        float *lc = lds + s_lds[q];
-#pragma unroll 4
-        for (int ci = 0; ci < 16; ++ci) {
-          float v = 0.f;
-          if (cb * 16 + ci < cin && s_glb[q] >= 0) v = xc[(size_t)ci * r3 + s_glb[q]];
-          lc[ci * bvp] = v;
-        }
-      }
-    }
+    if (!kPipe) stage_load(cb);
+    stage_store();
+    if (kPipe && cb + 1 < cblocks) stage_load(cb + 1);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     // ---- 27 taps x JN k-steps of MFMA; weights one tap ahead, B fragments (LDS) one k-step ahead
     f32x4 a_cur[MT], a_nxt[MT];
@@ -118,15 +134,25 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
     for (int ni = 0; ni < NTW; ++ni) bf[ni] = l3[obase[ni]];  // tap 0, k-step 0
     for (int tap = 0; tap < 27; ++tap) {
       const int tn = tap + 1 < 27 ? tap + 1 : tap;
+#ifndef GLDM_C3_NO_A
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) a_nxt[mi] = wv[((size_t)mi * kblocks + tn * cblocks + cb) * 64];
+#else
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) a_nxt[mi] = a_cur[mi];
+#endif
       const int toff = ((tap / 9) * 6 + (tap / 3) % 3) * zp + tap % 3;
       const int tnoff = ((tn / 9) * 6 + (tn / 3) % 3) * zp + tn % 3;
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
         const int noff = j + 1 < JN ? toff + 4 * (j + 1) * bvp : tnoff;  // the read after the last one is redundant
+#ifndef GLDM_C3_NO_B
 #pragma unroll
         for (int ni = 0; ni < NTW; ++ni) bn[ni] = l3[obase[ni] + noff];
+#else
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) bn[ni] = bf[ni] + (float)noff * 1e-9f;
+#endif
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -353,7 +379,7 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int mt = (cout + 15) / 16, ntw = r / 4;
   if (r % 4 || (size_t)16 * brick_row_stride(r) * 4 > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
-  if (36 * (r + 2) > 6 * kConvThreads) return GLDM_ERR_UNSUPPORTED;  // staging map: 6 brick elements per thread (r <= 40)
+
 #define GLDM_CONV_CASE(M, N) \
   if (mt == M && ntw == N) return launch_conv<M, N>(x, w_packed, bias, b, cin, cout, r, y, partial, s)
   GLDM_CONV_CASE(3, 6);   // 48 ch @ 24^3  (shipped fpc/ppc PVCNN encoder)
