@@ -315,3 +315,49 @@ def test_return_intermediate_all_steps(ldm):
     pcs2, metas2 = synthetic_batch(2, 1024)
     with pytest.raises(NotImplementedError):
         inf.generate_grasps(pcs2, metas2, num_grasps=4, return_intermediate=True)
+
+
+@pytest.mark.parametrize("b,cin,cout,n,relu,hout", [(3, 96, 768, 1024, True, 0), (2, 768, 1536, 64, True, 3),
+                                                     (1, 32, 256, 32, False, 16), (5, 64, 256, 96, True, 1)])
+def test_pointwise_mlp_layer_and_fused_head(b, cin, cout, n, relu, hout):
+    """gldm_pointwise_mlp (k = 1 conv + folded BN + ReLU, optional head on the accumulators) vs torch-CPU f32 matmul.
+    2e-5 relative to the output scale: same k-ordered f32 accumulation, different blocking."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from graspldm_amd import dense
+    from graspldm_amd.r1d_pack import mfma_a_fragments
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(b, cin, n, generator=g)
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, generator=g)
+    y_ref = torch.einsum("oc,bcn->bon", w, x) + bias.view(1, -1, 1)
+    if relu:
+        y_ref = y_ref.relu()
+    head = None
+    if hout:
+        wh, bh = torch.randn(hout, cout, generator=g) / cout ** 0.5, torch.randn(hout, generator=g)
+        z_ref = torch.einsum("oc,bcn->bon", wh, y_ref) + bh.view(1, -1, 1)
+        head = (dense.pack_head(wh).cuda(), bh.cuda(), hout)
+    assert dense.fused_mlp_supported(x.cuda(), cin, cout)
+    y, z = dense.pointwise_mlp(x.cuda(), mfma_a_fragments(w).cuda(), bias.cuda(), cout, relu, head=head, keep_y=True)
+    assert _err(y, y_ref) < 2e-5 * max(1.0, y_ref.abs().max().item())
+    if hout:
+        assert _err(z, z_ref) < 2e-5 * max(1.0, z_ref.abs().max().item())
+        _, z2 = dense.pointwise_mlp(x.cuda(), mfma_a_fragments(w).cuda(), bias.cuda(), cout, relu, head=head, keep_y=False)
+        assert torch.equal(z, z2)   # the head does not depend on whether y is also written
+
+
+def test_pointwise_mlp_rejects_unsupported_shapes():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from graspldm_amd import _lib as L
+    x = torch.zeros(1, 48, 64, device="cuda")
+    w = torch.zeros(256 * 48, device="cuda")
+    bias = torch.zeros(256, device="cuda")
+    y = torch.zeros(1, 256, 64, device="cuda")
+    with pytest.raises(L.GldmError, match="shape not supported"):   # cin % 32 != 0
+        L.call("gldm_pointwise_mlp", L.ptr(x), L.ptr(w), L.ptr(bias), 1, 48, 256, 64, 1, None, None, 0, L.ptr(y), None,
+               L.current_stream(x.device))
+    with pytest.raises(L.GldmError):                           # neither y nor a head
+        L.call("gldm_pointwise_mlp", L.ptr(x), L.ptr(w), L.ptr(bias), 1, 64, 256, 64, 1, None, None, 0, None, None,
+               L.current_stream(x.device))

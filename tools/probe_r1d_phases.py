@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''
 import os, sys, time, json, torch
 sys.path.insert(0, %r)
+from graspldm_amd import _lib
+if os.environ.get('GLDM_LIB'): _lib.LIB_PATH = os.environ['GLDM_LIB']
 from graspldm_amd.pipeline import build_fpc_ldm
 from graspldm_amd.r1d_pack import SCHED_DDIM
 ldm = build_fpc_ldm(device="cuda:0"); ldm.set_inference_timesteps(100)
