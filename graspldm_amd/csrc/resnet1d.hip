@@ -838,24 +838,8 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
     red1[(c.wave * 2 + slot) * 16 + sm] = s1;
     red2[(c.wave * 2 + slot) * 16 + sm] = s2;
   }
-  __syncthreads();
-  float tot = 0.f, ps1[kParts], ps2[kParts];
-#pragma unroll
-  for (int q = 0; q < kParts; ++q) {
-    const int pw = GK == 0 ? ((c.wave & ~1) + q) : (GK == 1 ? ((c.wave & 3) + 4 * q) : ((c.wave & 1) + 2 * q));
-    ps1[q] = red1[(pw * 2 + slot) * 16 + sm];
-    ps2[q] = red2[(pw * 2 + slot) * 16 + sm];
-    tot += ps1[q];
-  }
-  const float mean = tot * (1.0f / (float)(kNloc * kParts));
-  float m2 = 0.f;
-#pragma unroll
-  for (int q = 0; q < kParts; ++q) {
-    const float dm = ps1[q] * (1.0f / (float)kNloc) - mean;
-    m2 += ps2[q] + (float)kNloc * dm * dm;
-  }
-  const float rstd = __builtin_amdgcn_rsqf(m2 * (1.0f / (float)(kNloc * kParts)) + 1e-5f);
-  // ---- scale / shift rows of this lane's sample: the same for all positions, once per m-tile
+  // ---- scale / shift rows of this lane's sample (the same for all positions: once per m-tile).  They do not depend
+  // on the statistics, so they are issued in front of the exchange barrier: the MFMA chain runs while the wave waits
   if (has_ss) {
     const lds_f *Gs = (const lds_f *)(c.lds + GG::kMiscG) + sm * g.E;
     float gb[4];
@@ -880,6 +864,23 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
       }
     }
   }
+  __syncthreads();
+  float tot = 0.f, ps1[kParts], ps2[kParts];
+#pragma unroll
+  for (int q = 0; q < kParts; ++q) {
+    const int pw = GK == 0 ? ((c.wave & ~1) + q) : (GK == 1 ? ((c.wave & 3) + 4 * q) : ((c.wave & 1) + 2 * q));
+    ps1[q] = red1[(pw * 2 + slot) * 16 + sm];
+    ps2[q] = red2[(pw * 2 + slot) * 16 + sm];
+    tot += ps1[q];
+  }
+  const float mean = tot * (1.0f / (float)(kNloc * kParts));
+  float m2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < kParts; ++q) {
+    const float dm = ps1[q] * (1.0f / (float)kNloc) - mean;
+    m2 += ps2[q] + (float)kNloc * dm * dm;
+  }
+  const float rstd = __builtin_amdgcn_rsqf(m2 * (1.0f / (float)(kNloc * kParts)) + 1e-5f);
   lds_f *d3 = (lds_f *)(g.mode == 2 ? g.res : dst);
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi)
@@ -1012,16 +1013,34 @@ __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInt
   for (int co = 0; co < 4; ++co) X[swz<NC>(co, n)] = x[co] + z[co];
 }
 
-// LinearAttention core for one head pair (qkv [192][64] -> 64 rows of o), position-major: wave = (head of the
-// pair, position), lane = (sample, part): 8 of the head's 32 channels at column 16 * position + sample.  The
-// sample's four key / value columns are the same lane's columns in the four position tiles; every reduction
-// over the parts is a permlane swap inside the wave: no LDS exchange, one barrier.
+// LinearAttention core for one head pair (qkv [192][64] -> 64 rows of o), position-major.
+// Phase 1: softmax of k over the sample's 4 positions, once per (head, channel, sample), written back in place
+// (wave = (head, 8 channels), lane = (sample, channel pair)).  Phase 2: wave = (head of the pair, position), lane =
+// (sample, part): 8 of the head's 32 channels at column 16 * position + sample; the sample's four key / value columns
+// are the same lane's columns in the four position tiles; every reduction over the parts is a permlane swap inside
+// the wave.  (Without phase 1 each of the 4 position waves recomputed the key softmax: 32 exponentials per lane.)
 __device__ __forceinline__ void attention_pair_pm(const Ctx &c, float *qkv, float *o_rows) {
   constexpr int NC = 64;
   if (GLDM_SKIP(c, 4)) return;
-  const lds_f *q3 = (const lds_f *)qkv;
+  lds_f *q3 = (lds_f *)qkv;
   lds_f *o3 = (lds_f *)o_rows;
-  const int h2 = c.wave >> 2, pq = c.wave & 3, sm = c.lane & 15, pt = c.lane >> 4, d0 = 8 * pt;
+  const int sm = c.lane & 15, pt = c.lane >> 4;
+  {
+    const int row0 = 64 + (c.wave >> 2) * kDimHead + 8 * (c.wave & 3) + 2 * pt;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float k[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k[j] = q3[swz<NC>(row0 + u, 16 * j + sm)];
+      const float km = fmaxf(fmaxf(k[0], k[1]), fmaxf(k[2], k[3]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k[j] = fast_exp(k[j] - km);
+      const float inv = __builtin_amdgcn_rcpf(k[0] + k[1] + k[2] + k[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q3[swz<NC>(row0 + u, 16 * j + sm)] = k[j] * inv;
+    }
+  }
+  const int h2 = c.wave >> 2, pq = c.wave & 3, d0 = 8 * pt;
   const int nn = 16 * pq + sm;
   const int qr = h2 * kDimHead + d0, kr = 64 + h2 * kDimHead + d0, vr = 128 + h2 * kDimHead + d0;
   float q[8];
@@ -1031,26 +1050,26 @@ __device__ __forceinline__ void attention_pair_pm(const Ctx &c, float *qkv, floa
     q[i] = q3[swz<NC>(qr + i, nn)];
     qmax = fmaxf(qmax, q[i]);
   }
-  float kv[8][4], vv[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) kv[i][j] = q3[swz<NC>(kr + i, 16 * j + sm)];
+  float vv[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) vv[i][j] = q3[swz<NC>(vr + i, 16 * j + sm)];
   qmax = half_max(row_pair_max(qmax));
-  float qsum = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float qe[8], qsum = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const float e = fast_exp(q[i] - qmax);
-    qsum += e;
-    const float km = fmaxf(fmaxf(kv[i][0], kv[i][1]), fmaxf(kv[i][2], kv[i][3]));
-    const float k0 = fast_exp(kv[i][0] - km), k1 = fast_exp(kv[i][1] - km), k2 = fast_exp(kv[i][2] - km),
-                k3 = fast_exp(kv[i][3] - km);
-    const float f = e * __builtin_amdgcn_rcpf(k0 + k1 + k2 + k3);
-    a0 += k0 * f; a1 += k1 * f; a2 += k2 * f; a3 += k3 * f;
+    qe[i] = fast_exp(q[i] - qmax);
+    qsum += qe[i];
+  }
+  __syncthreads();  // phase 1's normalised keys are in place
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a0 += q3[swz<NC>(kr + i, sm)] * qe[i];
+    a1 += q3[swz<NC>(kr + i, 16 + sm)] * qe[i];
+    a2 += q3[swz<NC>(kr + i, 32 + sm)] * qe[i];
+    a3 += q3[swz<NC>(kr + i, 48 + sm)] * qe[i];
   }
   qsum = half_sum(row_pair_sum(qsum));
   a0 = half_sum(row_pair_sum(a0)); a1 = half_sum(row_pair_sum(a1));
