@@ -1213,10 +1213,84 @@ __device__ __forceinline__ void layer_norm_rows(const Ctx &c, const float *src, 
   __syncthreads();
 }
 
+// One-exchange form for the 64-column engine (lane = column, wave = row slot): every wave reduces its rows to
+// (sum, M2 about its own mean), ONE barrier, then the parallel-variance merge of the 8 pairs: two barriers per
+// LayerNorm instead of three.
+template <int ITERS>
+__device__ __forceinline__ void layer_norm_rows_1x(const Ctx &c, const float *src, float *dst, float *res, int C,
+                                                   int g_off) {
+  constexpr int NC = 64;
+  using GG = Geo<NC>;
+  lds_f *red1 = (lds_f *)(c.lds + GG::kMiscRed1), *red2 = (lds_f *)(c.lds + GG::kMiscRed2);
+  const int n = c.lane, slot = c.wave;
+  const lds_f *s3 = (const lds_f *)src;
+  const float *g = c.w + g_off;
+  float v[ITERS], gv[ITERS];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int row = slot + GG::kSlots * i;
+    const float x = s3[swz<NC>(row < C ? row : 0, n)];
+    gv[i] = g[row < C ? row : 0];
+    v[i] = row < C ? x : 0.f;
+    sum += v[i];
+  }
+  const int cnt = slot < C ? (C - slot + GG::kSlots - 1) / GG::kSlots : 0;  // rows of this slot (wave uniform)
+  const float mloc = sum * __builtin_amdgcn_rcpf((float)(cnt > 0 ? cnt : 1));  // C, cnt: powers of two -> exact
+  float m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int row = slot + GG::kSlots * i;
+    const float d = row < C ? v[i] - mloc : 0.f;
+    m2 += d * d;
+  }
+  red1[slot * NC + n] = sum;
+  red2[slot * NC + n] = m2;
+  __syncthreads();
+  float tot = 0.f, ps[GG::kWaves], pm[GG::kWaves];
+#pragma unroll
+  for (int q = 0; q < GG::kWaves; ++q) {
+    ps[q] = red1[q * NC + n];
+    pm[q] = red2[q * NC + n];
+    tot += ps[q];
+  }
+  const float inv_c = __builtin_amdgcn_rcpf((float)C);
+  const float mean = tot * inv_c;
+  float vt = 0.f;
+#pragma unroll
+  for (int q = 0; q < GG::kWaves; ++q) {
+    const int cq = q < C ? (C - q + GG::kSlots - 1) / GG::kSlots : 0;  // wave uniform
+    const float fq = (float)cq, iq = __builtin_amdgcn_rcpf((float)(cq > 0 ? cq : 1));
+    const float dm = ps[q] * iq - mean;
+    vt += cq > 0 ? pm[q] + fq * dm * dm : 0.f;
+  }
+  const float rstd = __builtin_amdgcn_rsqf(vt * inv_c + 1e-5f);
+  lds_f *d3 = (lds_f *)dst, *r3 = (lds_f *)res;
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int row = slot + GG::kSlots * i;
+    if (row < C) {
+      const float y = (v[i] - mean) * rstd * gv[i];
+      const int a = swz<NC>(row, n);
+      if (res) r3[a] = r3[a] + y;
+      else d3[a] = y;
+    }
+  }
+  __syncthreads();
+}
+
 template <int NC>
 __device__ __forceinline__ void layer_norm_pass(const Ctx &c, const float *src, float *dst, float *res, int C, int g_off) {
   if (GLDM_SKIP(c, 2)) return;
   C = __builtin_amdgcn_readfirstlane(C);
+  if constexpr (NC == 64) {
+    const int it1 = (C + Geo<NC>::kSlots - 1) / Geo<NC>::kSlots;
+    if (it1 <= 1) layer_norm_rows_1x<1>(c, src, dst, res, C, g_off);
+    else if (it1 <= 4) layer_norm_rows_1x<4>(c, src, dst, res, C, g_off);
+    else if (it1 <= 8) layer_norm_rows_1x<8>(c, src, dst, res, C, g_off);
+    else layer_norm_rows_1x<16>(c, src, dst, res, C, g_off);
+    return;
+  }
   const int it = (C + Geo<NC>::kSlots - 1) / Geo<NC>::kSlots;
   if (it <= 1) layer_norm_rows<NC, 1>(c, src, dst, res, C, g_off);
   else if (it <= 2) layer_norm_rows<NC, 2>(c, src, dst, res, C, g_off);
