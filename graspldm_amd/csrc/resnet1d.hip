@@ -1013,6 +1013,50 @@ __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInt
   for (int co = 0; co < 4; ++co) X[swz<NC>(co, n)] = x[co] + z[co];
 }
 
+// PreNorm LayerNorm + to_qkv 1x1 conv of the 4-channel level (resnets.py:104-124,211-222) as one VALU phase: a column's
+// 4 channels are normalised in its lane (no exchange), then wave w produces rows 24 w .. 24 w + 23 of the 192-row
+// q|k|v block of one head pair: 96 FMAs per lane against wave-uniform (scalar-path) weights, fma chain in the MFMA's
+// k order.  Replaces a 3-barrier LayerNorm pass and a padded K = 16 MFMA GEMM (8 k cycles) by ~1 k cycles.
+__device__ __forceinline__ void qkv4_pm(const Ctx &c, int w_off, int g_off, const float *src, float *dst) {
+  constexpr int NC = 64;
+  const int n = c.lane;
+  const lds_f *s3 = (const lds_f *)src;
+  lds_f *d3 = (lds_f *)dst;
+  float x[4];
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci) x[ci] = s3[swz<NC>(ci, n)];
+  const float mean = (x[0] + x[1] + x[2] + x[3]) * 0.25f;
+  float vt = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci) {
+    const float d = x[ci] - mean;
+    vt += d * d;
+  }
+  const float rstd = __builtin_amdgcn_rsqf(vt * 0.25f + 1e-5f);
+  const float *g = c.w + g_off;
+  float y[4];
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci) y[ci] = (x[ci] - mean) * rstd * g[ci];
+  // A fragments of [192 x 16 (4 real)]: lane (r % 16) + 16 k of m-tile r / 16 holds W[r][k] in its first element.  The
+  // wave's 24 rows span two m-tiles: two fragment loads, then every weight is broadcast from its lane (v_readlane:
+  // no memory round trip per weight).
+  const WStream wv(c.w + w_off, c.lane);
+  const int r0 = __builtin_amdgcn_readfirstlane(c.wave * 24), t0 = r0 >> 4;
+  const f32x4 f0 = wv[(size_t)t0 * 64], f1 = wv[(size_t)(t0 + 1) * 64];
+#pragma unroll
+  for (int q = 0; q < 24; ++q) {
+    const int r = r0 + q;
+    const bool second = (r >> 4) != t0;  // wave uniform
+    const int fv = __float_as_int(second ? f1[0] : f0[0]);
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(fv, (r & 15) + 16 * k)), y[k], acc);
+    d3[swz<NC>(r, n)] = acc;
+  }
+  __syncthreads();
+}
+
 // LinearAttention core for one head pair (qkv [192][64] -> 64 rows of o), position-major.
 // Phase 1: softmax of k over the sample's 4 positions, once per (head, channel, sample), written back in place
 // (wave = (head, 8 channels), lane = (sample, channel pair)).  Phase 2: wave = (head of the pair, position), lane =
@@ -1508,7 +1552,7 @@ struct RunArgs {
 // down conv).  It is written once per workgroup into LDS (12 ints per op) and interpreted by a switch
 // inside the step loop, so every phase body exists once, inlined, with registers allocated across the
 // whole kernel: no calls, no callee-save traffic and no spilled kernel state between phases.
-enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4 };
+enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKV4 = 5 };
 // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9
 constexpr int kFlagAlias = 1 << 8;
 
@@ -1655,10 +1699,16 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
       resblock(d.rb[2 * lv], C, false);
       resblock(d.rb[2 * lv + 1], C, true);
       const gldm_r1d_level &v = d.lv[lv];
-      emit(OP_LN, X, Y, -1, C, v.ln_g);
-      emit(OP_CONV, v.qkv_w[0], -1, Y, QKV, C, 192, 1);
-      emit(OP_ATT, QKV, O);
-      emit(OP_CONV, v.qkv_w[1], -1, Y, QKV, C, 192, 1);
+      if (NC == 64 && C == 4) {  // LayerNorm + qkv of the 4-channel level: one VALU phase per head pair
+        emit(OP_QKV4, v.qkv_w[0], v.ln_g, X, QKV);
+        emit(OP_ATT, QKV, O);
+        emit(OP_QKV4, v.qkv_w[1], v.ln_g, X, QKV);
+      } else {
+        emit(OP_LN, X, Y, -1, C, v.ln_g);
+        emit(OP_CONV, v.qkv_w[0], -1, Y, QKV, C, 192, 1);
+        emit(OP_ATT, QKV, O);
+        emit(OP_CONV, v.qkv_w[1], -1, Y, QKV, C, 192, 1);
+      }
       emit(OP_ATT, QKV, O + 64 * NC);
       emit(OP_CONV, v.out_w, v.out_b, O, Y, kHidden, C, 1);
       emit(OP_LN, Y, -1, X, C, v.ln2_g);
@@ -1705,6 +1755,9 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
           else resblock4_valu<NC>(c, o, E);
         }
         if (o[11]) __syncthreads();
+        break;
+      case OP_QKV4:
+        if constexpr (NC == 64) qkv4_pm(c, o[1], o[2], c.lds + o[3], c.lds + o[4]);
         break;
       case OP_LN:
         layer_norm_pass<NC>(c, c.lds + o[1], o[2] >= 0 ? c.lds + o[2] : nullptr, o[3] >= 0 ? c.lds + o[3] : nullptr,
@@ -2190,7 +2243,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
                     : (L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s));
   if (stamp) {
     static long long host[kMaxOps + 2];
-    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT"};
+    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "QKV4"};
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(host, dstamps, sizeof(host), hipMemcpyDeviceToHost);
     // the tape is rebuilt on the host only to label the stamps
@@ -2208,7 +2261,8 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
     for (int lv = 0; lv < a.d.n_levels; ++lv) {
       const int C = dims[lv];
       resblock(C); resblock(C);
-      line(3, C, C, 0); line(1, C, 192, 1); line(4, C, 64, 0); line(1, C, 192, 1); line(4, C, 64, 0);
+      if (pm && C == 4) { line(5, C, 192, 1); line(4, C, 64, 0); line(5, C, 192, 1); line(4, C, 64, 0); }
+      else { line(3, C, C, 0); line(1, C, 192, 1); line(4, C, 64, 0); line(1, C, 192, 1); line(4, C, 64, 0); }
       line(1, 128, C, 1); line(3, C, C, 0); line(1, C, dims[lv + 1], 3);
     }
     resblock(dims[a.d.n_levels]);
