@@ -388,6 +388,13 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
   GLDM_CONV_CASE(4, 4);   // 64 ch @ 16^3
   GLDM_CONV_CASE(8, 2);   // 128 ch @ 8^3
   GLDM_CONV_CASE(4, 8);   // 64 ch @ 32^3
+  // half-width / half-resolution variants (the reference's encoder benchmark runs PVCNN / PVCNN2 at 0.5 / 0.5)
+  GLDM_CONV_CASE(2, 4);   // 32 ch @ 16^3
+  GLDM_CONV_CASE(4, 2);   // 64 ch @ 8^3
+  GLDM_CONV_CASE(1, 4);   // 16 ch @ 16^3
+  GLDM_CONV_CASE(2, 2);   // 32 ch @ 8^3
+  GLDM_CONV_CASE(4, 1);   // 64 ch @ 4^3
+  GLDM_CONV_CASE(8, 1);   // 128 ch @ 4^3
 #undef GLDM_CONV_CASE
   return GLDM_ERR_UNSUPPORTED;
 }

@@ -205,7 +205,8 @@ def test_bias_act_rejects_unaligned_rows():
 
 
 @pytest.mark.parametrize("cin,cout,r", [(3, 48, 24), (48, 48, 24), (48, 96, 12), (96, 96, 12), (3, 32, 32), (64, 64, 16),
-                                        (20, 48, 24)])
+                                        (20, 48, 24), (3, 32, 16), (32, 64, 8), (16, 16, 16), (32, 32, 8), (64, 64, 4),
+                                        (128, 128, 4)])
 def test_conv3d_groupnorm_swish_kernels(cin, cout, r):
     """gldm_conv3d_k3 + gldm_groupnorm_swish vs torch conv3d / group_norm on the CPU (fp32, 2e-5:
     K = 27 cin products per output in a different summation order)."""
