@@ -1458,43 +1458,88 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
       o3[swz<NC>(hl * kDimHead + e0 + i, n)] = vv[i].x * a0 + vv[i].y * a1 + vv[i].z * a2 + vv[i].w * a3;
     __syncthreads();
   } else {
-    // L = 16 (pose decoder, once per grasp): every lane recomputes A for its head and column
-    float qmax = -3.0e38f;
-    for (int d = 0; d < kDimHead; ++d) qmax = fmaxf(qmax, q3[swz<NC>(qrow0 + d, n)]);
-    float qsum = 0.f;
-    for (int d = 0; d < kDimHead; ++d) qsum += fast_exp(q3[swz<NC>(qrow0 + d, n)] - qmax);
-    const float qscale = 0.17677669529663687f / qsum;
-    float A[L];
+    // L = 16 (pose decoder): 2 samples x 16 positions per tile, 4 waves.  Both softmaxes are normalised in place
+    // first (keys over a sample's 16 positions: two lanes per (head, channel, sample); queries over the 32 channels,
+    // scaled by dim_head^-0.5: four lanes per (head, column)), then a wave per (head, sample) takes
+    // A = Kn^T Qn (16 x 16, K = 32) and out = V A (32 x 16, K = 16) as 16 MFMAs: A's accumulator registers are the
+    // B operand of the second product as they stand (k-step r = key positions {4 kq + r}).  (The first form had every
+    // lane recompute A with 512 exponentials: 30-80 k cycles per op, a third of the whole decode.)
+    static_assert(NC == 32, "decoder tile");
+    const int t = c.tid;
+    lds_f *w3 = (lds_f *)qkv;
+    {
+      const int item = t >> 1, half = t & 1, h = item >> 6, d = (item >> 1) & 31, sm = item & 1;
+      const int row = 64 + h * kDimHead + d, col0 = sm * 16 + 8 * half;
+      float k[8];
+      float km = -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < L; ++i) A[i] = 0.f;
-    for (int d = 0; d < kDimHead; ++d) {
-      const float qd = fast_exp(q3[swz<NC>(qrow0 + d, n)] - qmax) * qscale;
-      float kv[L];
-      float kmax = -3.0e38f;
-#pragma unroll
-      for (int i = 0; i < L; ++i) {
-        kv[i] = q3[swz<NC>(krow0 + d, sbase + i)];
-        kmax = fmaxf(kmax, kv[i]);
+      for (int j = 0; j < 8; ++j) {
+        k[j] = w3[swz<NC>(row, col0 + j)];
+        km = fmaxf(km, k[j]);
       }
-      float ksum = 0.f;
+      km = fmaxf(km, dpp_mov<0xB1>(km));  // the other half of the sample's positions: lane ^ 1
+      float ks = 0.f;
 #pragma unroll
-      for (int i = 0; i < L; ++i) {
-        kv[i] = fast_exp(kv[i] - kmax);
-        ksum += kv[i];
+      for (int j = 0; j < 8; ++j) {
+        k[j] = fast_exp(k[j] - km);
+        ks += k[j];
       }
-      const float f = qd / ksum;
+      ks += dpp_mov<0xB1>(ks);
+      const float inv = __builtin_amdgcn_rcpf(ks);
 #pragma unroll
-      for (int i = 0; i < L; ++i) A[i] += kv[i] * f;
+      for (int j = 0; j < 8; ++j) w3[swz<NC>(row, col0 + j)] = k[j] * inv;
     }
-    for (int e = e0; e < e0 + CH; ++e) {
-      float acc = 0.f;
+    {
+      const int item = t >> 2, qt = t & 3, h = item >> 5, col = item & 31;
+      const int row0 = h * kDimHead + 8 * qt;
+      float q[8];
+      float qm = -3.0e38f;
 #pragma unroll
-      for (int i = 0; i < L; ++i) acc += q3[swz<NC>(vrow0 + e, sbase + i)] * A[i];
-      o3[swz<NC>(hl * kDimHead + e, n)] = acc;
+      for (int j = 0; j < 8; ++j) {
+        q[j] = w3[swz<NC>(row0 + j, col)];
+        qm = fmaxf(qm, q[j]);
+      }
+      qm = fmaxf(qm, dpp_mov<0xB1>(qm));
+      qm = fmaxf(qm, dpp_mov<0x4E>(qm));  // the four channel quarters of a column: one quad
+      float qs = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        q[j] = fast_exp(q[j] - qm);
+        qs += q[j];
+      }
+      qs += dpp_mov<0xB1>(qs);
+      qs += dpp_mov<0x4E>(qs);
+      const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(qs);  // dim_head ** -0.5 / sum
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w3[swz<NC>(row0 + j, col)] = q[j] * sc;
+    }
+    __syncthreads();
+    const int h = c.wave >> 1, sm = c.wave & 1, m = c.lane & 15, kq = c.lane >> 4;
+    f32x4 am = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // channel d = 4 j + kq
+      const float ka = q3[swz<NC>(64 + h * kDimHead + 4 * j + kq, sm * 16 + m)];  // Kn^T[key position m][d]
+      const float qb = q3[swz<NC>(h * kDimHead + 4 * j + kq, sm * 16 + m)];       // Qn[d][query position m]
+      am = __builtin_amdgcn_mfma_f32_16x16x4f32(ka, qb, am, 0, 0, 0);
+    }
+    // am: lane (query position m, kq), register r = A[key position 4 kq + r][m]
+    f32x4 o0 = f32x4{0.f, 0.f, 0.f, 0.f}, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // k-step r: key positions 4 kq + r
+      const float v0 = q3[swz<NC>(128 + h * kDimHead + m, sm * 16 + 4 * kq + r)];
+      const float v1 = q3[swz<NC>(128 + h * kDimHead + 16 + m, sm * 16 + 4 * kq + r)];
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, am[r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, am[r], o1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o3[swz<NC>(h * kDimHead + 4 * kq + r, sm * 16 + m)] = o0[r];
+      o3[swz<NC>(h * kDimHead + 16 + 4 * kq + r, sm * 16 + m)] = o1[r];
     }
     __syncthreads();
   }
 }
+
 
 // ---------------------------------------------------------- the network ----
 // Step-segment hand-off between workgroups (a tile whose steps are split over a chain of slots).
