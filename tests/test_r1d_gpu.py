@@ -219,3 +219,36 @@ def test_decoder_more_tiles_than_slots(engines):
     assert torch.equal(tm[-40:], tm2) and torch.equal(lg[-40:], lg2)
     tm3, lg3 = dec.decode(zh[:64].contiguous(), cemb[:64].contiguous(), 1)
     assert torch.equal(tm[:64], tm3) and torch.equal(lg[:64], lg3)
+
+
+def test_sample_major_fallback_engine_for_other_denoiser_shapes():
+    """A 4-position denoiser whose widths are outside the position-major engine's set (16 / 32 channels here) runs on
+    the sample-major 32-column engine (r1d_kernel<32, 4>), chains included; checked against the oracle."""
+    from oracle import torch_ref as R
+    from graspldm_amd.resnets import TimeConditionedResNet1D
+    from graspldm_amd.r1d import SCHED_DDIM
+    from graspldm_amd.synthetic import load_synthetic_weights
+    net = TimeConditionedResNet1D(dim=4, channels=1, block_channels=(16, 32), input_conditioning_dims=64,
+                                  resnet_block_groups=4, dropout=0.1, is_time_conditioned=True, learned_variance=False,
+                                  learned_sinusoidal_cond=False, random_fourier_features=True)
+    load_synthetic_weights(net, seed=3)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(13, 1, 4, generator=g)
+    z = torch.randn(13, 3, 64, generator=g)
+    t = torch.randint(0, 1000, (13,), generator=g)
+    eps = net(x.cuda(), time=t.cuda(), z_cond=z.cuda())
+    exp = R.resnet1d_forward(sd, "", x, z_cond=z, time=t)
+    assert _err(eps, exp) < 2e-5
+    # more tiles than slots: the step-segment chains of the 32-column engine, bitwise vs a small batch
+    eng = net.engine(torch.device("cuda:0"))
+    n = _slots() * 8 + 19
+    xb = torch.randn(n, 1, 4, generator=g).cuda()
+    zb = torch.randn(n, 3, 64, generator=g).cuda()
+    ts, coef = _ddim_tables(100)
+    ts, coef = ts[-6:].contiguous().cuda(), coef[-6:].contiguous().cuda()
+    cemb = eng.cond_embed(zb)
+    big = eng.denoise(xb, cemb, 1, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
+    small = eng.denoise(xb[-40:].contiguous(), cemb[-40:].contiguous(), 1, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
+    assert torch.equal(big[-40:], small) and eng.workspace_errors() == 0

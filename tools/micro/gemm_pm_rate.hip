@@ -55,6 +55,24 @@ __global__ __launch_bounds__(512, 2) void pm_probe(const float *w, int cin, int 
   if (c.tid == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+__global__ __launch_bounds__(512, 2) void pm_1x1_probe(const float *w, int cin, int cout, int iters, long long *cycles) {
+  using GG = Geo<64>;
+  extern __shared__ float lds[];
+  Ctx c{w, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63, 0, GG::kNT};
+  for (int i = c.tid; i < GG::kLdsFloats; i += GG::kThreads) lds[i] = 0.37f * (float)((i * 2654435761u >> 20) & 1023) / 1024.f - 0.18f;
+  __syncthreads();
+  const long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+    Ctx cc = c;
+    asm volatile("" : "+v"(cc.tid), "+v"(cc.lane));
+    int ci = cin, co = cout;
+    asm volatile("" : "+s"(ci), "+s"(co));
+    conv_gemm<64, 4>(cc, 0, -1, lds + GG::kBufX, ci, 1, lds + GG::kBufH, co, false);
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  if (c.tid == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 __global__ __launch_bounds__(512, 2) void pm_gn_probe(const float *w, int cin, int cout, int mode, int iters, long long *cycles) {
   using GG = Geo<64>;
   extern __shared__ float lds[];
@@ -131,6 +149,18 @@ int main() {
   (void)hipFuncSetAttribute((const void *)pm_gn_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
   (void)hipFuncSetAttribute((const void *)sm_probe<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
   const int shapes[][2] = {{256, 256}, {128, 256}, {128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}};
+  (void)hipFuncSetAttribute((const void *)pm_1x1_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+  {
+    const int s11[][2] = {{128, 192}, {64, 192}, {32, 192}, {128, 128}, {128, 64}, {128, 32}};
+    for (auto &sh : s11) {
+      static int q_cin, q_cout; static const float *q_w; static long long *q_c;
+      q_cin = sh[0]; q_cout = sh[1]; q_w = w; q_c = dcyc;
+      (void)time_launch([] { hipLaunchKernelGGL(pm_1x1_probe, dim3(256), dim3(512), (size_t)Geo<64>::kLdsFloats * 4, 0, q_w, q_cin, q_cout, 200, q_c); }, 1);
+      const double cyc = avg_cycles(dcyc, 256, iters);
+      const double ideal = (sh[1] / 16) * (sh[0] / 4.0) * 4 * 32.0 / 4;
+      printf("1x1 cin=%3d cout=%3d on 64 columns: %6.0f cycles per call (MFMA-bound %5.0f = %4.1f%%)\n", sh[0], sh[1], cyc, ideal, 100 * ideal / cyc);
+    }
+  }
   for (auto &sh : shapes) {
     const int cin = sh[0], cout = sh[1];
     static int s_cin, s_cout; static const float *s_w; static long long *s_c;
