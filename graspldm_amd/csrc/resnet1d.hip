@@ -2140,13 +2140,25 @@ __global__ __launch_bounds__(Geo<64>::kThreads, 2) void sa_mlp_kernel(const SaAr
     const bool live = j0 + jj < a.m;
     const int id = live ? idx[col] : 0;
     const int rows = a.cin_pad[0];
-    for (int r = c.wave; r < rows; r += GG::kWaves) {
-      float v = 0.f;
-      if (live) {
-        if (r < 3) v = pts[r * a.n + id] - ctr[r * a.m + j0 + jj];
-        else if (r < 3 + a.c) v = feat[(size_t)(r - 3) * a.n + id];
+    // six rows per wave in flight at a time: every element is a scattered memory round trip, and issued one by one
+    // (load, wait, store) the gather took as long as the tile's MFMAs.  (Requesting the NEXT tile's rows before the
+    // MLP from a persistent workgroup was slower: the in-order vmcnt makes the first weight fragment wait for them.)
+    for (int r0 = c.wave; r0 < rows; r0 += 6 * GG::kWaves) {
+      float v[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int r = r0 + q * GG::kWaves;
+        v[q] = 0.f;
+        if (live && r < rows) {
+          if (r < 3) v[q] = pts[r * a.n + id] - ctr[r * a.m + j0 + jj];
+          else if (r < 3 + a.c) v[q] = feat[(size_t)(r - 3) * a.n + id];
+        }
       }
-      X[swz<NC>(r, col)] = v;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int r = r0 + q * GG::kWaves;
+        if (r < rows) X[swz<NC>(r, col)] = v[q];
+      }
     }
   }
   __syncthreads();
