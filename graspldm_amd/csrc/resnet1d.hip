@@ -1013,6 +1013,94 @@ __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInt
   for (int co = 0; co < 4; ++co) X[swz<NC>(co, n)] = x[co] + z[co];
 }
 
+// to_out of LinearAttention: Conv1d(128 -> C, k = 1) -> LayerNorm over the channels -> residual add
+// (resnets.py:211-235, Residual(PreNorm(...)) :59-65,116-124), as ONE phase of the 64-column engine: the LayerNorm
+// statistics of a column are merged across the waves that hold its rows -- per-wave (sum, M2 about the wave's own
+// mean) over its 16 rows, one LDS exchange, parallel-variance merge -- and x += LN(y) g is applied to the
+// accumulators.  Replaces a conv phase that stored y plus a LayerNorm phase that read it back (3 barriers).
+template <int NT>
+__device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const float *bias, int mt0, int nt0,
+                                            bool active, int p0, int np, const float *src, int cin, float *xres, int C,
+                                            const float *gain) {
+  using GG = Geo<64>;
+  constexpr int NC = 64;
+  const int kq = c.lane >> 4, col = c.lane & 15;
+  f32x4 acc[1][NT];
+  lds_f *red1 = (lds_f *)(c.lds + GG::kMiscRed1), *red2 = (lds_f *)(c.lds + GG::kMiscRed2);
+  const int row0 = 16 * mt0 + 4 * kq;
+  const int nloc = C < 16 ? C : 16;  // rows behind one published pair
+  f32x4 gv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + row0);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[0][ni] = bv;
+    gemm_fast<NC, 4, 1, 1, NT>(c, wp, cin >> 4, mt0, nt0, src, acc);
+    gv = *reinterpret_cast<const f32x4 *>(gain + row0);
+    const float inv_n = __builtin_amdgcn_rcpf((float)nloc);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s1 += row0 + r < C ? acc[0][ni][r] : 0.f;
+      s1 = half_sum(row_pair_sum(s1));
+      const float ml = s1 * inv_n;
+      float s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = row0 + r < C ? acc[0][ni][r] - ml : 0.f;
+        s2 += d * d;
+      }
+      s2 = half_sum(row_pair_sum(s2));
+      if (kq == 0) {
+        red1[c.wave * NC + 16 * (nt0 + ni) + col] = s1;
+        red2[c.wave * NC + 16 * (nt0 + ni) + col] = s2;
+      }
+    }
+  }
+  __syncthreads();
+  if (active) {
+    const float inv_c = __builtin_amdgcn_rcpf((float)C), inv_n = __builtin_amdgcn_rcpf((float)nloc);
+    lds_f *x3 = (lds_f *)xres;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const int cc = 16 * (nt0 + ni) + col;
+      float ps[8], pm[8], tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {  // np <= 8 partner waves (wave uniform); each pair is read once
+        const int pw = p0 + (q < np ? q : 0);
+        ps[q] = red1[pw * NC + cc];
+        pm[q] = red2[pw * NC + cc];
+        tot += q < np ? ps[q] : 0.f;
+      }
+      const float mean = tot * inv_c;
+      float m2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float dm = ps[q] * inv_n - mean;
+        m2 += q < np ? pm[q] + (float)nloc * dm * dm : 0.f;
+      }
+      const float rstd = __builtin_amdgcn_rsqf(m2 * inv_c + 1e-5f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (row0 + r < C) {
+          const int a = swz<NC>(row0 + r, cc);
+          x3[a] = x3[a] + (acc[0][ni][r] - mean) * rstd * gv[r];
+        }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void out_ln_pm(const Ctx &c, int w_off, int b_off, const float *src, int cin, float *xres,
+                                          int C, int g_off) {
+  const float *wp = c.w + w_off, *bias = c.w + b_off, *gain = c.w + g_off;
+  const int mtiles = (C + 15) >> 4, w = c.wave;
+  if (mtiles == 8) out_ln_wave<4>(c, wp, bias, w, 0, true, 0, 8, src, cin, xres, C, gain);
+  else if (mtiles == 4) out_ln_wave<2>(c, wp, bias, w & 3, 2 * (w >> 2), true, 4 * (w >> 2), 4, src, cin, xres, C, gain);
+  else if (mtiles == 2) out_ln_wave<1>(c, wp, bias, w & 1, w >> 1, true, 2 * (w >> 1), 2, src, cin, xres, C, gain);
+  else out_ln_wave<1>(c, wp, bias, 0, w & 3, w < 4, w & 3, 1, src, cin, xres, C, gain);
+}
+
 // PreNorm LayerNorm + to_qkv 1x1 conv of the 4-channel level (resnets.py:104-124,211-222) as one VALU phase: a column's
 // 4 channels are normalised in its lane (no exchange), then wave w produces rows 24 w .. 24 w + 23 of the 192-row
 // q|k|v block of one head pair: 96 FMAs per lane against wave-uniform (scalar-path) weights, fma chain in the MFMA's
@@ -1597,7 +1685,7 @@ struct RunArgs {
 // down conv).  It is written once per workgroup into LDS (12 ints per op) and interpreted by a switch
 // inside the step loop, so every phase body exists once, inlined, with registers allocated across the
 // whole kernel: no calls, no callee-save traffic and no spilled kernel state between phases.
-enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKV4 = 5 };
+enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKV4 = 5, OP_OUTLN = 6 };
 // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9
 constexpr int kFlagAlias = 1 << 8;
 
@@ -1755,8 +1843,12 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
         emit(OP_CONV, v.qkv_w[1], -1, Y, QKV, C, 192, 1);
       }
       emit(OP_ATT, QKV, O + 64 * NC);
-      emit(OP_CONV, v.out_w, v.out_b, O, Y, kHidden, C, 1);
-      emit(OP_LN, Y, -1, X, C, v.ln2_g);
+      if (NC == 64 && (C == 4 || C == 32 || C == 64 || C == 128)) {  // to_out conv + LayerNorm + residual: one phase
+        emit(OP_OUTLN, v.out_w, v.out_b, O, X, kHidden, C, v.ln2_g);
+      } else {
+        emit(OP_CONV, v.out_w, v.out_b, O, Y, kHidden, C, 1);
+        emit(OP_LN, Y, -1, X, C, v.ln2_g);
+      }
       emit(OP_CONV, v.down_w, v.down_b, X, X, C, Cn, 3 | kFlagAlias);
     }
   }
@@ -1803,6 +1895,9 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
         break;
       case OP_QKV4:
         if constexpr (NC == 64) qkv4_pm(c, o[1], o[2], c.lds + o[3], c.lds + o[4]);
+        break;
+      case OP_OUTLN:
+        if constexpr (NC == 64) out_ln_pm(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4], o[6], o[7]);
         break;
       case OP_LN:
         layer_norm_pass<NC>(c, c.lds + o[1], o[2] >= 0 ? c.lds + o[2] : nullptr, o[3] >= 0 ? c.lds + o[3] : nullptr,
@@ -2300,7 +2395,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
                     : (L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s));
   if (stamp) {
     static long long host[kMaxOps + 2];
-    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "QKV4"};
+    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "QKV4", "OUTLN"};
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(host, dstamps, sizeof(host), hipMemcpyDeviceToHost);
     // the tape is rebuilt on the host only to label the stamps
@@ -2320,7 +2415,9 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
       resblock(C); resblock(C);
       if (pm && C == 4) { line(5, C, 192, 1); line(4, C, 64, 0); line(5, C, 192, 1); line(4, C, 64, 0); }
       else { line(3, C, C, 0); line(1, C, 192, 1); line(4, C, 64, 0); line(1, C, 192, 1); line(4, C, 64, 0); }
-      line(1, 128, C, 1); line(3, C, C, 0); line(1, C, dims[lv + 1], 3);
+      if (pm && (C == 4 || C == 32 || C == 64 || C == 128)) line(6, 128, C, 1);
+      else { line(1, 128, C, 1); line(3, C, C, 0); }
+      line(1, C, dims[lv + 1], 3);
     }
     resblock(dims[a.d.n_levels]);
     printf("step total (ops): %lld clk; step prologue (embedding sums, init conv): %lld clk\n", host[op] - host[0],
