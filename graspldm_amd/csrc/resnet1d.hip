@@ -1433,16 +1433,12 @@ __device__ __forceinline__ void layer_norm_pass(const Ctx &c, const float *src, 
 
 // -------------------------------------------------- linear attention -------
 // qkv: [192][NC] = q(2 heads x 32) | k | v for one head pair; writes 64 rows of o.
-// The 32 channels of a head are split in 4 parts of 8 over (waves of the head) x (row slots).
+// (Sample-major 32-column engine; the 64-column engine has attention_pair_pm.)
 template <int NC, int L>
 __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *o_rows) {
   if (GLDM_SKIP(c, 4)) return;
   using GG = Geo<NC>;
-  constexpr int WPH = GG::kWaves / 2;       // waves per head
-  const int n = c.lane & (NC - 1), sub = c.lane / NC, sbase = n & ~(L - 1);
-  constexpr int CH = kDimHead / (WPH * GG::kRP);  // channels of a head per lane: 8 (4 at 8 waves)
-  const int hl = c.wave / WPH, part = (c.wave % WPH) * GG::kRP + sub, e0 = CH * part;
-  const int qrow0 = hl * kDimHead, krow0 = 64 + hl * kDimHead, vrow0 = 128 + hl * kDimHead;
+  static_assert(NC == 32 && GG::kWaves == 4 && (L == 4 || L == 16), "sample-major engine geometry");
   const lds_f *q3 = (const lds_f *)qkv;
   lds_f *o3 = (lds_f *)o_rows;
   if constexpr (L == 4 && NC == 32 && GG::kWaves == 4) {
@@ -1483,67 +1479,6 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       o3[swz<NC>(h2 * kDimHead + d0 + i, nn)] = vv[i].x * a0 + vv[i].y * a1 + vv[i].z * a2 + vv[i].w * a3;
-    __syncthreads();
-  } else if constexpr (L == 4) {
-    // softmax statistics and the 4x4 matrix A = softmax_n(k)^T softmax_d(q) are combined over
-    // the parts by a lane swap (row slots) and one exchange through LDS (waves)
-    float *red1 = c.lds + GG::kMiscRed1, *red2 = c.lds + GG::kMiscRed2;
-    lds_f *part_a = (lds_f *)qkv;  // q rows are dead after phase 1: [kWaves][4][NC] partial A
-    float q[CH];
-    float qmax = -3.0e38f;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      q[i] = q3[swz<NC>(qrow0 + e0 + i, n)];
-      qmax = fmaxf(qmax, q[i]);
-    }
-    f32x4 kv[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) kv[i] = *(const lds_f4 *)(q3 + swz<NC>(krow0 + e0 + i, sbase));
-    if (GG::kRP == 2) qmax = half_max(qmax);
-    red1[c.wave * NC + n] = qmax;
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < WPH; ++w) qmax = fmaxf(qmax, red1[(hl * WPH + w) * NC + n]);
-    float qsum = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const float e = fast_exp(q[i] - qmax);
-      qsum += e;
-      const float km = fmaxf(fmaxf(kv[i].x, kv[i].y), fmaxf(kv[i].z, kv[i].w));
-      const float k0 = fast_exp(kv[i].x - km), k1 = fast_exp(kv[i].y - km), k2 = fast_exp(kv[i].z - km),
-                  k3 = fast_exp(kv[i].w - km);
-      const float f = e * __builtin_amdgcn_rcpf(k0 + k1 + k2 + k3);
-      a0 += k0 * f; a1 += k1 * f; a2 += k2 * f; a3 += k3 * f;
-    }
-    if (GG::kRP == 2) {
-      qsum = half_sum(qsum);
-      a0 = half_sum(a0); a1 = half_sum(a1);
-      a2 = half_sum(a2); a3 = half_sum(a3);
-    }
-    red2[c.wave * NC + n] = qsum;
-    part_a[(c.wave * 4 + 0) * NC + n] = a0;
-    part_a[(c.wave * 4 + 1) * NC + n] = a1;
-    part_a[(c.wave * 4 + 2) * NC + n] = a2;
-    part_a[(c.wave * 4 + 3) * NC + n] = a3;
-    f32x4 vv[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) vv[i] = *(const lds_f4 *)(q3 + swz<NC>(vrow0 + e0 + i, sbase));
-    __syncthreads();
-    qsum = 0.f; a0 = a1 = a2 = a3 = 0.f;
-#pragma unroll
-    for (int w = 0; w < WPH; ++w) {
-      const int ww = hl * WPH + w;
-      qsum += red2[ww * NC + n];
-      a0 += part_a[(ww * 4 + 0) * NC + n];
-      a1 += part_a[(ww * 4 + 1) * NC + n];
-      a2 += part_a[(ww * 4 + 2) * NC + n];
-      a3 += part_a[(ww * 4 + 3) * NC + n];
-    }
-    const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(qsum);  // dim_head ** -0.5 / sum
-    a0 *= sc; a1 *= sc; a2 *= sc; a3 *= sc;
-#pragma unroll
-    for (int i = 0; i < CH; ++i)
-      o3[swz<NC>(hl * kDimHead + e0 + i, n)] = vv[i].x * a0 + vv[i].y * a1 + vv[i].z * a2 + vv[i].w * a3;
     __syncthreads();
   } else {
     // L = 16 (pose decoder): 2 samples x 16 positions per tile, 4 waves.  Both softmaxes are normalised in place
