@@ -914,27 +914,36 @@ __device__ __forceinline__ void conv_pm3_cin4(const Ctx &c, const float *wp, con
     x[1][ci] = m;
     x[2][ci] = p < 3 ? r : 0.f;
   }
-  float out[4];
-  const int per_wave = 4;
+  // 32 output channels per round (4 per wave); wider first levels take more rounds.  All rounds are computed before
+  // the (possibly aliased) destination is written.
+  constexpr int kMaxRounds = kMaxC / 32;
+  float out[kMaxRounds][4];
 #pragma unroll
-  for (int k = 0; k < per_wave; ++k) {
-    const int co = __builtin_amdgcn_readfirstlane(c.wave * per_wave + k);
-    const int cc = co < cout ? co : cout - 1;
-    float acc = bias ? bias[cc] : 0.f;
-    const float *wr = wp + (size_t)(cc >> 4) * 256 + (cc & 15) * 4;  // [(ci * 16 + co % 16) * 4 + tap]
+  for (int rd = 0; rd < kMaxRounds; ++rd) {
+    if (rd * 32 < cout) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+      for (int k = 0; k < 4; ++k) {
+        const int co = __builtin_amdgcn_readfirstlane(rd * 32 + c.wave * 4 + k);
+        const int cc = co < cout ? co : cout - 1;
+        float acc = bias ? bias[cc] : 0.f;
+        const float *wr = wp + (size_t)(cc >> 4) * 256 + (cc & 15) * 4;  // [(ci * 16 + co % 16) * 4 + tap]
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci) acc = fmaf(wr[ci * 64 + t], x[t][ci], acc);
-    out[k] = acc;
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int ci = 0; ci < 4; ++ci) acc = fmaf(wr[ci * 64 + t], x[t][ci], acc);
+        out[rd][k] = acc;
+      }
+    }
   }
   if (alias) __syncthreads();
   lds_f *d3 = (lds_f *)dst;
 #pragma unroll
-  for (int k = 0; k < per_wave; ++k) {
-    const int co = c.wave * per_wave + k;
-    if (co < cout) d3[swz<NC>(co, n)] = out[k];
-  }
+  for (int rd = 0; rd < kMaxRounds; ++rd)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int co = rd * 32 + c.wave * 4 + k;
+      if (co < cout) d3[swz<NC>(co, n)] = out[rd][k];
+    }
 }
 
 // ResnetBlock of the 4-channel level on the VALU of one wave: lane = column (16 samples x 4 positions), every

@@ -252,3 +252,39 @@ def test_sample_major_fallback_engine_for_other_denoiser_shapes():
     big = eng.denoise(xb, cemb, 1, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
     small = eng.denoise(xb[-40:].contiguous(), cemb[-40:].contiguous(), 1, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
     assert torch.equal(big[-40:], small) and eng.workspace_errors() == 0
+
+
+@pytest.mark.parametrize("block_channels", [(64, 128), (32, 256), (128,), (32, 64, 64)])
+def test_position_major_engine_other_widths(block_channels):
+    """The 64-column engine on other width sequences of its supported set (first level 4 channels, then 32..256):
+    wider first down-conv (4 -> 64 / 128), a 32 -> 256 down-conv, a repeated width; against the oracle, one forward
+    (2e-5) and a 12-step DDIM run (1e-4)."""
+    from oracle import torch_ref as R
+    from graspldm_amd.resnets import TimeConditionedResNet1D
+    from graspldm_amd.r1d import SCHED_DDIM
+    from graspldm_amd.synthetic import load_synthetic_weights
+    net = TimeConditionedResNet1D(dim=4, channels=1, block_channels=block_channels, input_conditioning_dims=64,
+                                  resnet_block_groups=4, dropout=0.1, is_time_conditioned=True, learned_variance=False,
+                                  learned_sinusoidal_cond=False, random_fourier_features=True)
+    load_synthetic_weights(net, seed=len(block_channels) + block_channels[0])
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    n = 21   # one full 16-sample tile + a 5-sample one
+    x = torch.randn(n, 1, 4, generator=g)
+    z = torch.randn(n, 3, 64, generator=g)
+    t = torch.randint(0, 1000, (n,), generator=g)
+    eps = net(x.cuda(), time=t.cuda(), z_cond=z.cuda())
+    exp = R.resnet1d_forward(sd, "", x, z_cond=z, time=t)
+    assert _err(eps, exp) < 2e-5, _err(eps, exp)
+    eng = net.engine(torch.device("cuda:0"))
+    ts, coef = _ddim_tables(100)
+    ts, coef = ts[-12:].contiguous(), coef[-12:].contiguous()
+    out = eng.denoise(x.cuda(), eng.cond_embed(z.cuda()), 1, timesteps=ts.cuda(), sched_kind=SCHED_DDIM, coef=coef.cuda())
+    sched = R.make_scheduler("ddim")
+    sched.set_timesteps(100)
+    xs = x.clone()
+    for tt in ts.tolist():
+        e = R.resnet1d_forward(sd, "", xs, z_cond=z, time=torch.full((n,), tt, dtype=torch.long))
+        xs = sched.step(e, tt, xs).prev_sample
+    assert _err(out, xs) < 1e-4, _err(out, xs)
