@@ -5,8 +5,10 @@ continuous time c_noise(sigma) = log(sigma) / 4 (one time-embedding row per step
 module builds it), the second-order blend with the previous denoised sample and the exponential-integrator update
 are per-step f32 coefficients computed here with 0-dim f32 tensors exactly as the reference computes them.
 
-`sample_normal` (the stochastic Heun sampler, :177-257: two network evaluations and fresh noise per step) is not
-built: the reference's own inference entry point only ever asks for DPM++ (tools/inference.py:607-609).
+`sample_normal` (the stochastic Heun sampler, :177-257: two network evaluations and fresh noise per step) drives
+the same engine one network evaluation per launch (gldm_denoise with GLDM_SCHED_NONE and a one-row time-embedding
+table); the few elementwise updates between the evaluations are torch ops on the [B,1,D] latent.  The reference's
+inference entry point only ever asks for DPM++ (tools/inference.py:607-609), so this path is kept simple, not fused.
 """
 import math
 import warnings
@@ -103,8 +105,58 @@ class ElucidatedDiffusion(nn.Module):
             return self.sample_using_dpmpp(**kwargs)
         return self.sample_normal(**kwargs)
 
-    def sample_normal(self, *a, **k):
-        raise NotImplementedError("the stochastic Heun sampler is not built; use use_dpmpp=True (DPM-Solver++(2M))")
+    def _net_eval(self, eng, cemb, samples_per_cond, x_in, sigma, device):
+        """preconditioned_network_forward (:117-139) through the engine: F(c_in x; c_noise(sigma))."""
+        sg = torch.full((1,), float(sigma))
+        temb = self._time_table(self.c_noise(sg)).to(device)
+        zero = torch.zeros(1, dtype=torch.int32, device=device)
+        c_in, c_skip, c_out = (f(sg)[0].to(device) for f in (self.c_in, self.c_skip, self.c_out))
+        net = eng.denoise(c_in * x_in, cemb, samples_per_cond, timesteps=zero, temb=temb)
+        return c_skip * x_in + c_out * net
+
+    @torch.no_grad()
+    def sample_normal(self, batch_size=16, z_cond=None, num_sample_steps=None, clamp=False, return_all=False, noise=None,
+                      step_noise=None, samples_per_cond=1, device=None):
+        """elucidated_diffusion.py:177-257: stochastic sampler with the second-order (Heun) correction.  `noise`
+        [B,1,D] and `step_noise` [S,B,1,D] (unit normal) default to draws on the model's device, in the reference's
+        order (x first, then one draw per step)."""
+        from math import sqrt
+        device = torch.device(self.device if device is None else device)
+        if device.type != "cuda":
+            raise RuntimeError("sampling runs on the GPU only (graspldm_amd has no CPU path)")
+        n_steps = self.num_sample_steps if num_sample_steps is None else num_sample_steps
+        shape = (batch_size, self.channels, self.seq_length)
+        sigmas = self.sample_schedule(n_steps)
+        gammas = torch.where((sigmas >= self.S_tmin) & (sigmas <= self.S_tmax),
+                             min(self.S_churn / n_steps, sqrt(2) - 1), 0.0)
+        if noise is None:
+            noise = torch.randn(shape, device=device)
+        x = sigmas[0].to(device) * noise.to(device)
+        net = self.net
+        net._cond_rows_of(z_cond)
+        eng = net.engine(device)
+        cemb = eng.cond_embed(z_cond.to(device))
+        all_x = [x]
+        for i in range(n_steps):
+            sigma, sigma_next, gamma = sigmas[i].item(), sigmas[i + 1].item(), gammas[i].item()
+            eps = self.S_noise * (torch.randn(shape, device=device) if step_noise is None else step_noise[i].to(device))
+            sigma_hat = sigma + gamma * sigma
+            x_hat = x + sqrt(sigma_hat ** 2 - sigma ** 2) * eps
+            out = self._net_eval(eng, cemb, samples_per_cond, x_hat, sigma_hat, device)
+            if clamp:
+                out = out.clamp(-1.0, 1.0)
+            d_over = (x_hat - out) / sigma_hat
+            x_next = x_hat + (sigma_next - sigma_hat) * d_over
+            if sigma_next != 0:
+                out2 = self._net_eval(eng, cemb, samples_per_cond, x_next, sigma_next, device)
+                if clamp:
+                    out2 = out2.clamp(-1.0, 1.0)
+                d_prime = (x_next - out2) / sigma_next
+                x_next = x_hat + 0.5 * (sigma_next - sigma_hat) * (d_over + d_prime)
+            x = x_next
+            if return_all:
+                all_x.append(x)
+        return x, all_x
 
     @torch.no_grad()
     def sample_using_dpmpp(self, batch_size=16, z_cond=None, num_sample_steps=20, clamp=False, return_all=False,

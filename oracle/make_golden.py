@@ -262,6 +262,13 @@ def dpmpp_golden():
         x, all_x = ed.sample(use_dpmpp=True, batch_size=8, z_cond=zc, num_sample_steps=20, clamp=clamp, return_all=False)
         assert torch.equal(all_x[0], ed.sample_schedule(20)[0] * noise)
         out["noise"], out["x_" + name] = noise, x
+    # the stochastic Heun sampler (sample_normal), 8 steps; the draws are recorded in the reference's order
+    torch.manual_seed(SEED + 1)
+    h_noise = torch.randn(8, 1, 4)
+    h_steps = torch.stack([torch.randn(8, 1, 4) for _ in range(8)])
+    torch.manual_seed(SEED + 1)
+    xh, _ = ed.sample(use_dpmpp=False, batch_size=8, z_cond=zc, num_sample_steps=8, clamp=False, return_all=False)
+    out["heun_noise"], out["heun_step_noise"], out["x_heun"] = h_noise, h_steps, xh
     _save("dpmpp.npz", **out)
 
 

@@ -161,6 +161,47 @@ def dpmpp_sample(sd, p, z_cond, noise, num_sample_steps=20, clamp=False, groups=
     return x
 
 
+def heun_sample(sd, p, z_cond, noise, step_noise, num_sample_steps=8, clamp=False, groups=4, sigma_min=0.002,
+                sigma_max=80, sigma_data=0.5, rho=7, S_churn=80, S_tmin=0.05, S_tmax=50, S_noise=1.003):
+    """ElucidatedDiffusion.sample_normal, elucidated_diffusion.py:177-257, with the noise draws handed in
+    (noise = the initial unit-normal draw, step_noise[i] = the draw of step i)."""
+    from math import sqrt
+    N = num_sample_steps
+    inv_rho = 1 / rho
+    steps = torch.arange(N, dtype=torch.float32)
+    sigmas = (sigma_max ** inv_rho + steps / (N - 1) * (sigma_min ** inv_rho - sigma_max ** inv_rho)) ** rho
+    sigmas = F.pad(sigmas, (0, 1), value=0.0)
+    gammas = torch.where((sigmas >= S_tmin) & (sigmas <= S_tmax), min(S_churn / N, sqrt(2) - 1), 0.0)
+    batch = noise.shape[0]
+
+    def precond(xx, sigma):
+        sg = torch.full((batch,), sigma)
+        ps = sg.reshape(-1, 1, 1)
+        c_in = 1 * (ps ** 2 + sigma_data ** 2) ** -0.5
+        c_skip = (sigma_data ** 2) / (ps ** 2 + sigma_data ** 2)
+        c_out = ps * sigma_data * (sigma_data ** 2 + ps ** 2) ** -0.5
+        c_noise = torch.log(sg.clamp(min=1e-20)) * 0.25
+        net = resnet1d_forward(sd, p, c_in * xx, z_cond=z_cond, time=c_noise, groups=groups)
+        out = c_skip * xx + c_out * net
+        return out.clamp(-1.0, 1.0) if clamp else out
+
+    x = sigmas[0] * noise
+    for i in range(N):
+        sigma, sigma_next, gamma = sigmas[i].item(), sigmas[i + 1].item(), gammas[i].item()
+        eps = S_noise * step_noise[i]
+        sigma_hat = sigma + gamma * sigma
+        x_hat = x + sqrt(sigma_hat ** 2 - sigma ** 2) * eps
+        out = precond(x_hat, sigma_hat)
+        d_over = (x_hat - out) / sigma_hat
+        x_next = x_hat + (sigma_next - sigma_hat) * d_over
+        if sigma_next != 0:
+            out2 = precond(x_next, sigma_next)
+            d_prime = (x_next - out2) / sigma_next
+            x_next = x_hat + 0.5 * (sigma_next - sigma_hat) * (d_over + d_prime)
+        x = x_next
+    return x
+
+
 def decoder_forward(sd, p, z_h, cond, groups=4):
     """ConditionalGraspPoseDecoder.forward, grasp_vae.py:401-436 (no qualities)."""
     h = F.linear(z_h, sd[p + "in_layer.weight"], sd[p + "in_layer.bias"]).unsqueeze(-2)
