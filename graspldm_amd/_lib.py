@@ -44,6 +44,7 @@ _SIGNATURES = {
     "gldm_bias_act": [_vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp],
     "gldm_devoxelize_fused": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "gldm_pointwise_mlp2": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_sa_mlp_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 

@@ -2386,6 +2386,9 @@ struct PwArgs {
   const float *x, *w, *bias, *head_w, *head_b;
   float *y, *z;
   int cin, cout, n, relu, hout, tiles_per_cloud, total_tiles;
+  // optional layer in front (x [b, cin0, n] -> relu(W0 x + b0) = the [cin][32] tile of the main layer, never in HBM)
+  const float *w0, *bias0;
+  int cin0;
 };
 
 __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
@@ -2401,11 +2404,43 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
   for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_cloud, c0 = (tile - b * a.tiles_per_cloud) * NC;
     __syncthreads();  // the previous tile's readers are done
-    const float *xb = a.x + (size_t)b * a.cin * a.n + c0;
-    for (int i = tid; i < a.cin * 8; i += 512) {
-      const int row = i >> 3, q = i & 7;
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + (size_t)row * a.n + 4 * q);
-      *reinterpret_cast<f32x4 *>(lds + swz<NC>(row, 4 * q)) = v;
+    if (a.w0) {
+      // layer in front: stage its [cin0][32] input tile behind the z partials, sweep its output rows (= the main
+      // layer's input rows) with the same GEMM core and leave them in LDS as the main layer's tile
+      float *x0 = zpart + 8 * 16 * NC;
+      const float *xb0 = a.x + (size_t)b * a.cin0 * a.n + c0;
+      for (int i = tid; i < a.cin0 * 8; i += 512) {
+        const int row = i >> 3, q = i & 7;
+        *reinterpret_cast<f32x4 *>(x0 + swz<NC>(row, 4 * q)) = *reinterpret_cast<const f32x4 *>(xb0 + (size_t)row * a.n + 4 * q);
+      }
+      __syncthreads();
+      const int cb0 = a.cin0 >> 4, mt_per_wave0 = a.cin >> 7;  // cin output rows = cin / 16 m-tiles over 8 waves
+      for (int ps = 0; ps < mt_per_wave0; ps += 2) {
+        const int mt0 = wave * mt_per_wave0 + ps;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias0 + 16 * (mt0 + mi) + 4 * kq);
+          acc[mi][0] = bv;
+          acc[mi][1] = bv;
+        }
+        gemm_fast_pf<NC, 4, 1, 2, 2, 2>(c, a.w0, cb0, mt0, 0, x0, acc);
+        lds_f *d3 = (lds_f *)lds;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              d3[swz<NC>(16 * (mt0 + mi) + 4 * kq + r, 16 * ni + col)] = fmaxf(acc[mi][ni][r], 0.f);
+      }
+    } else {
+      const float *xb = a.x + (size_t)b * a.cin * a.n + c0;
+      for (int i = tid; i < a.cin * 8; i += 512) {
+        const int row = i >> 3, q = i & 7;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + (size_t)row * a.n + 4 * q);
+        *reinterpret_cast<f32x4 *>(lds + swz<NC>(row, 4 * q)) = v;
+      }
     }
     __syncthreads();
     f32x4 zacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -2534,14 +2569,16 @@ GLDM_API int gldm_pose_epilogue(const float *tmrp, const float *logit, const flo
 }
 
 
-GLDM_API int gldm_pointwise_mlp(const float *x, const float *w_packed, const float *bias, int b, int cin, int cout,
-                                int n, int relu, const float *head_w_packed, const float *head_bias, int hout,
-                                float *y, float *z, gldm_stream_t stream) {
-  if (!x || !w_packed || !bias || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
-  if (!y && !head_w_packed) return GLDM_ERR_INVALID_ARG;
-  if (head_w_packed && (!z || hout <= 0 || hout > 16)) return GLDM_ERR_INVALID_ARG;
+namespace {
+int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0, const float *w, const float *bias, int b,
+                     int cin, int cout, int n, int relu, const float *head_w, const float *head_b, int hout, float *y,
+                     float *z, hipStream_t stream) {
+  if (!x || !w || !bias || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
+  if (!y && !head_w) return GLDM_ERR_INVALID_ARG;
+  if (head_w && (!z || hout <= 0 || hout > 16)) return GLDM_ERR_INVALID_ARG;
   if ((cin & 31) || (cout & 255) || (n & 31)) return GLDM_ERR_UNSUPPORTED;  // k-blocks in pairs, 2 m-tiles x 8 waves, 32-point tiles
-  const size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32) * sizeof(float);
+  if (w0 && (!b0 || cin0 <= 0 || (cin0 & 31) || (cin & 255))) return GLDM_ERR_UNSUPPORTED;
+  const size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
   if (lds_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
   static bool attr = false;
   if (!attr) {
@@ -2550,15 +2587,33 @@ GLDM_API int gldm_pointwise_mlp(const float *x, const float *w_packed, const flo
     attr = true;
   }
   PwArgs a{};
-  a.x = x; a.w = w_packed; a.bias = bias; a.head_w = head_w_packed; a.head_b = head_bias; a.y = y; a.z = z;
+  a.x = x; a.w = w; a.bias = bias; a.head_w = head_w; a.head_b = head_b; a.y = y; a.z = z;
   a.cin = cin; a.cout = cout; a.n = n; a.relu = relu; a.hout = hout;
+  a.w0 = w0; a.bias0 = b0; a.cin0 = cin0;
   a.tiles_per_cloud = n / 32;
   a.total_tiles = b * a.tiles_per_cloud;
   const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
   int grid = cu_count() * per_cu;
   if (grid > a.total_tiles) grid = a.total_tiles;
-  hipLaunchKernelGGL(pointwise_mlp_kernel, dim3(grid), dim3(512), lds_bytes, reinterpret_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(pointwise_mlp_kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+}  // namespace
+
+GLDM_API int gldm_pointwise_mlp(const float *x, const float *w_packed, const float *bias, int b, int cin, int cout,
+                                int n, int relu, const float *head_w_packed, const float *head_bias, int hout,
+                                float *y, float *z, gldm_stream_t stream) {
+  return launch_pointwise(x, nullptr, nullptr, 0, w_packed, bias, b, cin, cout, n, relu, head_w_packed, head_bias, hout,
+                          y, z, reinterpret_cast<hipStream_t>(stream));
+}
+
+GLDM_API int gldm_pointwise_mlp2(const float *x, const float *w0_packed, const float *bias0, int cin0,
+                                 const float *w_packed, const float *bias, int b, int cin, int cout, int n,
+                                 const float *head_w_packed, const float *head_bias, int hout, float *y, float *z,
+                                 gldm_stream_t stream) {
+  if (!w0_packed) return GLDM_ERR_INVALID_ARG;
+  return launch_pointwise(x, w0_packed, bias0, cin0, w_packed, bias, b, cin, cout, n, 1, head_w_packed, head_bias,
+                          hout, y, z, reinterpret_cast<hipStream_t>(stream));
 }
 
 GLDM_API int gldm_sa_mlp_forward(const float *points, const float *centers, const float *features,

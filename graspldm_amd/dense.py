@@ -64,17 +64,30 @@ def fused_mlp_supported(x, cin, cout):
             and 4 * (32 * cin + 4096) <= 160 * 1024)
 
 
-def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True):
+def fused_mlp2_supported(x, cin0, cin, cout):
+    """Two layers in one launch (gldm_pointwise_mlp2): cin0 -> cin -> cout."""
+    return (x.ndim == 3 and x.is_contiguous() and cin0 % 32 == 0 and cin % 256 == 0 and cout % 256 == 0
+            and x.shape[-1] % 32 == 0 and 4 * (32 * (cin + cin0) + 4096) <= 160 * 1024)
+
+
+def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True, front=None):
     """One fused launch: y = act(W x + b) over [B, Cin, N] (hand-written f32-MFMA GEMM, csrc/resnet1d.hip:
-    pointwise_mlp_kernel) and optionally z = Wh y + bh on the accumulators.  head = (packed Wh, bh, hout)."""
+    pointwise_mlp_kernel) and optionally z = Wh y + bh on the accumulators.  head = (packed Wh, bh, hout).
+    front = (packed W0, b0, cin): a ReLU layer x -> relu(W0 x + b0) in front, its output kept in LDS only."""
     from . import _lib as L
     b, cin, n = x.shape
     y = torch.empty((b, cout, n), dtype=torch.float32, device=x.device) if keep_y or head is None else None
     z = torch.empty((b, head[2], n), dtype=torch.float32, device=x.device) if head is not None else None
+    hp = (L.ptr(head[0]) if head else None, L.ptr(head[1]) if head else None, head[2] if head else 0)
     with torch.cuda.device(x.device):
-        L.call("gldm_pointwise_mlp", L.ptr(x), L.ptr(w_packed), L.ptr(bias), b, cin, cout, n, int(relu),
-               L.ptr(head[0]) if head else None, L.ptr(head[1]) if head else None, head[2] if head else 0,
-               L.ptr(y), L.ptr(z), L.current_stream(x.device))
+        if front is not None:
+            if not relu:
+                raise ValueError("the two-layer launch applies ReLU after both layers")
+            L.call("gldm_pointwise_mlp2", L.ptr(x), L.ptr(front[0]), L.ptr(front[1]), cin, L.ptr(w_packed), L.ptr(bias),
+                   b, front[2], cout, n, *hp, L.ptr(y), L.ptr(z), L.current_stream(x.device))
+        else:
+            L.call("gldm_pointwise_mlp", L.ptr(x), L.ptr(w_packed), L.ptr(bias), b, cin, cout, n, int(relu), *hp,
+                   L.ptr(y), L.ptr(z), L.current_stream(x.device))
     return y, z
 
 

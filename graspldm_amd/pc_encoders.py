@@ -43,9 +43,9 @@ class PVCNNEncoder(nn.Module):
         return x.squeeze(1) if x.shape[-2] == 1 else x
 
     def _backbone_and_head(self, x, cond, w, b):
-        """backbone -> head.  When the backbone ends in a wide SharedMLP layer (PVCNN: 768 -> 1536), that layer and the
-        folded head run as ONE launch: the head product is taken on the layer's accumulators and its [B, 1536, N]
-        output (1.6 GB per 256 clouds) is never written."""
+        """backbone -> head.  When the backbone ends in wide SharedMLP layers (PVCNN: 96 -> 768 -> 1536), they and the
+        folded head run as ONE launch: the 768-row tile is produced in LDS, the head product is taken on the last
+        layer's accumulators, and neither [B, 768, N] (0.8 GB per 256 clouds) nor [B, 1536, N] (1.6 GB) is written."""
         from .pvcnn import PVCNN, SharedMLP
         bb = self.pvcnn_modules
         layers = list(bb.point_features) if isinstance(bb, PVCNN) else []
@@ -55,9 +55,19 @@ class PVCNNEncoder(nn.Module):
             cin, cout = conv.weight.shape[1], conv.weight.shape[0]
             feats = x[:, : bb.in_channels, :]
             coords = feats[:, :3, :].contiguous()
-            for layer in layers[:-1]:
+            prev = layers[-2] if len(layers) > 1 else None
+            two = isinstance(prev, SharedMLP) and len(prev.layers) == 3  # 96 -> 768 -> 1536 -> head in one launch
+            for layer in layers[: -2 if two else -1]:
                 feats, _ = layer((feats, coords))
             feats = feats.contiguous().float()
+            if two:
+                conv0, bn0 = prev.layers[0], prev.layers[1]
+                if w.shape[0] <= 16 and dense.fused_mlp2_supported(feats, conv0.weight.shape[1], cin, cout):
+                    _, b0, wp0 = dense.folded_conv_bn(conv0, bn0, feats.device)
+                    _, bf, wp = dense.folded_conv_bn(conv, bn, feats.device)
+                    return dense.pointwise_mlp(feats, wp, bf, cout, True, head=self._packed_head(w, b), keep_y=False,
+                                               front=(wp0, b0, cin))[1]
+                feats = prev(feats).contiguous()
             if w.shape[0] <= 16 and dense.fused_mlp_supported(feats, cin, cout):
                 _, bf, wp = dense.folded_conv_bn(conv, bn, feats.device)
                 return dense.pointwise_mlp(feats, wp, bf, cout, True, head=self._packed_head(w, b), keep_y=False)[1]

@@ -271,6 +271,15 @@ int gldm_pointwise_mlp(const float *x /*[b,cin,n]*/, const float *w_packed, cons
                        const float *head_w_packed, const float *head_bias /*[hout] or NULL*/, int hout,
                        float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
 
+/* Two consecutive SharedMLP layers (both with ReLU) and the optional head in ONE launch: the first layer's output
+ * (x [b,cin0,n] -> [b,cin,n]) is produced tile by tile in LDS as the second layer's input and never reaches HBM
+ * (the shipped encoder's 96 -> 768 -> 1536 -> head: 0.8 GB less written and read per 256 clouds).
+ * cin0 % 32 == 0, cin % 256 == 0, other constraints as gldm_pointwise_mlp, 4 (32 (cin + cin0) + 4096) <= 160 KiB. */
+int gldm_pointwise_mlp2(const float *x /*[b,cin0,n]*/, const float *w0_packed, const float *bias0 /*[cin]*/, int cin0,
+                        const float *w_packed, const float *bias /*[cout]*/, int b, int cin, int cout, int n,
+                        const float *head_w_packed, const float *head_bias, int hout,
+                        float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
+
 /* ---------------------------------------------------------- voxel branch of PVConv */
 
 /* ref: grasp_ldm/models/modules/ext/pvcnn/modules/pvconv.py:48-66 (nn.Conv3d k=3 p=1 on the

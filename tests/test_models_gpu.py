@@ -348,6 +348,39 @@ def test_pointwise_mlp_layer_and_fused_head(b, cin, cout, n, relu, hout):
         assert torch.equal(z, z2)   # the head does not depend on whether y is also written
 
 
+@pytest.mark.parametrize("b,cin0,cin,cout,n,hout", [(2, 96, 768, 1536, 64, 3), (3, 32, 256, 256, 96, 0),
+                                                    (1, 64, 512, 768, 32, 16)])
+def test_pointwise_mlp_two_layers_one_launch(b, cin0, cin, cout, n, hout):
+    """gldm_pointwise_mlp2: relu(W1 relu(W0 x + b0) + b1) (+ head) with the middle tensor kept in LDS, against the
+    same two layers as separate gldm_pointwise_mlp launches (bit-identical: same GEMM core, same k order) and against
+    a torch-CPU f32 reference (2e-5 of the output scale)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from graspldm_amd import dense
+    from graspldm_amd.r1d_pack import mfma_a_fragments
+    g = torch.Generator().manual_seed(cin0 + cin + cout)
+    x = torch.randn(b, cin0, n, generator=g)
+    w0, b0 = torch.randn(cin, cin0, generator=g) / cin0 ** 0.5, torch.randn(cin, generator=g)
+    w1, b1 = torch.randn(cout, cin, generator=g) / cin ** 0.5, torch.randn(cout, generator=g)
+    h_ref = (torch.einsum("oc,bcn->bon", w0, x) + b0.view(1, -1, 1)).relu()
+    y_ref = (torch.einsum("oc,bcn->bon", w1, h_ref) + b1.view(1, -1, 1)).relu()
+    head = None
+    if hout:
+        wh, bh = torch.randn(hout, cout, generator=g) / cout ** 0.5, torch.randn(hout, generator=g)
+        z_ref = torch.einsum("oc,bcn->bon", wh, y_ref) + bh.view(1, -1, 1)
+        head = (dense.pack_head(wh).cuda(), bh.cuda(), hout)
+    xc, p0, p1 = x.cuda(), mfma_a_fragments(w0).cuda(), mfma_a_fragments(w1).cuda()
+    assert dense.fused_mlp2_supported(xc, cin0, cin, cout)
+    y, z = dense.pointwise_mlp(xc, p1, b1.cuda(), cout, True, head=head, keep_y=True, front=(p0, b0.cuda(), cin))
+    h = dense.pointwise_mlp(xc, p0, b0.cuda(), cin, True)[0]
+    y2, z2 = dense.pointwise_mlp(h, p1, b1.cuda(), cout, True, head=head, keep_y=True)
+    assert _err(y, y_ref) < 2e-5 * max(1.0, y_ref.abs().max().item())
+    assert torch.equal(y, y2)
+    if hout:
+        assert _err(z, z_ref) < 2e-5 * max(1.0, z_ref.abs().max().item())
+        assert torch.equal(z, z2)
+
+
 def test_pointwise_mlp_rejects_unsupported_shapes():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
