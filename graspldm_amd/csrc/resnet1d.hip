@@ -89,6 +89,9 @@ struct Geo {
 static_assert(Geo<64>::kLdsFloats * 4 <= 160 * 1024, "LDS budget (1 WG/CU)");
 static_assert(Geo<32>::kLdsFloats * 4 * 2 <= 160 * 1024, "LDS budget (2 WG/CU)");
 
+// (Tried: XOR with row bit 0 ^ row bit 2, which also frees the accumulator stores (rows 4 kq + r) of their 2-way bank
+// conflict.  The B-fragment reads of a k-block then need two base registers instead of one with immediate offsets,
+// and every GEMM phase got 5-7 % slower.)
 template <int NC>
 __device__ __forceinline__ int swz(int row, int col) { return row * NC + (col ^ ((row & 1) << 4)); }
 
@@ -153,9 +156,12 @@ __device__ __forceinline__ float tap_right(float v, bool keep) {  // value of co
 // Fast path (Cin % 16 == 0).  A 16-column tile never straddles a sample (L divides 16), so the
 // row-boundary lanes of the halo shift are exactly the lanes whose tap falls outside the sample:
 // zero fill (bound_ctrl) for L = 16, an extra (col % L) mask for L = 4.
-template <int NC, int L, int TAPS, int MT, int NT, int PF>
+struct NoPre { __device__ __forceinline__ void operator()() const {} };
+// pre(): work that does not depend on the GEMM, run right after the first weight fragments have been requested (it
+// then costs nothing while their round trip is outstanding).
+template <int NC, int L, int TAPS, int MT, int NT, int PF, class PRE = NoPre>
 __device__ __forceinline__ void gemm_fast_pf(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0, int nt0,
-                                             const float *src, f32x4 (&acc)[MT][NT]) {
+                                             const float *src, f32x4 (&acc)[MT][NT], const PRE &pre = PRE()) {
   // PF = weight blocks in flight; cblocks % PF == 0.  The unrolled body is UNCONDITIONAL: a load
   // whose only consumer sits behind a branch is sunk into that branch by the compiler (and then
   // waited for at once), and a branch around a load forces s_waitcnt 0 at the join.  Block indices
@@ -228,6 +234,7 @@ __device__ __forceinline__ void gemm_fast_pf(const Ctx &c, const float *__restri
     for (int cb = 0; cb < cblocks; ++cb) {
       load_a(0, cb, -1);
       load_b(0, cb);
+      if (cb == 0) pre();
 #pragma unroll
       for (int j = 0; j < 4; ++j) mfma_step(0, 0, j);
     }
@@ -235,6 +242,9 @@ __device__ __forceinline__ void gemm_fast_pf(const Ctx &c, const float *__restri
 #pragma unroll
     for (int u = 0; u < PF - 1; ++u) load_a(u, u < last ? u : last, -1);
     load_b(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    pre();
+    __builtin_amdgcn_sched_barrier(0);
     for (int cb0 = 0; cb0 < cblocks; cb0 += PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -1111,10 +1121,11 @@ __device__ __forceinline__ void out_ln_pm(const Ctx &c, int w_off, int b_off, co
 }
 
 // PreNorm LayerNorm + to_qkv 1x1 conv of the 4-channel level (resnets.py:104-124,211-222) as one VALU phase: a column's
-// 4 channels are normalised in its lane (no exchange), then wave w produces rows 24 w .. 24 w + 23 of the 192-row
-// q|k|v block of one head pair: 96 FMAs per lane against wave-uniform (scalar-path) weights, fma chain in the MFMA's
-// k order.  Replaces a 3-barrier LayerNorm pass and a padded K = 16 MFMA GEMM (8 k cycles) by ~1 k cycles.
-__device__ __forceinline__ void qkv4_pm(const Ctx &c, int w_off, int g_off, const float *src, float *dst) {
+// 4 channels are normalised in its lane (no exchange), then wave w produces rows 48 w .. 48 w + 47 of the 384-row
+// q|k|v block (all four heads, to_qkv's own row order; the LayerNorm gain is folded into the packed weights): 192
+// FMAs per lane against wave-uniform weights, fma chain in the MFMA's k order.  Replaces a 3-barrier LayerNorm pass
+// and padded K = 16 MFMA GEMMs.
+__device__ __forceinline__ void qkv4_pm(const Ctx &c, int w_off, const float *src, float *dst) {
   constexpr int NC = 64;
   const int n = c.lane;
   const lds_f *s3 = (const lds_f *)src;
@@ -1130,96 +1141,198 @@ __device__ __forceinline__ void qkv4_pm(const Ctx &c, int w_off, int g_off, cons
     vt += d * d;
   }
   const float rstd = __builtin_amdgcn_rsqf(vt * 0.25f + 1e-5f);
-  const float *g = c.w + g_off;
   float y[4];
 #pragma unroll
-  for (int ci = 0; ci < 4; ++ci) y[ci] = (x[ci] - mean) * rstd * g[ci];
-  // A fragments of [192 x 16 (4 real)]: lane (r % 16) + 16 k of m-tile r / 16 holds W[r][k] in its first element.  The
-  // wave's 24 rows span two m-tiles: two fragment loads, then every weight is broadcast from its lane (v_readlane:
-  // no memory round trip per weight).
+  for (int ci = 0; ci < 4; ++ci) y[ci] = (x[ci] - mean) * rstd;
+  // A fragments of [384 x 16 (4 real)]: lane (r % 16) + 16 k of m-tile r / 16 holds W'[r][k] in its first element.
+  // Three fragment loads for the wave's three m-tiles, then every weight is broadcast from its lane (v_readlane: no
+  // memory round trip per weight).
   const WStream wv(c.w + w_off, c.lane);
-  const int r0 = __builtin_amdgcn_readfirstlane(c.wave * 24), t0 = r0 >> 4;
-  const f32x4 f0 = wv[(size_t)t0 * 64], f1 = wv[(size_t)(t0 + 1) * 64];
+  const int t0 = __builtin_amdgcn_readfirstlane(c.wave * 3);
+  f32x4 f[3];
 #pragma unroll
-  for (int q = 0; q < 24; ++q) {
-    const int r = r0 + q;
-    const bool second = (r >> 4) != t0;  // wave uniform
-    const int fv = __float_as_int(second ? f1[0] : f0[0]);
-    float acc = 0.f;
+  for (int t = 0; t < 3; ++t) f[t] = wv[(size_t)(t0 + t) * 64];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(fv, (r & 15) + 16 * k)), y[k], acc);
-    d3[swz<NC>(r, n)] = acc;
+  for (int t = 0; t < 3; ++t) {
+    const int fv = __float_as_int(f[t][0]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(fv, q + 16 * k)), y[k], acc);
+      d3[swz<NC>(16 * (t0 + t) + q, n)] = acc;
+    }
   }
   __syncthreads();
 }
 
-// LinearAttention core for one head pair (qkv [192][64] -> 64 rows of o), position-major.
-// Phase 1: softmax of k over the sample's 4 positions, once per (head, channel, sample), written back in place
-// (wave = (head, 8 channels), lane = (sample, channel pair)).  Phase 2: wave = (head of the pair, position), lane =
-// (sample, part): 8 of the head's 32 channels at column 16 * position + sample; the sample's four key / value columns
-// are the same lane's columns in the four position tiles; every reduction over the parts is a permlane swap inside
-// the wave.  (Without phase 1 each of the 4 position waves recomputed the key softmax: 32 exponentials per lane.)
-__device__ __forceinline__ void attention_pair_pm(const Ctx &c, float *qkv, float *o_rows) {
+// PreNorm LayerNorm folded into the to_qkv 1x1 conv (resnets.py:104-124,211-222) for the 16 | C levels of the
+// position-major engine:  W (g * (x - mean) * rstd) = rstd * (W' x - mean * s),  W' = W diag(g), s = W' 1  (both
+// prepared on the host).  All 384 q|k|v rows (to_qkv's own order) in one sweep: 3 m-tiles x 4 n-tiles a wave.
+// The column statistics are taken while the first weight fragments are on their way: wave w owns columns 8 w .. 8 w + 7,
+// lane = (row part, column), two passes over the C / 8 values in its registers (the reference's mean, then
+// sum (x - mean)^2), the parts meet through DPP / permlane swaps, (mean, rstd) go to LDS and are picked up by every
+// wave's epilogue after the barrier that follows the GEMM: no LayerNorm phase, no normalised copy of x.
+template <int RP>  // rows per lane: C / 8
+__device__ __forceinline__ void column_stats8(const Ctx &c, const float *src, float inv_c) {
+  constexpr int NC = 64;
+  using GG = Geo<NC>;
+  const lds_f *s3 = (const lds_f *)src;
+  const int n = 8 * c.wave + (c.lane & 7), rp = c.lane >> 3;
+  float v[RP], sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < RP; ++i) {
+    v[i] = s3[swz<NC>(rp + 8 * i, n)];
+    sum += v[i];
+  }
+  auto all_parts = [](float x) {  // lanes differing in bits 3, 4, 5
+    x += dpp_mov<0x128>(x);  // row_ror:8
+    return half_sum(row_pair_sum(x));
+  };
+  const float mean = all_parts(sum) * inv_c;
+  float m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < RP; ++i) {
+    const float d = v[i] - mean;
+    m2 = fmaf(d, d, m2);
+  }
+  const float rstd = __builtin_amdgcn_rsqf(all_parts(m2) * inv_c + 1e-5f);
+  if (rp == 0) {
+    ((lds_f *)(c.lds + GG::kMiscRed1))[n] = mean;
+    ((lds_f *)(c.lds + GG::kMiscRed2))[n] = rstd;
+  }
+}
+
+__device__ __forceinline__ void qkv_ln_pm(const Ctx &c, int w_off, int s_off, const float *src, int C, float *dst) {
+  constexpr int NC = 64, MT = 3, NT = 4;
+  using GG = Geo<NC>;
+  if (GLDM_SKIP(c, 8)) return;
+  const float *wp = c.w + w_off, *srow = c.w + s_off;
+  const int mt0 = 3 * c.wave;
+  const int col = c.lane & 15, kq = c.lane >> 4;
+  f32x4 sv[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) sv[mi] = *reinterpret_cast<const f32x4 *>(srow + 16 * (mt0 + mi) + 4 * kq);
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int cblocks = C >> 4;
+  const float inv_c = __builtin_amdgcn_rcpf((float)C);  // C: a power of two -> exact
+  if (cblocks == 8) {
+    gemm_fast_pf<NC, 4, 1, MT, NT, 4>(c, wp, cblocks, mt0, 0, src, acc, [&]() { column_stats8<16>(c, src, inv_c); });
+  } else if (cblocks == 4) {
+    gemm_fast_pf<NC, 4, 1, MT, NT, 4>(c, wp, cblocks, mt0, 0, src, acc, [&]() { column_stats8<8>(c, src, inv_c); });
+  } else {
+    gemm_fast_pf<NC, 4, 1, MT, NT, 2>(c, wp, cblocks, mt0, 0, src, acc, [&]() { column_stats8<4>(c, src, inv_c); });
+  }
+  __syncthreads();  // every column's (mean, rstd) is in LDS
+  const lds_f *mean3 = (const lds_f *)(c.lds + GG::kMiscRed1), *rstd3 = (const lds_f *)(c.lds + GG::kMiscRed2);
+  lds_f *d3 = (lds_f *)dst;
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const float rstd = rstd3[16 * ni + col];
+    const float mr = mean3[16 * ni + col] * rstd;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int row0 = 16 * (mt0 + mi) + 4 * kq, cf = 16 * ni + col;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d3[swz<NC>(row0 + r, cf)] = acc[mi][ni][r] * rstd - mr * sv[mi][r];
+    }
+  }
+  __syncthreads();
+}
+
+// LinearAttention core (resnets.py:223-235) of all four heads, position-major, in place: qkv [384][64] in to_qkv's row
+// order (q | k | v, head h at rows 32 h of each third); the output o [128][64] overwrites q.
+//   out[e][n] = sum_m v[e][m] A[m][n],   A[m][n] = scale / sum_d exp(q[d][n] - max) * sum_d softmax_m(k[d])[m] exp(q[d][n] - max)
+// Phase 1: softmax of k over the sample's 4 positions, once per (head, channel, sample), written back in place (wave =
+// (head, 16 channels), lane = (sample, 4 channels)).  Phase 2: wave = (head, position pair), lane = (sample, part):
+// 8 of the head's 32 channels at the two columns 16 * position + sample; the sample's four key / value columns are
+// the same lane's columns in the four position tiles, read once for both positions; every reduction over the parts
+// is a permlane swap inside the wave.  A lane overwrites exactly the q elements it alone has read: no o buffer.
+// Banks: lanes l and l + 16 (neighbouring parts) sit 8 (phase 1: 4) rows apart in the same columns, the same bank of
+// a ds_read_b32 / ds_write_b32.  Phase 1's odd parts walk the positions in the order 1, 0, 3, 2 and phase 2's odd
+// parts walk their channels in that order: opposite row parity or column half, hence the other half of the banks.
+__device__ __forceinline__ void attention_quad_pm(const Ctx &c, float *qkv) {
   constexpr int NC = 64;
   if (GLDM_SKIP(c, 4)) return;
   lds_f *q3 = (lds_f *)qkv;
-  lds_f *o3 = (lds_f *)o_rows;
-  const int sm = c.lane & 15, pt = c.lane >> 4;
+  const int sm = c.lane & 15, pt = c.lane >> 4, odd = pt & 1;
+  const int head = c.wave >> 1, half = c.wave & 1;
   {
-    const int row0 = 64 + (c.wave >> 2) * kDimHead + 8 * (c.wave & 3) + 2 * pt;
+    const int row0 = kHidden + kDimHead * head + 16 * half + 4 * pt, cx = odd << 4;
+    float k[4][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float k[4];
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) k[j] = q3[swz<NC>(row0 + u, 16 * j + sm)];
-      const float km = fmaxf(fmaxf(k[0], k[1]), fmaxf(k[2], k[3]));
+      for (int j = 0; j < 4; ++j) k[u][j] = q3[swz<NC>(row0 + u, (16 * j + sm) ^ cx)];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) k[j] = fast_exp(k[j] - km);
-      const float inv = __builtin_amdgcn_rcpf(k[0] + k[1] + k[2] + k[3]);
+    for (int u = 0; u < 4; ++u) {
+      const float km = fmaxf(fmaxf(k[u][0], k[u][1]), fmaxf(k[u][2], k[u][3]));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q3[swz<NC>(row0 + u, 16 * j + sm)] = k[j] * inv;
+      for (int j = 0; j < 4; ++j) k[u][j] = fast_exp(k[u][j] - km);
+      const float inv = __builtin_amdgcn_rcpf(k[u][0] + k[u][1] + k[u][2] + k[u][3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q3[swz<NC>(row0 + u, (16 * j + sm) ^ cx)] = k[u][j] * inv;
     }
   }
-  const int h2 = c.wave >> 2, pq = c.wave & 3, d0 = 8 * pt;
-  const int nn = 16 * pq + sm;
-  const int qr = h2 * kDimHead + d0, kr = 64 + h2 * kDimHead + d0, vr = 128 + h2 * kDimHead + d0;
-  float q[8];
-  float qmax = -3.0e38f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    q[i] = q3[swz<NC>(qr + i, nn)];
-    qmax = fmaxf(qmax, q[i]);
-  }
+  const int d0 = kDimHead * head + 8 * pt;
+  const int qr = d0, kr = kHidden + d0, vr = 2 * kHidden + d0;
+  const int n0 = 32 * half + sm;  // columns of the wave's two positions: n0, n0 + 16
+  float qe[2][8], qsum[2];
   float vv[8][4];
+  {
+    float q[2][8], qmax[2] = {-3.0e38f, -3.0e38f};
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vv[i][j] = q3[swz<NC>(vr + i, 16 * j + sm)];
-  qmax = half_max(row_pair_max(qmax));
-  float qe[8], qsum = 0.f;
+      for (int e = 0; e < 2; ++e) {
+        q[e][i] = q3[swz<NC>(qr + (i ^ odd), n0 + 16 * e)];
+        qmax[e] = fmaxf(qmax[e], q[e][i]);
+      }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    qe[i] = fast_exp(q[i] - qmax);
-    qsum += qe[i];
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vv[i][j] = q3[swz<NC>(vr + (i ^ odd), 16 * j + sm)];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      qmax[e] = half_max(row_pair_max(qmax[e]));
+      qsum[e] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        qe[e][i] = fast_exp(q[e][i] - qmax[e]);
+        qsum[e] += qe[e][i];
+      }
+    }
   }
   __syncthreads();  // phase 1's normalised keys are in place
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float a[2][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    a0 += q3[swz<NC>(kr + i, sm)] * qe[i];
-    a1 += q3[swz<NC>(kr + i, 16 + sm)] * qe[i];
-    a2 += q3[swz<NC>(kr + i, 32 + sm)] * qe[i];
-    a3 += q3[swz<NC>(kr + i, 48 + sm)] * qe[i];
-  }
-  qsum = half_sum(row_pair_sum(qsum));
-  a0 = half_sum(row_pair_sum(a0)); a1 = half_sum(row_pair_sum(a1));
-  a2 = half_sum(row_pair_sum(a2)); a3 = half_sum(row_pair_sum(a3));
-  const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(qsum);  // dim_head ** -0.5 / sum
-  a0 *= sc; a1 *= sc; a2 *= sc; a3 *= sc;
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[e][j] = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
-    o3[swz<NC>(h2 * kDimHead + d0 + i, nn)] = vv[i][0] * a0 + vv[i][1] * a1 + vv[i][2] * a2 + vv[i][3] * a3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float kk = q3[swz<NC>(kr + (i ^ odd), 16 * j + sm)];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) a[e][j] = fmaf(kk, qe[e][i], a[e][j]);
+    }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(half_sum(row_pair_sum(qsum[e])));  // dim_head ** -0.5 / sum
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[e][j] = half_sum(row_pair_sum(a[e][j])) * sc;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      q3[swz<NC>(qr + (i ^ odd), n0 + 16 * e)] =
+          vv[i][0] * a[e][0] + vv[i][1] * a[e][1] + vv[i][2] * a[e][2] + vv[i][3] * a[e][3];
   __syncthreads();
 }
 
@@ -1629,7 +1742,7 @@ struct RunArgs {
 // down conv).  It is written once per workgroup into LDS (12 ints per op) and interpreted by a switch
 // inside the step loop, so every phase body exists once, inlined, with registers allocated across the
 // whole kernel: no calls, no callee-save traffic and no spilled kernel state between phases.
-enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKV4 = 5, OP_OUTLN = 6 };
+enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKV4 = 5, OP_OUTLN = 6, OP_QKVLN = 7 };
 // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9
 constexpr int kFlagAlias = 1 << 8;
 
@@ -1776,21 +1889,27 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
       resblock(d.rb[2 * lv], C, false);
       resblock(d.rb[2 * lv + 1], C, true);
       const gldm_r1d_level &v = d.lv[lv];
-      if (NC == 64 && C == 4) {  // LayerNorm + qkv of the 4-channel level: one VALU phase per head pair
-        emit(OP_QKV4, v.qkv_w[0], v.ln_g, X, QKV);
-        emit(OP_ATT, QKV, O);
-        emit(OP_QKV4, v.qkv_w[1], v.ln_g, X, QKV);
+      // position-major engine (C <= 128 at attention levels): X rows [0, 128) | q,k,v of the four heads: 384 rows, o in
+      // place of q.  The PreNorm LayerNorm is folded into the qkv conv (C = 4: computed in the lanes of the qkv phase).
+      constexpr int QKV4H = 128 * NC;
+      static_assert(NC != 64 || QKV4H + 3 * kHidden * NC <= GG::kArena, "four-head attention layout");
+      int Oa = O;
+      if (NC == 64) {
+        if (C == 4) emit(OP_QKV4, v.qkvn_w, X, QKV4H);
+        else emit(OP_QKVLN, v.qkvn_w, v.qkvn_s, X, QKV4H, C);
+        emit(OP_ATT, QKV4H);
+        Oa = QKV4H;
       } else {
         emit(OP_LN, X, Y, -1, C, v.ln_g);
         emit(OP_CONV, v.qkv_w[0], -1, Y, QKV, C, 192, 1);
         emit(OP_ATT, QKV, O);
         emit(OP_CONV, v.qkv_w[1], -1, Y, QKV, C, 192, 1);
+        emit(OP_ATT, QKV, O + 64 * NC);
       }
-      emit(OP_ATT, QKV, O + 64 * NC);
       if (NC == 64 && (C == 4 || C == 32 || C == 64 || C == 128)) {  // to_out conv + LayerNorm + residual: one phase
-        emit(OP_OUTLN, v.out_w, v.out_b, O, X, kHidden, C, v.ln2_g);
+        emit(OP_OUTLN, v.out_w, v.out_b, Oa, X, kHidden, C, v.ln2_g);
       } else {
-        emit(OP_CONV, v.out_w, v.out_b, O, Y, kHidden, C, 1);
+        emit(OP_CONV, v.out_w, v.out_b, Oa, Y, kHidden, C, 1);
         emit(OP_LN, Y, -1, X, C, v.ln2_g);
       }
       emit(OP_CONV, v.down_w, v.down_b, X, X, C, Cn, 3 | kFlagAlias);
@@ -1838,7 +1957,10 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
         if (o[11]) __syncthreads();
         break;
       case OP_QKV4:
-        if constexpr (NC == 64) qkv4_pm(c, o[1], o[2], c.lds + o[3], c.lds + o[4]);
+        if constexpr (NC == 64) qkv4_pm(c, o[1], c.lds + o[2], c.lds + o[3]);
+        break;
+      case OP_QKVLN:
+        if constexpr (NC == 64) qkv_ln_pm(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4]);
         break;
       case OP_OUTLN:
         if constexpr (NC == 64) out_ln_pm(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4], o[6], o[7]);
@@ -1848,7 +1970,7 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
                             o[4], o[5]);
         break;
       default:
-        if constexpr (NC == 64) attention_pair_pm(c, c.lds + o[1], c.lds + o[2]);
+        if constexpr (NC == 64) attention_quad_pm(c, c.lds + o[1]);
         else attention_pair<NC, L>(c, c.lds + o[1], c.lds + o[2]);
         break;
     }
@@ -2249,6 +2371,8 @@ bool pm_supported(const gldm_r1d_desc *d) {
 #endif
   if (d->seq_len != 4 || d->latent_dim != 0 || d->n_head != 0 || d->emb_dim != 16 || d->groups != 4) return false;
   if (d->dims[0] != 4) return false;
+  for (int i = 0; i < d->n_levels; ++i)  // to_qkv with the PreNorm gain folded in (ABI 4 packers provide it)
+    if (d->lv[i].qkvn_w <= 0 || d->lv[i].qkvn_s <= 0) return false;
   for (int i = 1; i <= d->n_levels; ++i) {
     const int C = d->dims[i];
     if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false;
@@ -2339,7 +2463,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
                     : (L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s));
   if (stamp) {
     static long long host[kMaxOps + 2];
-    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "QKV4", "OUTLN"};
+    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "QKV4", "OUTLN", "QKVLN"};
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(host, dstamps, sizeof(host), hipMemcpyDeviceToHost);
     // the tape is rebuilt on the host only to label the stamps
@@ -2347,7 +2471,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
     for (int i = 0; i <= a.d.n_levels; ++i) dims[i] = a.d.dims[i];
     int op = 0;
     auto line = [&](int type, int C, int cout, int taps) {
-      printf("op %3d %-4s C=%3d cout=%3d k=%d : %7lld clk\n", op, names[type], C, cout, taps, host[op + 1] - host[op]);
+      printf("op %3d %-5s C=%3d cout=%3d k=%d : %7lld clk\n", op, names[type], C, cout, taps, host[op + 1] - host[op]);
       ++op;
     };
     auto resblock = [&](int C) {
@@ -2357,7 +2481,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
     for (int lv = 0; lv < a.d.n_levels; ++lv) {
       const int C = dims[lv];
       resblock(C); resblock(C);
-      if (pm && C == 4) { line(5, C, 192, 1); line(4, C, 64, 0); line(5, C, 192, 1); line(4, C, 64, 0); }
+      if (pm) { line(C == 4 ? 5 : 7, C, 384, 1); line(4, C, 128, 0); }
       else { line(3, C, C, 0); line(1, C, 192, 1); line(4, C, 64, 0); line(1, C, 192, 1); line(4, C, 64, 0); }
       if (pm && (C == 4 || C == 32 || C == 64 || C == 128)) line(6, 128, C, 1);
       else { line(1, 128, C, 1); line(3, C, C, 0); }

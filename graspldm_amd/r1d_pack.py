@@ -28,7 +28,7 @@ class R1dResblock(ctypes.Structure):
 class R1dLevel(ctypes.Structure):
     _fields_ = [("ln_g", ctypes.c_int32), ("qkv_w", ctypes.c_int32 * 2), ("out_w", ctypes.c_int32),
                 ("out_b", ctypes.c_int32), ("ln2_g", ctypes.c_int32), ("down_w", ctypes.c_int32),
-                ("down_b", ctypes.c_int32)]
+                ("down_b", ctypes.c_int32), ("qkvn_w", ctypes.c_int32), ("qkvn_s", ctypes.c_int32)]
 
 
 class R1dDesc(ctypes.Structure):
@@ -152,6 +152,11 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
         for pr in range(2):
             rows = torch.cat([wqkv[o + 64 * pr:o + 64 * pr + 64] for o in (0, hid, 2 * hid)])
             lv.qkv_w[pr] = buf.add(mfma_a_fragments(rows))
+        # PreNorm LayerNorm folded into to_qkv (csrc/resnet1d.hip: qkv_ln_pm / qkv4_pm), to_qkv's own row order:
+        # W LN(x) = rstd (W' x - mean s),  W' = W diag(g), s = W' 1; products and sums in f64, rounded once
+        wn = (wqkv.double() * sd[q + "2.fn.norm.g"].double().reshape(1, -1)).float()
+        lv.qkvn_w = buf.add(mfma_a_fragments(wn))
+        lv.qkvn_s = buf.add(wn.double().sum(dim=1).float())
         lv.out_w = buf.add(mfma_a_fragments(sd[q + "2.fn.fn.to_out.0.weight"][:, :, 0]))
         lv.out_b = buf.add(sd[q + "2.fn.fn.to_out.0.bias"])
         lv.ln2_g = buf.add(sd[q + "2.fn.fn.to_out.1.g"])

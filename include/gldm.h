@@ -160,6 +160,10 @@ typedef struct gldm_r1d_level {
   int32_t out_w, out_b; /* to_out.0 [C x 128] packed, bias [C]                    */
   int32_t ln2_g;        /* to_out.1 LayerNorm gain [C]                            */
   int32_t down_w, down_b; /* Conv1d(C -> C', k=3) packed, bias [C']               */
+  int32_t qkvn_w;       /* ABI 4: to_qkv with the PreNorm gain folded in, W' = W diag(g), in to_qkv's own
+                           row order (q | k | v, head h at rows 32 h of each third): 384 x C packed;
+                           0 / negative = absent (the position-major engine is then not used)       */
+  int32_t qkvn_s;       /* ABI 4: row sums of W' [384] (the mean term of the folded LayerNorm)     */
 } gldm_r1d_level;
 
 typedef struct gldm_r1d_desc {
