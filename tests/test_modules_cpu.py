@@ -118,8 +118,39 @@ def test_packed_descriptor_of_denoiser(fpc_state_dict):
     d.emb_dim = 32  # not a shape of the position-major engine -> sample-major tiles: ceil(20 / 8) of 32 columns
     assert _lib.lib().gldm_r1d_workspace_bytes(ptr, 20) == 256 + 3 * 32 * 8
     d.emb_dim = 16
+    keep = d.lv[1].qkvn_w
+    d.lv[1].qkvn_w = 0  # a descriptor without the folded qkv block (ABI 3 packers) -> sample-major tiles as well
+    assert _lib.lib().gldm_r1d_workspace_bytes(ptr, 20) == 256 + 3 * 32 * 8
+    d.lv[1].qkvn_w = keep
     d.dims[1] = 200  # attention level wider than the LDS plan -> refused, not mis-run
     assert _lib.lib().gldm_r1d_workspace_bytes(ptr, 20) == -1
+
+
+def test_folded_prenorm_qkv_block_of_the_descriptor(fpc_state_dict):
+    """ABI 4: per level, to_qkv with the PreNorm LayerNorm gain folded in (W' = W diag(g), to_qkv's own row order,
+    MFMA fragment order) and its row sums s = W' 1, so that W LN(x) = rstd (W' x - mean s) (csrc/resnet1d.hip:
+    qkv_ln_pm).  Checked entry by entry against the state dict, and the identity itself against torch's LayerNorm form
+    (resnets.py:104-124)."""
+    from graspldm_amd.r1d_pack import pack_resnet1d
+    pre = "diffusion_model.model."
+    p = pack_resnet1d(fpc_state_dict, pre, groups=4, seq_len=4, num_steps=1000)
+    d, w = p["desc"], p["weights"]
+    for lv, C in enumerate([4, 32, 64, 128]):
+        q = pre + f"blocks.{lv}.2."
+        wq = fpc_state_dict[q + "fn.fn.to_qkv.weight"][:, :, 0].float()
+        g = fpc_state_dict[q + "fn.norm.g"].float().reshape(-1)
+        wn = (wq.double() * g.double().reshape(1, -1)).float()
+        kb = (C + 15) // 16
+        frag = w[d.lv[lv].qkvn_w:d.lv[lv].qkvn_w + 24 * kb * 256].view(24, kb, 64, 4)
+        for r, k in ((0, 0), (37, C - 1), (383, C // 2), (200, 1)):
+            assert frag[r // 16, k // 16, (r % 16) + 16 * (k % 4), (k % 16) // 4] == wn[r, k]
+        s = w[d.lv[lv].qkvn_s:d.lv[lv].qkvn_s + 384]
+        assert torch.allclose(s, wn.sum(dim=1), rtol=0, atol=1e-5)
+        x = torch.randn(C, 7, generator=torch.Generator().manual_seed(lv)) * 2.0 + 3.0   # columns with an offset
+        mean, var = x.mean(dim=0, keepdim=True), x.var(dim=0, unbiased=False, keepdim=True)
+        ref = wq @ ((x - mean) * (var + 1e-5).rsqrt() * g.reshape(-1, 1))
+        fold = (wn @ x - mean * s.reshape(-1, 1)) * (var + 1e-5).rsqrt()
+        assert (ref - fold).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 def test_modules_refuse_cpu_tensors():

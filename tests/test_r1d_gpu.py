@@ -254,6 +254,35 @@ def test_sample_major_fallback_engine_for_other_denoiser_shapes():
     assert torch.equal(big[-40:], small) and eng.workspace_errors() == 0
 
 
+def test_folded_layernorm_with_offset_columns_and_fallback_without_the_folded_block(engines, fpc_state_dict):
+    """The position-major engine takes the PreNorm LayerNorm inside the qkv conv (rstd (W' x - mean s), statistics
+    from a two-pass sweep of the column).  A latent far from the origin (|x| up to 30: residual streams with a large
+    common offset per column) must still agree with the oracle, and a descriptor without the folded block (qkvn_w = 0,
+    what an ABI 3 packer leaves) must run on the sample-major engine with the same result."""
+    from oracle import torch_ref as R
+    from graspldm_amd.r1d import R1dEngine
+    from graspldm_amd.r1d_pack import pack_resnet1d
+    pre = "diffusion_model.model."
+    g = torch.Generator().manual_seed(23)
+    n = 37
+    x = torch.randn(n, 1, 4, generator=g) * 10.0 + 5.0
+    z = torch.randn(n, 3, 64, generator=g)
+    t = torch.randint(0, 1000, (n,), generator=g)
+    exp = R.resnet1d_forward(fpc_state_dict, pre, x, z_cond=z, time=t)
+    dev = torch.device("cuda:0")
+    outs = []
+    for drop in (False, True):
+        packed = pack_resnet1d(fpc_state_dict, pre, groups=4, seq_len=4, num_steps=1000)
+        if drop:
+            for lv in range(4):
+                packed["desc"].lv[lv].qkvn_w = 0
+        eng = R1dEngine(packed, dev)
+        outs.append(eng.denoise(x.cuda(), eng.cond_embed(z.cuda()), 1, sample_t=t.int().cuda()))
+    scale = max(1.0, exp.abs().max().item())
+    assert _err(outs[0], exp) < 2e-5 * scale, _err(outs[0], exp)
+    assert _err(outs[1], exp) < 2e-5 * scale, _err(outs[1], exp)
+
+
 @pytest.mark.parametrize("block_channels", [(64, 128), (32, 256), (128,), (32, 64, 64)])
 def test_position_major_engine_other_widths(block_channels):
     """The 64-column engine on other width sequences of its supported set (first level 4 channels, then 32..256):
