@@ -222,7 +222,7 @@ def main():
         fsa()
         t_fsa = event_time(fsa, 10)
         sa_flop = B * 2 * Ms * Us * (131 * 128 + 128 * 128 + 128 * 256)
-        kernels.append(dict(kernel="sa_mlp_kernel (SSG SA2 fused gather + MLP 131-128-128-256 + max)", bound="mfma",
+        kernels.append(dict(kernel="sa_mlp2_kernel (SSG SA2 fused gather + MLP 131-128-128-256 + max, 128-column tiles)", bound="mfma",
                             avg_ms=t_fsa * 1e3, achieved=sa_flop / t_fsa / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
                             unit="TFLOP/s", frac=sa_flop / t_fsa / 1e12 / PEAK_F32_MFMA_TFLOPS,
                             hbm_bytes_avoided=B * 4 * (Cs + 3) * Ms * Us))

@@ -169,13 +169,31 @@ __device__ __forceinline__ void gemm_fast_pf(const Ctx &c, const float *__restri
   const int col = c.lane & 15, kq = c.lane >> 4;
   const int kblocks = TAPS * cblocks;
   const WStream wv(wp, c.lane);
+  // B-fragment addresses.  Row 4 j + kq has the parity of kq for every j, so the swizzle is the same for all four
+  // k-steps, and with nt0 even it only swaps the n-tiles of a pair: at 8 n-tiles (nt0 = 0) two lane-dependent bases
+  // (even / odd n-tile) plus compile-time offsets, which the reads carry as immediates -- not 32 registers.  (At 2 and
+  // 4 n-tiles the engine's phases measured 1 % slower this way, spill-free as they became.)
   int boff[4][NT];
+  if constexpr (NT >= 8) {
+    int bb[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+    for (int e = 0; e < 2; ++e) bb[e] = swz<NC>(kq, 16 * (nt0 + e) + col);
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) boff[j][ni] = swz<NC>(4 * j + kq, 16 * (nt0 + ni) + col);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) boff[j][ni] = bb[ni & 1] + 4 * j * NC + 16 * (ni & ~1);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) boff[j][ni] = swz<NC>(4 * j + kq, 16 * (nt0 + ni) + col);
+  }
   f32x4 a[PF][TAPS][MT];
-  float b[2][4][NT];
+  // B values: double buffered over k-blocks, except at 8 n-tiles, where a k-step's 8+ MFMAs are cover enough: the row
+  // of step j is refilled from the next block the moment step j's MFMAs have issued (three steps to arrive), in ONE
+  // set of registers (32 fewer at NT = 8).
+  constexpr bool kBS = NT >= 8 && PF > 1;
+  float b[kBS ? 1 : 2][4][NT];
   f32x4 side[TAPS > 1 ? 2 : 1][MT][NT];  // tap 0 and tap 2 partial results (tap 1 goes to acc)
   if (TAPS == 3) {
 #pragma unroll
@@ -253,10 +271,15 @@ __device__ __forceinline__ void gemm_fast_pf(const Ctx &c, const float *__restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (j < 3) load_a((u + PF - 1) % PF, acb, j);
-          if (j == 0) load_b((u + 1) & 1, bcb);
+          if (!kBS && j == 0) load_b((u + 1) & 1, bcb);
           __builtin_amdgcn_sched_barrier(0);
-          mfma_step(u, u & 1, j);
+          mfma_step(u, kBS ? 0 : (u & 1), j);
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (kBS) {
+            const lds_f *sn = src3 + bcb * 16 * NC;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) b[0][j][ni] = sn[boff[j][ni]];
+          }
         }
       }
     }
@@ -2621,6 +2644,178 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
   }
 }
 
+
+// ======================================================== fused set abstraction, 128-column tiles ==
+// sa_mlp_kernel at twice the tile: 128 columns = 128 / U centres x U neighbours per workgroup (8 waves, one workgroup
+// per CU).  Every weight fragment then serves 8 n-tiles, a layer's fill / epilogue / barrier is paid once per 128
+// columns, and the last layer's output is never stored: max over a centre's neighbours is taken on the accumulators
+// (in-lane over the centre's n-tiles, DPP over the 16 columns of a tile; ReLU after the max, it is monotone) and only
+// [cout][centres] leaves the CU.  LDS: region A [max(cin_pad0, cout1)][128] (the gathered tile, later layer 2's
+// output) + region B [cout0][128] (+ [cout2] for 4 layers).  Shapes outside this plan run on sa_mlp_kernel.
+__device__ __forceinline__ float row16_max(float x) {  // max over the 16 lanes of a DPP row
+  x = fmaxf(x, dpp_mov<0xB1>(x));   // quad_perm [1,0,3,2]
+  x = fmaxf(x, dpp_mov<0x4E>(x));   // quad_perm [2,3,0,1]
+  x = fmaxf(x, dpp_mov<0x141>(x));  // row_half_mirror
+  x = fmaxf(x, dpp_mov<0x140>(x));  // row_mirror
+  return x;
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void sa2_tiles(const Ctx &c, const SaArgs &a, int l, int mt0, int nt0, const float *src,
+                                          float *dst, bool last, int j0, float *outb) {
+  constexpr int NC = 128;
+  const int col = c.lane & 15, kq = c.lane >> 4;
+  const float *wp = a.weights + a.w_off[l], *bias = a.weights + a.b_off[l];
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 16 * (mt0 + mi) + 4 * kq);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = bv;
+  }
+  const int cblocks = a.cin_pad[l] >> 4;
+  if ((cblocks & 3) == 0) gemm_fast_pf<NC, 16, 1, MT, NT, 4>(c, wp, cblocks, mt0, nt0, src, acc);
+  else gemm_fast_pf<NC, 16, 1, MT, NT, 2>(c, wp, cblocks, mt0, nt0, src, acc);  // the launcher checked: even
+  if (!last) {
+    lds_f *d3 = (lds_f *)dst;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          d3[swz<NC>(16 * (mt0 + mi) + 4 * kq + r, 16 * (nt0 + ni) + col)] = fmaxf(acc[mi][ni][r], 0.f);
+    return;
+  }
+  // max over each centre's U columns: tpc = U / 16 n-tiles per centre (1, 2 or 4; NT is a multiple of it)
+  const int tpc = a.u >> 4;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float m[NT];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) m[ni] = acc[mi][ni][r];
+      if (tpc >= 2) {
+#pragma unroll
+        for (int ni = 0; ni < NT; ni += 2) m[ni] = fmaxf(m[ni], m[ni + 1 < NT ? ni + 1 : ni]);
+      }
+      if (tpc >= 4) {
+#pragma unroll
+        for (int ni = 0; ni < NT; ni += 4) m[ni] = fmaxf(m[ni], m[ni + 2 < NT ? ni + 2 : ni]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        if (ni % tpc) continue;  // wave uniform
+        const float v = fmaxf(row16_max(m[ni]), 0.f);
+        const int jj = (nt0 + ni) / tpc;  // centre of the tile
+        if (col == 0 && j0 + jj < a.m) outb[(size_t)(16 * (mt0 + mi) + 4 * kq + r) * a.m + j0 + jj] = v;
+      }
+    }
+}
+
+// The gather of tile t + 1 is requested in front of tile t's last layer and stored after it: its scattered round
+// trips (12 k cycles exposed per tile before) run under the longest GEMM of the tile.  Everything about it is
+// UNCONDITIONAL -- clamped tile index, clamped addresses, the store of a last redundant tile -- because a load behind a
+// branch, or one whose only consumer is behind a branch, is waited for on the spot.  (The in-order vmcnt makes the
+// layer's first weight fragment wait for the gather's loads: a few hundred cycles once per tile, measured.)
+constexpr int kSaFly = 32;  // feature rows per thread in flight: 4 row quarters x 32 = 128 feature channels
+
+struct SaTile {
+  const float *pts, *ctr, *feat;
+  int id, jj, j0;
+  bool live;
+};
+
+__device__ __forceinline__ SaTile sa2_tile(const SaArgs &a, int t, int tiles_per_cloud, int cpt, int col) {
+  const int b = t / tiles_per_cloud, tile = t - b * tiles_per_cloud;
+  SaTile s;
+  s.j0 = tile * cpt;
+  s.jj = col / a.u;
+  s.live = s.j0 + s.jj < a.m;
+  s.pts = a.points + (size_t)b * 3 * a.n;
+  s.ctr = a.centers + (size_t)b * 3 * a.m;
+  s.feat = a.feat ? a.feat + (size_t)b * a.c * a.n : a.points;
+  const int32_t *idx = a.idx + ((size_t)b * a.m + s.j0) * a.u;
+  s.id = idx[s.live ? col : 0];
+  s.id = s.live ? s.id : 0;
+  return s;
+}
+
+__device__ __forceinline__ void sa2_gather_load(const SaArgs &a, const SaTile &s, int rq, float &xyz, float (&v)[kSaFly]) {
+  const int r3 = rq < 3 ? rq : 0;
+  xyz = s.pts[r3 * a.n + s.id] - s.ctr[r3 * a.m + (s.live ? s.j0 + s.jj : 0)];
+  const int cmax = a.c > 0 ? a.c - 1 : 0;
+#pragma unroll
+  for (int q = 0; q < kSaFly; ++q) {
+    const int f = rq + 4 * q;
+    v[q] = s.feat[(size_t)(f < cmax ? f : cmax) * a.n + s.id];
+  }
+}
+
+__device__ __forceinline__ void sa2_gather_store(const SaArgs &a, const SaTile &s, int rq, int col, float xyz,
+                                                 const float (&v)[kSaFly], float *A) {
+  constexpr int NC = 128;
+  lds_f *A3 = (lds_f *)A;
+  const int rows = a.cin_pad[0];
+  if (rq < 3) A3[swz<NC>(rq, col)] = s.live ? xyz : 0.f;
+#pragma unroll
+  for (int q = 0; q < kSaFly; ++q) {
+    const int f = rq + 4 * q;
+    if (3 + f < rows) A3[swz<NC>(3 + f, col)] = (s.live && f < a.c) ? v[q] : 0.f;
+  }
+  for (int r = 3 + 4 * kSaFly + rq; r < rows; r += 4) A3[swz<NC>(r, col)] = 0.f;  // zero pad beyond 131 rows
+}
+
+__global__ __launch_bounds__(512, 1) void sa_mlp2_kernel(const SaArgs a, int rows_a, int tiles_per_cloud, int total_tiles) {
+  constexpr int NC = 128;
+  extern __shared__ float lds[];
+  Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
+        0, 8};
+  const int cpt = NC / a.u;  // centres per tile
+  float *A = lds, *B = lds + (size_t)rows_a * NC;
+  const int w = c.wave, col = c.tid & (NC - 1), rq = c.tid >> 7;
+  auto layer = [&](int l, const float *src, float *dst, int j0, float *outb) {
+    const bool last = l == a.n_layers - 1;
+    const int mtiles = a.cout[l] >> 4;
+    // the lane ids are laundered per call: otherwise every variant's lane-derived LDS offsets are hoisted out of the
+    // tile loop as invariants and live (spilled) across the whole kernel
+    Ctx cl = c;
+    asm volatile("" : "+v"(cl.tid), "+v"(cl.lane));
+    if (mtiles >= 8) {  // one m-tile x all 8 n-tiles per pass: every weight fragment serves 128 columns
+      for (int p = 0; p < (mtiles >> 3); ++p) sa2_tiles<1, 8>(cl, a, l, w + 8 * p, 0, src, dst, last, j0, outb);
+    } else if (mtiles == 4) sa2_tiles<1, 4>(cl, a, l, w & 3, 4 * (w >> 2), src, dst, last, j0, outb);
+    else sa2_tiles<1, 2>(cl, a, l, w & 1, 2 * (w >> 1), src, dst, last, j0, outb);
+  };
+  // persistent workgroups (a tile is 45 us of work and a workgroup launch several)
+  int t = blockIdx.x;
+  {
+    const SaTile s = sa2_tile(a, t, tiles_per_cloud, cpt, col);
+    float xyz, v[kSaFly];
+    sa2_gather_load(a, s, rq, xyz, v);
+    sa2_gather_store(a, s, rq, col, xyz, v, A);
+  }
+  __syncthreads();
+  for (; t < total_tiles; t += gridDim.x) {
+    const int b = t / tiles_per_cloud, j0 = (t - b * tiles_per_cloud) * cpt;
+    float *outb = a.out + (size_t)b * a.cout[a.n_layers - 1] * a.m;
+    float *src = A, *dst = B;
+    for (int l = 0; l + 1 < a.n_layers; ++l) {
+      layer(l, src, dst, j0, outb);
+      __syncthreads();
+      float *tsw = src; src = dst; dst = tsw;
+    }
+    const int tn = t + (int)gridDim.x < total_tiles ? t + (int)gridDim.x : t;
+    const SaTile s = sa2_tile(a, tn, tiles_per_cloud, cpt, col);
+    float xyz, v[kSaFly];
+    sa2_gather_load(a, s, rq, xyz, v);
+    layer(a.n_layers - 1, src, dst, j0, outb);
+    __syncthreads();  // the last layer may have been reading region A
+    sa2_gather_store(a, s, rq, col, xyz, v, A);
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 GLDM_API int gldm_r1d_cond_embed(const float *z_cond, const float *w, const float *b, int n_cond, int rows, int dc,
@@ -2762,6 +2957,36 @@ GLDM_API int gldm_sa_mlp_forward(const float *points, const float *centers, cons
     a.cin_pad[l] = cin_pad[l]; a.cout[l] = cout[l]; a.w_off[l] = w_off[l]; a.b_off[l] = b_off[l];
   }
   if (cin_pad[0] < 3 + c) return GLDM_ERR_INVALID_ARG;
+  {  // 128-column tiles when the layer plan fits: widths 32 / 64 / 128 / 256 k, U a multiple of 16, both regions in LDS
+    bool ok = (u == 16 || u == 32 || u == 64) && n_layers >= 1 && c <= 4 * kSaFly;
+    int rows_a = cin_pad[0], rows_b = 0;
+    for (int l = 0; l < n_layers && ok; ++l) {
+      const int mt = cout[l] >> 4;
+      ok = (mt == 2 || mt == 4 || (mt >= 8 && (mt & 7) == 0)) && (cin_pad[l] & 31) == 0;
+      if (l + 1 < n_layers) {  // stored outputs: even layers -> B, odd layers -> A
+        if (l & 1) rows_a = rows_a > cout[l] ? rows_a : cout[l];
+        else rows_b = rows_b > cout[l] ? rows_b : cout[l];
+      } else if (ok) {  // the max runs on one wave's n-tiles: a centre's U / 16 tiles must not straddle two waves
+        const int nt = mt >= 8 ? 8 : (mt == 4 ? 4 : 2);
+        ok = (u >> 4) <= nt;
+      }
+    }
+    const size_t lds2 = (size_t)(rows_a + rows_b) * 128 * sizeof(float);
+    static const bool tile64 = getenv("GLDM_SA_TILE64") != nullptr;  // diagnostic: force the 64-column kernel
+    if (ok && lds2 <= 160 * 1024 && !tile64) {
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp2_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr2 = true;
+      }
+      const int cpt2 = 128 / u, tpc = (m + cpt2 - 1) / cpt2, total = tpc * b;
+      const int grid = total < cu_count() ? total : cu_count();
+      hipLaunchKernelGGL(sa_mlp2_kernel, dim3(grid), dim3(512), lds2, reinterpret_cast<hipStream_t>(stream), a, rows_a,
+                         tpc, total);
+      return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+    }
+  }
   const size_t lds_bytes = (size_t)(Geo<64>::kBufH + kMaxC * 64) * sizeof(float);
   static bool attr = false;
   if (!attr) {

@@ -26,7 +26,7 @@ def fusable(shared_mlp, num_neighbors):
         cout = layers[3 * i].weight.shape[0]
         if cout % 16 or cout > 256 or (cout // 16) not in _OK_MTILES:
             return False
-    return layers[0].weight.shape[1] <= 256
+    return (layers[0].weight.shape[1] + 31) // 32 * 32 <= 256
 
 
 class SaMlpPlan:
@@ -39,7 +39,9 @@ class SaMlpPlan:
         cin_pad, cout, w_off, b_off = [], [], [], []
         for i in range(n):
             w, b = fold_conv_bn(layers[3 * i], layers[3 * i + 1])
-            kpad = (w.shape[1] + 15) // 16 * 16
+            # K in pairs of 16-deep blocks: the kernels' weight-fragment pipeline runs two blocks per trip (an odd count
+            # would fall back to load-wait-compute per block); the padding rows are zero in the weights and the tile
+            kpad = (w.shape[1] + 31) // 32 * 32 if i == 0 else (w.shape[1] + 15) // 16 * 16  # later layers: cin = cout of the previous one
             wp = torch.zeros(w.shape[0], kpad)
             wp[:, : w.shape[1]] = w.cpu()
             cin_pad.append(kpad)
