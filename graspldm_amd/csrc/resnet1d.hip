@@ -717,7 +717,10 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
                   sc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_sc[p][mi][j], gb[j], sc, 0, 0, 0);
                   sh = __builtin_amdgcn_mfma_f32_16x16x4f32(a_sh[p][mi][j], gb[j], sh, 0, 0, 0);
                 }
-                for (int kb = 1; kb < ekb; ++kb) {  // wide embeddings (the pose decoder: E = 64)
+                // (E = 64, the pose decoder: 32 of these per m-tile and sample, 17 % on top of a 256-wide conv's own
+                // MFMAs -- a 16-column n-tile is ONE sample there, so 15 of its 16 columns repeat the first.  Requesting
+                // the kb >= 1 fragments together instead of one round trip each changed nothing: it is MFMA time.)
+                for (int kb = 1; kb < ekb; ++kb) {  // wide embeddings
                   const f32x4 a2 = wss[((size_t)mt * ekb + kb) * 64], a3 = wss[((size_t)((g.C >> 4) + mt) * ekb + kb) * 64];
 #pragma unroll
                   for (int j = 0; j < 4; ++j) {
@@ -2446,7 +2449,10 @@ Plan make_plan(int n_samples, int n_steps, int L, int nc, bool allow_chain = tru
 
 template <int NC, int L>
 int launch_one(const RunArgs &a, int tiles, hipStream_t s) {
-  const size_t lds_bytes = (size_t)Geo<NC>::kLdsFloats * sizeof(float);
+  size_t lds_bytes = (size_t)Geo<NC>::kLdsFloats * sizeof(float);
+#ifdef GLDM_DEBUG_KNOBS
+  if (getenv("GLDM_R1D_ONE_WG") && lds_bytes < 100 * 1024) lds_bytes = 100 * 1024;  // one workgroup per CU: phases on their own
+#endif
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&r1d_kernel<NC, L>),
