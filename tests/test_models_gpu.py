@@ -160,10 +160,14 @@ def test_ddpm_sampler_runs_and_is_seed_reproducible(ldm):
 
 
 @pytest.mark.parametrize("b,c,n,m,u,chans", [(2, 128, 512, 128, 64, (128, 128, 256)), (3, 0, 1024, 512, 64, (64, 64, 128)),
-                                             (2, 32, 1024, 1024, 32, (32, 64)), (1, 5, 300, 37, 16, (16, 32, 32, 64))])
+                                             (2, 32, 1024, 1024, 32, (32, 64)), (1, 5, 300, 37, 16, (16, 32, 32, 64)),
+                                             (2, 64, 256, 37, 32, (64, 128)), (300, 16, 128, 5, 16, (32, 64, 128, 256)),
+                                             (1, 160, 200, 9, 64, (128, 128))])
 def test_fused_sa_mlp_equals_unfused_oracle(b, c, n, m, u, chans):
     """gldm_sa_mlp_forward (gather + grouped MLP + max, fused) vs the oracle's
-    ball_group -> shared_mlp -> max on the same weights; includes ragged tiles (m*u % 64 != 0)."""
+    ball_group -> shared_mlp -> max on the same weights.  Cases 1-3, 5, 6 run on the 128-column kernel (sa_mlp2_kernel:
+    2 / 4 / 8 centres per tile, ragged last tiles, more tiles than persistent workgroups, 4 layers), cases 4 and 7 on
+    the 64-column one (a 16-row layer; more feature channels than the gather prefetch holds)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from graspldm_amd.pvcnn import PointNetSAModule
