@@ -15,6 +15,8 @@
 // no extra pass over the tensor for its statistics (combined in f64, fixed order).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "gldm.h"
 #include "wstream.h"
@@ -25,6 +27,26 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) float lds_f;
+
+#ifdef GLDM_DEBUG_KNOBS
+__device__ long long g_c3_stamp[32];
+#define GLDM_C3_STAMP(i) \
+  do { if (blockIdx.x == 5 && blockIdx.y == (gridDim.y >> 1) && threadIdx.x == 0) g_c3_stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define GLDM_C3_STAMP(i) do {} while (0)
+#endif
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float x) {  // every lane of a 16-lane DPP row ends with the row's sum
+  x += dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp_mov<0x141>(x);  // row_half_mirror
+  x += dpp_mov<0x140>(x);  // row_mirror
+  return x;
+}
 
 constexpr int kConvThreads = 256;
 constexpr int kBrick = 4;  // brick is kBrick x kBrick x r output voxels
@@ -41,9 +63,16 @@ template <int MT, int NTW, int JN>
 __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float *__restrict__ x,
                                                                     const float *__restrict__ wp,
                                                                     const float *__restrict__ bias, int cin, int cout,
-                                                                    int r, float *__restrict__ y,
+                                                                    int r_arg, float *__restrict__ y,
                                                                     float *__restrict__ partial) {
+  constexpr int r = 4 * NTW;  // the instantiation fixes the resolution: every division below is by a constant (with a
+  (void)r_arg;                // run-time r the index maps of a workgroup cost 8 k cycles before its first load)
   extern __shared__ float lds[];
+  // Everything outside the tap loops (index maps, staging, barriers, epilogue) is short latency-bound work that shares
+  // its SIMD with the other workgroups' MFMA streams: it gets issue priority (the streams need one slot per 32 cycles
+  // and lose nothing); measured on the 48 -> 96 conv at 12^3, its epilogue took 70 k cycles without.
+  __builtin_amdgcn_s_setprio(3);
+  GLDM_C3_STAMP(0);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 15, kq = lane >> 4;
   const int bpr = r / kBrick;                       // bricks per axis
@@ -118,14 +147,19 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
   };
   constexpr bool kLate = SQ <= 2;
   constexpr bool kPipe = SQ <= 4;  // 64 staged registers beside the accumulators; wider bricks (r = 32) stage in place
+  GLDM_C3_STAMP(1);
   if (kPipe) stage_load(0);
+  GLDM_C3_STAMP(2);
   for (int cb = 0; cb < cblocks; ++cb) {
     __syncthreads();  // previous block's reads are done
+    if (cb < 3) GLDM_C3_STAMP(3 + 4 * cb);
     if (!kPipe) stage_load(cb);
     stage_store();
+    if (cb < 3) GLDM_C3_STAMP(4 + 4 * cb);
     if (kPipe && !kLate && cb + 1 < cblocks) stage_load(cb + 1);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    if (cb < 3) GLDM_C3_STAMP(5 + 4 * cb);
     // ---- 27 taps x JN k-steps of MFMA; weights one tap ahead, B fragments (LDS) one k-step ahead
     f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
@@ -133,10 +167,14 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
     float bf[NTW], bn[NTW];
 #pragma unroll
     for (int ni = 0; ni < NTW; ++ni) bf[ni] = l3[obase[ni]];  // tap 0, k-step 0
+    __builtin_amdgcn_s_setprio(0);
     for (int tap = 0; tap < 27; ++tap) {
       // vmcnt is in order: staged loads requested before the weight loads make the first fragment wait for them.
       // Small bricks (r = 12: 32 loads per thread) are requested behind the LAST weight load of the block instead, with
       // only the last taps' MFMAs in front (8-9 % faster there; for r = 24, 64 loads inside the tap loop, 14 % slower).
+#ifdef GLDM_DEBUG_KNOBS
+      if (cb < 2 && (tap == 1 || tap == 2 || tap == 14)) GLDM_C3_STAMP(14 + 3 * cb + (tap == 1 ? 0 : (tap == 2 ? 1 : 2)));
+#endif
       if (kLate && tap == 25 && cb + 1 < cblocks) stage_load(cb + 1);
       const int tn = tap + 1 < 27 ? tap + 1 : tap;
 #ifndef GLDM_C3_NO_A
@@ -169,9 +207,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) a_cur[mi] = a_nxt[mi];
     }
+    __builtin_amdgcn_s_setprio(3);
+    if (cb < 3) GLDM_C3_STAMP(6 + 4 * cb);
   }
-  // ---- epilogue: store + per-channel partial statistics of this brick
+  // ---- epilogue: per-channel partial statistics of this brick, then the stores.  The stores come LAST: a barrier
+  // behind them waits for every one of them to be written (vmcnt(0): 70 k cycles per workgroup at r = 12).
   __syncthreads();
+  GLDM_C3_STAMP(20);
   float *s_part = lds;  // [4 waves][MT*16][2]
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
@@ -179,27 +221,23 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
     for (int q = 0; q < 4; ++q) {
       const int co = 16 * mi + 4 * kq + q;
       float s = 0.f, s2 = 0.f;
-      if (co < cout) {
 #pragma unroll
-        for (int ni = 0; ni < NTW; ++ni) {
-          const float v = acc[mi][ni][q];
-          y[(size_t)co * r3 + gvox[ni]] = v;
-          s += v;
-          s2 += v * v;
-        }
+      for (int ni = 0; ni < NTW; ++ni) {
+        const float v = acc[mi][ni][q];
+        s += v;
+        s2 += v * v;
       }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {
-        s += __shfl_xor(s, off, 64);
-        s2 += __shfl_xor(s2, off, 64);
-      }
+      s = row16_sum(s);   // over the 16 columns of the tile: DPP (a __shfl_xor is an LDS round trip, 8 per row here)
+      s2 = row16_sum(s2);
       if (col == 0 && co < cout) {
         s_part[(wave * MT * 16 + co) * 2] = s;
         s_part[(wave * MT * 16 + co) * 2 + 1] = s2;
       }
     }
   }
+  GLDM_C3_STAMP(24);
   __syncthreads();
+  GLDM_C3_STAMP(25);
   if (tid < cout) {
     float s = 0.f, s2 = 0.f;
     for (int w = 0; w < 4; ++w) {
@@ -210,6 +248,22 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
     p[0] = s;
     p[1] = s2;
   }
+  GLDM_C3_STAMP(26);
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = 16 * mi + 4 * kq + q;
+      if (co < cout) {
+#pragma unroll
+#ifndef GLDM_C3_NO_STORE
+        for (int ni = 0; ni < NTW; ++ni) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
+#else
+        for (int ni = 0; ni < NTW; ++ni) if (acc[mi][ni][q] == 1.2345f) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
+#endif
+      }
+    }
+  GLDM_C3_STAMP(21);
 }
 
 // GroupNorm(groups) + Swish over [B, C, r^3]; statistics from the conv's per-brick partials.
@@ -385,6 +439,27 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
   const int mt = (cout + 15) / 16, ntw = r / 4;
   if (r % 4 || (size_t)16 * brick_row_stride(r) * 4 > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
 
+#ifdef GLDM_DEBUG_KNOBS
+  struct StampDump {  // diagnostic builds: GLDM_C3_STAMP=1 prints the phase clocks of one mid-grid workgroup per call
+    hipStream_t s; int cin, cout, r;
+    ~StampDump() {
+      if (!getenv("GLDM_C3_STAMP")) return;
+      long long h[32];
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_c3_stamp), sizeof(h));
+      printf("conv3d %d->%d @%d: setup %lld, stage0 issue %lld", cin, cout, r, h[1] - h[0], h[2] - h[1]);
+      for (int cb = 0; cb < (cin + 15) / 16 && cb < 3; ++cb)
+        printf(" | cb%d: wait %lld store %lld barrier %lld taps %lld", cb, h[3 + 4 * cb] - (cb ? h[2 + 4 * cb] : h[2]),
+               h[4 + 4 * cb] - h[3 + 4 * cb], h[5 + 4 * cb] - h[4 + 4 * cb], h[6 + 4 * cb] - h[5 + 4 * cb]);
+      printf(" | epilogue %lld (stats %lld, barrier %lld, partials %lld, stores %lld), total %lld", h[21] - h[20], h[24] - h[20],
+             h[25] - h[24], h[26] - h[25], h[21] - h[26], h[21] - h[0]);
+      for (int cb = 0; cb < 2; ++cb)
+        printf(" | cb%d taps: first %lld, second %lld, 2..13 %lld", cb, h[14 + 3 * cb] - h[5 + 4 * cb],
+               h[15 + 3 * cb] - h[14 + 3 * cb], h[16 + 3 * cb] - h[15 + 3 * cb]);
+      printf("\n");
+    }
+  } dump{s, cin, cout, r};
+#endif
 #define GLDM_CONV_CASE(M, N) \
   if (mt == M && ntw == N) return launch_conv<M, N>(x, w_packed, bias, b, cin, cout, r, y, partial, s)
   GLDM_CONV_CASE(3, 6);   // 48 ch @ 24^3  (shipped fpc/ppc PVCNN encoder)
