@@ -137,6 +137,9 @@ struct Ctx {
   int tid, wave, lane;
   int skip;         // diagnostic phase-skip mask (GLDM_R1D_SKIP), 0 in production
   int nta;          // live 16-column n-tiles of this workgroup (kNT = full tile, 1 = tail tile)
+  // scale / shift rows precomputed per conditioning cloud (pose decoder: ss_table_kernel), for the tile's samples 0 and
+  // 1 (16-position engine: a 16-column n-tile is one sample), or null: computed in the epilogue
+  const float *ss_row[2] = {nullptr, nullptr};
 };
 
 // ---------------------------------------------------------------- GEMM ----
@@ -551,6 +554,7 @@ struct GnEpilogue {
   int ss_w, ss_b, E;   // packed [2C x E] scale/shift Linear (A fragments) + combined bias, or ss_w < 0
   int C, cpg;          // channels, channels per group (1, 4, 8, 16 or the rows of a wave)
   float *res;          // residual stream (mode 2)
+  int tab_off = 0;     // this ResnetBlock's rows in the per-cloud scale/shift table (Ctx::ss_row)
 };
 
 // One wave's share of a GEMM: PASSES x MT m-tiles by NT n-tiles, one k-sweep per pass.  Passes keep
@@ -710,7 +714,14 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
             const int mt = mt0 + p * MT + mi;
             const int row0 = 16 * mt + 4 * kq;
             f32x4 sc = sc0[p][mi], sh = sh0[p][mi];
-            if (has_ss) {
+            const float *tab = L == 16 ? c.ss_row[(nt0 + ni) & 1] : nullptr;  // wave uniform
+            if (has_ss && wide && tab) {
+              // The pose decoder's embedding does not depend on the grasp: the rows were computed once per cloud
+              // (ss_table_kernel).  In here they cost 32 MFMAs per m-tile and SAMPLE (E = 64), 17 % on top of a
+              // 256-wide conv's own, 15 of every n-tile's 16 columns repeating the first.
+              sc = *reinterpret_cast<const f32x4 *>(tab + g.tab_off + row0);
+              sh = *reinterpret_cast<const f32x4 *>(tab + g.tab_off + g.C + row0);
+            } else if (has_ss) {
               if (wide) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1753,7 +1764,9 @@ struct RunArgs {
   const float *step_noise;
   float *out0;            // denoise: x_out [n][L]; decode: tmrp [n][6]
   float *out1;            // decode: logit [n]
-  float *ws;              // unused (ABI)
+  float *ws;              // workspace: chain header + hand-off granules (+ the decoder's scale/shift table)
+  const float *ss_tab;    // [n_cond][ss_stride] scale/shift rows of every ResnetBlock per conditioning cloud, or null
+  int ss_stride;
   int skip;               // diagnostic phase-skip mask (GLDM_R1D_SKIP env; 0 in production)
   // Work distribution (make_plan): `slots` persistent workgroups; slot p owns tiles p, p + slots, ... (`rounds` of
   // them) for all steps; each of the `left_tiles` tiles beyond the whole rounds is cut into `chain` step segments of
@@ -1769,8 +1782,9 @@ struct RunArgs {
 // inside the step loop, so every phase body exists once, inlined, with registers allocated across the
 // whole kernel: no calls, no callee-save traffic and no spilled kernel state between phases.
 enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKV4 = 5, OP_OUTLN = 6, OP_QKVLN = 7 };
-// conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9
+// conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9 | (scale/shift table offset / 4) << 12
 constexpr int kFlagAlias = 1 << 8;
+constexpr int kFlagTabShift = 12;
 
 // ResnetBlock of a 4-channel level with 4-position samples (the first level of the latent denoiser) on the
 // VALU of ONE wave, in registers: as two MFMA ops it is two padded 16x16 tiles and two long epilogues for
@@ -1898,13 +1912,17 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
     o[8] = a8; o[9] = a9; o[10] = a10; o[11] = a11;
   };
   constexpr int X = GG::kBufX, H = GG::kBufH, Y = GG::kBufY, O = GG::kBufO, QKV = GG::kBufQKV;
+  int tab_off = 0;  // rows [2C] of every ResnetBlock, in block order (ss_table_kernel writes the same layout)
   auto resblock = [&](const gldm_r1d_resblock &rb, int C, bool last_of_pair) {
+    const int toff = tab_off;
+    tab_off += 2 * C;
     if (C == 4 && d.seq_len == 4) {  // one-wave VALU form; the barrier comes after the second block
       emit(OP_RES4, rb.c1_w, rb.c1_b, rb.n1_w, rb.n1_b, rb.c2_w, rb.c2_b, rb.n2_w, rb.n2_b, rb.ss_w, rb.ss_b,
            last_of_pair ? 1 : 0);
       return;
     }
-    emit(OP_CONV, rb.c1_w, rb.c1_b, X, H, C, C, 3 | (1 << 9), rb.n1_w, rb.n1_b, rb.ss_w, rb.ss_b);
+    emit(OP_CONV, rb.c1_w, rb.c1_b, X, H, C, C, 3 | (1 << 9) | ((toff >> 2) << kFlagTabShift), rb.n1_w, rb.n1_b, rb.ss_w,
+         rb.ss_b);
     emit(OP_CONV, rb.c2_w, rb.c2_b, H, X, C, C, 3 | (2 << 9), rb.n2_w, rb.n2_b, -1, 0);  // X += act(GN(conv(H)))
   };
   // constant indices only: a dynamically indexed kernel argument is copied to scratch memory
@@ -1971,7 +1989,8 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
     switch (o[0]) {
       case OP_CONV: {
         const int mode = GLDM_SKIP(c, 1) ? 0 : (o[7] >> 9) & 3;
-        const GnEpilogue g{mode, o[8], o[9], GLDM_SKIP(c, 16) ? -1 : o[10], o[11], E, o[6], o[6] / 4, c.lds + o[4]};
+        const GnEpilogue g{mode, o[8], o[9], GLDM_SKIP(c, 16) ? -1 : o[10], o[11], E, o[6], o[6] / 4, c.lds + o[4],
+                           (o[7] >> kFlagTabShift) << 2};
         conv_gemm<NC, L>(c, o[1], o[2], c.lds + o[3], o[5], o[7] & 255, c.lds + o[4], o[6], (o[7] & kFlagAlias) != 0, 0, g);
         break;
       }
@@ -2120,6 +2139,13 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   const int samp0 = tile * S;
   const int nsamp = min(S, a.n_samples - samp0);  // samples this tile holds (the batch's last tile may be short)
   c.nta = (nsamp * L <= 16) ? 1 : GG::kNT;
+  if (L == 16 && a.ss_tab) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int gi = min(samp0 + min(q, nsamp - 1), a.n_samples - 1);
+      c.ss_row[q] = a.ss_tab + (size_t)(gi / a.samples_per_cond) * a.ss_stride;
+    }
+  }
   // ---- latent row for this tile: from the input (first step) or from the slot that ran the steps before s0
   if (c.tid < NC) {
     const int s = samp_of(c.tid), l = pos_of(c.tid);
@@ -2386,6 +2412,15 @@ int validate(const gldm_r1d_desc *d) {
     if (i < d->n_levels && C > 128) return GLDM_ERR_UNSUPPORTED;  // attention levels keep 4 regions in LDS
   }
   return GLDM_OK;
+}
+
+// Rows of the per-cloud scale/shift table (ss_table_kernel) when the engine uses one: the 16-position pose decoder
+// (no time embedding, wide embedding: E >= 32).  0 = no table.
+int ss_table_rows(const gldm_r1d_desc *d) {
+  if (d->seq_len != 16 || d->latent_dim <= 0 || d->emb_dim < 32 || d->emb_dim > 256 || d->dims[0] < 16) return 0;
+  int rows = 0;
+  for (int i = 0; i < 2 * d->n_levels + 1; ++i) rows += 2 * d->dims[i < 2 * d->n_levels ? i / 2 : d->n_levels];
+  return rows;
 }
 
 // The position-major 64-column engine (r1d_kernel<64, 4>) serves the latent denoiser of the shipped
@@ -2822,6 +2857,42 @@ __global__ __launch_bounds__(512, 1) void sa_mlp2_kernel(const SaArgs a, int row
   }
 }
 
+
+// Scale / shift rows of every ResnetBlock for one conditioning cloud (ResnetBlock.mlp, resnets.py:125-151, when the
+// embedding has no time part: the pose decoder):  ss[rb][row] = comb_b[row] + sum_e W[row][e] G[e],  G = sum over the
+// cond rows of SiLU(cemb) -- the value the conv epilogue would compute with MFMAs for every sample and column.
+// Table layout per cloud: blocks in tape order, [scale rows (C) | shift rows (C)] each (build_tape's tab_off).
+__global__ __launch_bounds__(256) void ss_table_kernel(const gldm_r1d_desc d, const float *__restrict__ w,
+                                                       const float *__restrict__ cemb, int stride,
+                                                       float *__restrict__ tab) {
+  __shared__ float G[256];
+  const int cond = blockIdx.x, E = d.emb_dim, R = d.cond_rows, ekb = E >> 4;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float g = 0.f;
+    for (int r = 0; r < R; ++r) g += silu(cemb[((size_t)cond * R + r) * E + e]);
+    G[e] = g;
+  }
+  __syncthreads();
+  float *out = tab + (size_t)cond * stride;
+  int off = 0;
+  const int n_rb = 2 * d.n_levels + 1;
+  for (int i = 0; i < n_rb; ++i) {
+    const int C = d.dims[i < 2 * d.n_levels ? i / 2 : d.n_levels];
+    const gldm_r1d_resblock &rb = d.rb[i];
+    for (int row = threadIdx.x; row < 2 * C; row += blockDim.x) {
+      // packed A fragments of the [2C x E] Linear: W[row][e] at ((mt * ekb + kb) * 64 + 16 kq + i) * 4 + j,
+      // row = 16 mt + i, e = 16 kb + 4 j + kq
+      const float *wr = w + rb.ss_w + (size_t)(row >> 4) * ekb * 256 + (row & 15) * 4;
+      float acc = w[rb.ss_b + row];
+      for (int kb = 0; kb < ekb; ++kb)
+        for (int j = 0; j < 4; ++j)
+          for (int kq = 0; kq < 4; ++kq) acc = fmaf(wr[kb * 256 + kq * 64 + j], G[16 * kb + 4 * j + kq], acc);
+      out[off + row] = acc;
+    }
+    off += 2 * C;
+  }
+}
+
 }  // namespace
 
 GLDM_API int gldm_r1d_cond_embed(const float *z_cond, const float *w, const float *b, int n_cond, int rows, int dc,
@@ -2839,7 +2910,9 @@ GLDM_API long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_sam
   const int nc = pm_supported(desc) ? 64 : engine_nc();
   const int S = nc / desc->seq_len;
   const long long tiles = (n_samples + S - 1) / S;
-  return kChainHdrBytes + tiles * nc * 8;
+  long long bytes = kChainHdrBytes + tiles * nc * 8;
+  if (ss_table_rows(desc) > 0) bytes = ((bytes + 255) & ~255LL) + (long long)n_samples * ss_table_rows(desc) * 4;
+  return bytes;
 }
 
 GLDM_API int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,
@@ -2877,6 +2950,19 @@ GLDM_API int gldm_decode(const gldm_r1d_desc *desc, const float *weights, const 
   a.weights = weights; a.temb = nullptr; a.cemb = cemb; a.samples_per_cond = samples_per_cond;
   a.x_in = z_h; a.n_samples = n_samples; a.n_steps = 1; a.sched_kind = GLDM_SCHED_NONE;
   a.out0 = tmrp; a.out1 = logit; a.ws = reinterpret_cast<float *>(workspace);
+  const int rows = ss_table_rows(desc);
+  if (rows > 0) {  // the table lives behind the hand-off granules of the workspace (gldm_r1d_workspace_bytes)
+    const int nc = engine_nc(), S = nc / desc->seq_len;
+    const long long tiles = (n_samples + S - 1) / S;
+    const long long off = ((kChainHdrBytes + tiles * nc * 8) + 255) & ~255LL;
+    float *tab = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + off);
+    const int n_cond = (n_samples + samples_per_cond - 1) / samples_per_cond;
+    hipLaunchKernelGGL(ss_table_kernel, dim3(n_cond), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *desc, weights,
+                       cemb, rows, tab);
+    if (hipGetLastError() != hipSuccess) return GLDM_ERR_LAUNCH;
+    a.ss_tab = tab;
+    a.ss_stride = rows;
+  }
   return launch_r1d(a, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -209,7 +209,10 @@ int gldm_r1d_cond_embed(const float *z_cond /*[n_cond,R,Dc]*/, const float *w /*
  * with attention, emb_dim % 16 == 0).  A step stays on chip; the workspace carries only the
  * work-distribution header (GLDM_R1D_WS_*: 256 bytes) and one 8-byte {latent value, tag} hand-off
  * granule per activation column, used when a batch does not fill whole rounds of workgroups and the
- * left-over tiles are split along the step axis over several workgroups.
+ * left-over tiles are split along the step axis over several workgroups.  For a pose-decoder descriptor
+ * (seq_len 16, latent_dim > 0, emb_dim >= 32) it also holds, behind those, the ResnetBlocks' scale/shift
+ * rows per conditioning cloud (4 bytes x n_samples x sum of 2 C over the blocks: sized for one grasp per
+ * cloud), written by gldm_decode itself before the fused launch.
  * Contract: the caller ZEROES the workspace once, when it allocates it; a workspace is used by one
  * launch at a time (launches on the same stream may share it, concurrent streams may not); the
  * library re-arms it at the end of every launch.  The 32-bit word at byte GLDM_R1D_WS_ERROR is set

@@ -126,6 +126,28 @@ def test_packed_descriptor_of_denoiser(fpc_state_dict):
     assert _lib.lib().gldm_r1d_workspace_bytes(ptr, 20) == -1
 
 
+def test_decoder_workspace_holds_the_scale_shift_table():
+    """gldm_r1d_workspace_bytes of the pose decoder: header + hand-off granules (2 samples per 32-column tile), rounded
+    to 256 bytes, + one row set per sample (upper bound of one grasp per cloud) of 2 C floats per ResnetBlock."""
+    import ctypes
+    from graspldm_amd import _lib
+    from graspldm_amd.pipeline import build_fpc_ldm
+    from graspldm_amd.r1d_pack import pack_resnet1d
+    dec = build_fpc_ldm(device=None).vae_model.decoder
+    sd = {k: v.detach().float().cpu() for k, v in dec.state_dict().items()}
+    packed = pack_resnet1d(sd, "net.", groups=dec.net.groups, seq_len=dec.feature_resolution, cond_rows=3, decoder=dict(
+        in_w=sd["in_layer.weight"], in_b=sd["in_layer.bias"], tmrp_w=sd["tmrp.weight"], tmrp_b=sd["tmrp.bias"],
+        cls_w=sd["class_logits.weight"], cls_b=sd["class_logits.bias"]))
+    d = packed["desc"]
+    ptr = ctypes.cast(ctypes.pointer(d), ctypes.c_void_p)
+    dims = list(d.dims)[: d.n_levels + 1]
+    assert dims == [16, 32, 64, 128, 256] and d.emb_dim == 64 and d.seq_len == 16
+    rows = sum(2 * dims[i // 2] for i in range(2 * d.n_levels)) + 2 * dims[d.n_levels]
+    n = 50
+    base = 256 + ((n + 1) // 2) * 32 * 8
+    assert _lib.lib().gldm_r1d_workspace_bytes(ptr, n) == (base + 255) // 256 * 256 + n * rows * 4
+
+
 def test_folded_prenorm_qkv_block_of_the_descriptor(fpc_state_dict):
     """ABI 4: per level, to_qkv with the PreNorm LayerNorm gain folded in (W' = W diag(g), to_qkv's own row order,
     MFMA fragment order) and its row sums s = W' 1, so that W LN(x) = rstd (W' x - mean s) (csrc/resnet1d.hip:
