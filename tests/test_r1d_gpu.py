@@ -221,6 +221,20 @@ def test_decoder_more_tiles_than_slots(engines):
     assert torch.equal(tm[:64], tm3) and torch.equal(lg[:64], lg3)
 
 
+def test_decoder_shared_conditioning_rows(engines):
+    """The decoder reads its ResnetBlocks' scale/shift rows from a per-cloud table (ss_table_kernel).  With 3 grasps
+    per cloud every other 2-sample tile straddles two clouds: must equal, bit for bit, the same batch with the
+    conditioning repeated per grasp (one table row set per sample)."""
+    _, dec = engines
+    g = torch.Generator().manual_seed(33)
+    n_cond, spc = 11, 3
+    zh = torch.randn(n_cond * spc, 4, generator=g).cuda()
+    zc = torch.randn(n_cond, 3, 64, generator=g).cuda()
+    tm, lg = dec.decode(zh, dec.cond_embed(zc), spc)
+    tm2, lg2 = dec.decode(zh, dec.cond_embed(zc.repeat_interleave(spc, dim=0)), 1)
+    assert torch.equal(tm, tm2) and torch.equal(lg, lg2)
+
+
 def test_sample_major_fallback_engine_for_other_denoiser_shapes():
     """A 4-position denoiser whose widths are outside the position-major engine's set (16 / 32 channels here) runs on
     the sample-major 32-column engine (r1d_kernel<32, 4>), chains included; checked against the oracle."""
