@@ -2164,10 +2164,35 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   }
   __syncthreads();
 
+  // The conditioning part of the embedding sum is the same at every step: thread i < S E keeps its (sample, e) entry's
+  // cond rows in registers for the whole segment (validate(): S E <= 320 <= threads of the 64-column engine; the
+  // 32-column engines take the loop below) and requests the NEXT step's time-embedding value a step ahead, so that the
+  // step prologue is three SiLUs and an LDS store instead of a chain of L2 round trips.
+  constexpr int kMaxR = 4;
+  const bool g_fast = S * E <= GG::kThreads && R <= kMaxR && !a.sample_t;
+  float ce_reg[kMaxR] = {0.f, 0.f, 0.f, 0.f}, se_reg = 0.f, te_next = 0.f;
+  if (g_fast && c.tid < S * E) {
+    const int s = c.tid / E, e = c.tid - s * E;
+    const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
+    const float *ce = a.cemb + ((size_t)(gi / a.samples_per_cond) * R) * E + e;
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r) ce_reg[r] = ce[(r < R ? r : 0) * E];
+    if (a.semb) se_reg = a.semb[(size_t)gi * E + e];  // latent_emb += cls_emb (class_conditioned_resnet.py:99-101)
+    if (a.temb) te_next = a.temb[(size_t)a.timesteps[s0] * E + e];
+  }
   for (int step = s0; step < s1; ++step) {
     if (GLDM_STAMPS(a.stamps) && blockIdx.x == 0 && c.tid == 0) a.stamps[kMaxOps + 1] = (long long)__builtin_readcyclecounter();
     // ---- G[s][e] = sum_r silu(temb[t][e] + cemb[cond][r][e])
-    if (!GLDM_SKIP(c, 32))
+    if (g_fast) {
+      if (c.tid < S * E) {
+        const float te = te_next + se_reg;
+        if (a.temb) te_next = a.temb[(size_t)a.timesteps[step + 1 < s1 ? step + 1 : step] * E + (c.tid % E)];
+        float g = 0.f;
+#pragma unroll
+        for (int r = 0; r < kMaxR; ++r) g += r < R ? silu(te + ce_reg[r]) : 0.f;
+        G[c.tid] = g;
+      }
+    } else if (!GLDM_SKIP(c, 32))
     for (int i = c.tid; i < S * E; i += GG::kThreads) {
       const int s = i / E, e = i - s * E;
       const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
