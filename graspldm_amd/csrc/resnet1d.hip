@@ -3089,7 +3089,11 @@ GLDM_API int gldm_sa_mlp_forward(const float *points, const float *centers, cons
       }
     }
     const size_t lds2 = (size_t)(rows_a + rows_b) * 128 * sizeof(float);
-    static const bool tile64 = getenv("GLDM_SA_TILE64") != nullptr;  // diagnostic: force the 64-column kernel
+#ifdef GLDM_DEBUG_KNOBS
+    static const bool tile64 = getenv("GLDM_SA_TILE64") != nullptr;  // diagnostic builds: force the 64-column kernel
+#else
+    constexpr bool tile64 = false;  // the shipped library reads no environment
+#endif
     if (ok && lds2 <= 160 * 1024 && !tile64) {
       static bool attr2 = false;
       if (!attr2) {
