@@ -51,11 +51,15 @@ __device__ __forceinline__ float row16_sum(float x) {  // every lane of a 16-lan
 constexpr int kConvThreads = 256;
 constexpr int kBrick = 4;  // brick is kBrick x kBrick x r output voxels
 
-__host__ __device__ inline int brick_row_stride(int r) {  // dwords per channel row in LDS, = 16 mod 32
-  const int bv = 6 * 6 * (r + 2);
-  int p = (bv + 31) / 32 * 32 + 16;
-  if (p - 32 >= bv) p -= 32;
-  return p;
+// z extent of a brick row in LDS: r + 2, or, where the brick is staged four z at a time, r + 8: float4 slots aligned with
+// the grid's own z (slot k = z 4 k - 4 .. 4 k - 1), so that every load is a 16-byte aligned dwordx4 inside the grid and
+// the two end slots of a row are all zero padding, written once (resolutions up to 24: the wider bricks would lose
+// their second workgroup per CU to the padding)
+__host__ __device__ constexpr bool brick_vec4(int r) { return r <= 24; }
+__host__ __device__ constexpr int brick_zp(int r) { return brick_vec4(r) ? r + 8 : r + 2; }  // vec4: z = -4 .. r + 3
+__host__ __device__ constexpr int brick_row_stride(int r) {  // dwords per channel row in LDS, = 16 mod 32
+  return ((6 * 6 * brick_zp(r) + 31) / 32 * 32 + 16) - 32 >= 6 * 6 * brick_zp(r) ? (6 * 6 * brick_zp(r) + 31) / 32 * 32 - 16
+                                                                                 : (6 * 6 * brick_zp(r) + 31) / 32 * 32 + 16;
 }
 
 // JN: k-steps of 4 input channels per tap and 16-channel block that hold real channels (Cin <= 4: 1, else 4)
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
   const int bpr = r / kBrick;                       // bricks per axis
   const int bx0 = (blockIdx.x / bpr) * kBrick, by0 = (blockIdx.x % bpr) * kBrick;
   const int b = blockIdx.y;
-  const int r3 = r * r * r, zp = r + 2, bv = 36 * zp, bvp = brick_row_stride(r);
+  constexpr bool kVec = brick_vec4(r);
+  constexpr int r3 = r * r * r, zp = brick_zp(r), bv = 36 * zp, bvp = brick_row_stride(r);
   const int cblocks = (cin + 15) >> 4, kblocks = 27 * cblocks;
   x += (size_t)b * cin * r3;
   y += (size_t)b * cout * r3;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
   for (int ni = 0; ni < NTW; ++ni) {
     const int o = 16 * (wave * NTW + ni) + col;       // 0 .. 16 r - 1
     const int iz = o % r, ixy = o / r, ix = ixy >> 2, iy = ixy & 3;
-    obase[ni] = (ix * 6 + iy) * zp + iz + kq * bvp;    // + row kq of each 4-row k-step
+    obase[ni] = (ix * 6 + iy) * zp + iz + (kVec ? 3 : 0) + kq * bvp;  // + row kq of each 4-row k-step (vec4: z = -1 sits at 3)
     gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + iz;
   }
   f32x4 acc[MT][NTW];
@@ -104,48 +109,95 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
     for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = bvv;
   }
 
-  // Staging map, computed once: thread t copies brick elements t, t + 256, ... (SQ of them) of every channel; their
-  // grid offsets / validity do not depend on the channel, so the per-block staging has no division in it (the index
-  // arithmetic used to cost as much as the block's MFMAs).
-  constexpr int SQ = (36 * (4 * NTW + 2) + kConvThreads - 1) / kConvThreads;  // r = 4 NTW: 4 at r = 24, 2 at r = 12
+  // Staging map, computed once.  Scalar form: thread t copies brick elements t, t + 256, ... (SQ of them) of every
+  // channel.  Vector form (kVec): a brick row is r / 4 + 2 float4 slots aligned with the grid's z; thread t owns the
+  // interior slot t (36 rows x r / 4 of them, at most one per thread): ONE aligned dwordx4 load per channel and ONE
+  // ds_write_b128 -- 16 + 16 instructions per thread and block at r = 24 instead of 64 + 64 -- and nothing else: the
+  // end slots of every row and the rows outside the grid are zero for the whole life of the workgroup and are written
+  // once, before the first block.  That matters because every instruction of these phases waits for a slot between
+  // the co-resident workgroup's MFMAs (45-90 cycles each): the staging is priced by its instruction count.
+  constexpr int kSlotsRow = r / 4, kSlots = 36 * kSlotsRow;
+  static_assert(!kVec || kSlots <= kConvThreads, "one interior slot per thread");
+  constexpr int SQ = kVec ? 1 : (36 * (4 * NTW + 2) + kConvThreads - 1) / kConvThreads;  // scalar: 4 at r = 24, 2 at r = 12
+  constexpr int kStageCh = JN == 1 ? 4 : 16;  // a <= 4-channel input only ever reads LDS rows 0..3 (one k-step per tap)
   int s_lds[SQ], s_glb[SQ];
 #pragma unroll
   for (int q = 0; q < SQ; ++q) {
     const int rem = tid + q * kConvThreads;
-    s_lds[q] = rem < bv ? rem : -1;
+    s_lds[q] = -1;
     s_glb[q] = -1;
-    if (rem < bv) {
+    if (kVec) {
+      if (rem < kSlots) {
+        const int ixy = rem / kSlotsRow, k = rem - ixy * kSlotsRow;
+        const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1;
+        s_lds[q] = ixy * zp + 4 * (k + 1);
+        if ((unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r) s_glb[q] = (gx * r + gy) * r + 4 * k;
+      }
+    } else if (rem < bv) {
+      s_lds[q] = rem;
       const int ixy = rem / zp, izp = rem - ixy * zp;
       const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1, gz = izp - 1;
       if ((unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r && (unsigned)gz < (unsigned)r)
         s_glb[q] = (gx * r + gy) * r + gz;
     }
   }
+  if constexpr (kVec) {  // the zero padding of the brick, once: both end slots of every row, interior slots of outside rows
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 72) {
+      float *lc = lds + (tid >> 1) * zp + ((tid & 1) ? 4 * (kSlotsRow + 1) : 0);
+#pragma unroll
+      for (int ci = 0; ci < kStageCh; ++ci) *reinterpret_cast<f32x4 *>(lc + ci * bvp) = z4;
+    }
+    if (s_lds[0] >= 0 && s_glb[0] < 0) {
+      float *lc = lds + s_lds[0];
+#pragma unroll
+      for (int ci = 0; ci < kStageCh; ++ci) *reinterpret_cast<f32x4 *>(lc + ci * bvp) = z4;
+    }
+  }
   // The staging is a latency problem (60 KB per block and workgroup, every load a memory round trip), so the NEXT
-  // block's 16 channels x SQ elements are requested before the current block's MFMA loop and only written to LDS
-  // after it: the round trips hide behind 1944 MFMAs per wave.
-  constexpr int kStageCh = JN == 1 ? 4 : 16;  // a <= 4-channel input only ever reads LDS rows 0..3 (one k-step per tap)
-  float stg[SQ][kStageCh];
+  // block's 16 channels are requested before the current block's MFMA loop and only written to LDS after it: the
+  // round trips hide behind 1944 MFMAs per wave.
+  float stg[kVec ? 1 : SQ][kVec ? 1 : kStageCh];
+  f32x4 stv[kVec ? kStageCh : 1];
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, cin * r3 * 4, 0x00020000);
   auto stage_load = [&](int cb) {
-    const float *xc = x + (size_t)(cb * 16) * r3;
+    if constexpr (kVec) {
+      // unconditional (threads without a slot read slot 0 and drop it); a channel past cin lies beyond the cloud's
+      // slice and reads 0 by the buffer rule
+      const int g0 = s_glb[0] >= 0 ? s_glb[0] : 0;
 #pragma unroll
-    for (int q = 0; q < SQ; ++q)
+      for (int ci = 0; ci < kStageCh; ++ci)
+        stv[ci] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((cb * 16 + ci) * r3 + g0) * 4, 0, 0));
+    } else {
+      const float *xc = x + (size_t)(cb * 16) * r3;
 #pragma unroll
-      for (int ci = 0; ci < kStageCh; ++ci) {
-        stg[q][ci] = 0.f;
-        if (s_glb[q] >= 0 && cb * 16 + ci < cin) stg[q][ci] = xc[(size_t)ci * r3 + s_glb[q]];
-      }
+      for (int q = 0; q < SQ; ++q)
+#pragma unroll
+        for (int ci = 0; ci < kStageCh; ++ci) {
+          stg[q][ci] = 0.f;
+          if (s_glb[q] >= 0 && cb * 16 + ci < cin) stg[q][ci] = xc[(size_t)ci * r3 + s_glb[q]];
+        }
+    }
   };
   auto stage_store = [&]() {
+    if constexpr (kVec) {
+      if (s_glb[0] >= 0) {
+        float *lc = lds + s_lds[0];
 #pragma unroll
-    for (int q = 0; q < SQ; ++q)
-      if (s_lds[q] >= 0) {
-        float *lc = lds + s_lds[q];
-#pragma unroll
-        for (int ci = 0; ci < kStageCh; ++ci) lc[ci * bvp] = stg[q][ci];
+        for (int ci = 0; ci < kStageCh; ++ci) *reinterpret_cast<f32x4 *>(lc + ci * bvp) = stv[ci];
       }
+    } else {
+#pragma unroll
+      for (int q = 0; q < SQ; ++q)
+        if (s_lds[q] >= 0) {
+          float *lc = lds + s_lds[q];
+#pragma unroll
+          for (int ci = 0; ci < kStageCh; ++ci) lc[ci * bvp] = stg[q][ci];
+        }
+    }
   };
-  constexpr bool kLate = SQ <= 2;
+  constexpr int kStageLoads = SQ * kStageCh;  // load instructions per thread and block
+  constexpr bool kLate = r <= 12 && kStageLoads <= 32;  // measured per resolution (see the tap loop)
   constexpr bool kPipe = SQ <= 4;  // 64 staged registers beside the accumulators; wider bricks (r = 32) stage in place
   GLDM_C3_STAMP(1);
   if (kPipe) stage_load(0);
