@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--scheduler", choices=["ddim", "ddpm"], default="ddim",
                     help="ddpm with --ddim-steps 1000 --points 4096 --grasps 200 is BASELINE.json configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / collective plumbing only, on CPU over gloo (no HIP, no numbers): used by the tests")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps alternate over (2: batch k+1's encoder overlaps batch k's denoise tail)")
     return ap.parse_args()
@@ -66,11 +68,91 @@ def event_time(fn, iters, lead=1):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without an outside launcher: N child processes of this script, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), started BEFORE anything here touches the GPU
+    (this parent never does, and nothing is re-exec'd).  Rank 0's JSON line is relayed; any failing child fails the run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    if not args.dry_run:
+        have = torch.cuda.device_count()   # counting devices does not initialise HIP on this image
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    # ONE JSON line on stdout: anything else rank 0's libraries wrote there (gloo / RCCL banners) goes to stderr
+    for line in out0.splitlines():
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"bench.py: rank exit codes {codes}")
+
+
+def dry_run(args, world, rank):
+    """The N > 1 plumbing on CPU (gloo): barriers, the result all-gather, MAX-over-ranks timing, one JSON line."""
+    import torch.distributed as dist
+    from graspldm_amd.distributed import gather_results
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    B, G = args.clouds_per_gpu, args.grasps
+    rows = torch.full((B * G, 7), float(rank))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = gather_results(rows, B * G, world * B * G)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = all(bool((out[r * B * G:(r + 1) * B * G] == r).all()) for r in range(world))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        n_seen = dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        n_seen = 1
+    if rank == 0:
+        print(json.dumps(dict(metric="dry run (no GPU work)", value=None, unit="grasps/s", n_gpus=n_seen, steps=args.steps,
+                              warmup=args.warmup, ms_per_step=dt / max(args.steps, 1) * 1e3, dry_run=True, gather_ok=ok,
+                              rows_gathered=int(out.shape[0]))))
+
+
+def workload_label(B, G, N, S, sched):
+    """Which BASELINE.json configuration (if any) the arguments are."""
+    if (N, S, sched, G) == (1024, 100, "ddim", 20):
+        if B == 256:
+            return "BASELINE.json configs[2] per GPU (configs[3] = this per-GPU workload on 8 GPUs)"
+        if B == 1:
+            return "BASELINE.json configs[1] (one object)"
+    if (N, S, sched, G) == (4096, 1000, "ddpm", 200):
+        return "BASELINE.json configs[4] shape (4096-pt partial clouds, 1000 DDPM steps, 200 grasps per cloud)"
+    return "custom arguments (not a BASELINE.json configuration)"
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}",
+              file=sys.stderr)
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -79,6 +161,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        world = dist.get_world_size()   # n_gpus in the line = the ranks RCCL saw
 
     from graspldm_amd import _lib
     _lib.lib()  # fail loudly here if the HIP library is missing
@@ -91,7 +174,8 @@ def main():
     ldm = build_fpc_ldm(n_points=N, scheduler=args.scheduler, device=dev)
     ldm.set_inference_timesteps(S)
     uniq = min(B, 32)   # 32 distinct synthetic objects per rank, tiled to B (resident in HBM)
-    pcs_u, metas_u = synthetic_batch(uniq, N, first_index=rank * uniq)
+    partial = (N, S, args.scheduler) == (4096, 1000, "ddpm")   # configs[4]: camera-facing side, resampled with duplicates
+    pcs_u, metas_u = synthetic_batch(uniq, N, partial=partial, first_index=rank * uniq)
     reps = (B + uniq - 1) // uniq
     pcs = pcs_u.repeat(reps, 1, 1)[:B].contiguous().to(dev)
     gmean = metas_u["grasp_mean"].repeat(reps, 1)[:B].contiguous().to(dev)
@@ -168,15 +252,19 @@ def main():
         # memory-side bytes of one launch from the committed PMC passes (tools/pmc_denoise.sh: FETCH_SIZE, doubled
         # per the gfx950 16-B/lane rule, + WRITE_SIZE); only quoted for the workload they were collected on
         traffic = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_denoise_pmc.json")
-        if os.path.exists(pmc_path):
+        traffic_source = None
+        import glob
+        for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_denoise_pmc.json")), reverse=True):
             pmc = json.load(open(pmc_path))
-            if pmc.get("n_latents") == B * G and pmc.get("steps") == S:
+            if pmc.get("n_latents") == B * G and pmc.get("steps") == S and args.scheduler == "ddim":
                 traffic = pmc["fetch_bytes_corrected"] + pmc["write_bytes"]
+                traffic_source = ("static: " + os.path.relpath(pmc_path, ROOT) + " (rocprofv3 --pmc passes of this workload, "
+                                  "tools/pmc_denoise.sh; not re-measured in this run)")
+                break
         roof = dict(kernel="r1d_kernel<64, 4> (gldm_denoise: %d %s steps fused, position-major tiles)" % (S, args.scheduler.upper()),
                     bound="mfma",
                     achieved=flop / t_den / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=flop / t_den / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
+                    frac=flop / t_den / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_source,
                     algorithmic_flop_per_launch=flop, avg_launch_ms=t_den * 1e3,
                     timing="HIP events around 3 launches on their own (no other stream active); in the pipelined "
                            "steps the other stream's encoder kernels share the GPU with the launch",
@@ -230,6 +318,24 @@ def main():
                             avg_ms=t_fsa * 1e3, achieved=sa_flop / t_fsa / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
                             unit="TFLOP/s", frac=sa_flop / t_fsa / 1e12 / PEAK_F32_MFMA_TFLOPS,
                             hbm_bytes_avoided=B * 4 * (Cs + 3) * Ms * Us))
+        # ---- BASELINE.json configs[1]: ONE object (B = 1, G grasps), latency per stage and end to end
+        if args.scheduler == "ddim":
+            pc1, x1 = pcs[:1].contiguous(), x_T[:G].contiguous()
+            z1 = ldm.vae_model.encode_pc(pc1)
+            ce1 = eng.cond_embed(z1)
+            dn1 = lambda: eng.denoise(x1, ce1, G, timesteps=ts, sched_kind=kind, coef=coef)
+            lat1 = dn1().squeeze(-2)
+            def obj1():
+                (tm1, lg1), _ = ldm.generate_grasps(pc1, num_grasps=G, x_T=x1)
+                return pose_epilogue(tm1, lg1, gmean[:1], gstd[:1], G)
+            obj1()
+            kernels.append(dict(kernel=f"one object end to end (BASELINE configs[1]: B=1, G={G}, {S} DDIM steps)", bound="latency",
+                                avg_ms=event_time(obj1, 5) * 1e3,
+                                stages_ms=dict(encode=event_time(lambda: ldm.vae_model.encode_pc(pc1), 5) * 1e3,
+                                               denoise=event_time(dn1, 5) * 1e3,
+                                               decode=event_time(lambda: dec(lat1, z1, samples_per_cond=G), 5) * 1e3),
+                                note="latency of a single cloud: the denoise launch is 2 position-major tiles on 2 of 256 CUs, "
+                                     "i.e. the per-step critical path of one workgroup"))
         # ---- CPU baseline: the torch-CPU oracle on this box's host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.scheduler == "ddim":
@@ -251,8 +357,8 @@ def main():
         out = dict(metric="grasps/sec whole-node (%d-pt cloud, %d %s steps)" % (N, S, args.scheduler.upper()), value=grasps_per_s,
                    unit="grasps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=f"LDM mode, {B} synthetic {N}-pt clouds per GPU x {G} grasps, {S} {args.scheduler.upper()} steps "
-                                        "(BASELINE.json configs[2]; configs[3] at 8 GPUs)",
+                   config=dict(workload=f"LDM mode, {B} synthetic {'partial ' if partial else ''}{N}-pt clouds per GPU x {G} grasps, "
+                                        f"{S} {args.scheduler.upper()} steps: " + workload_label(B, G, N, S, args.scheduler),
                                clouds_per_gpu=B, grasps_per_cloud=G, points=N, ddim_steps=S,
                                encoder="PVCNNEncoder (shipped fpc config)", parallelism=f"cloud-sharded x{world}",
                                weights="synthetic recipe seed 0", streams=args.streams),

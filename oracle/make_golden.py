@@ -20,6 +20,10 @@ Fixtures hold inputs and expected outputs only (data, no reference source).
   schema_*.json            state-dict key -> (shape, dtype) of the reference modules
   G8 sa_module.npz         PointNetSAModule on one cloud (SSG SA1/SA2 shapes)
      pointnet2_ssg.npz     PointNet2SSG forward on one cloud (every 8th point kept)
+     c5_ldm_e2e.npz        BASELINE configs[4]: n_points=4096, one partial cloud, 1000 DDPM steps, G=200
+                           (`python -m oracle.make_golden c5`)
+     ppc_ldm_e2e.npz       the shipped partial-cloud experiment (z16, pc256, DDPM): denoiser / decoder forwards and
+                           end to end on 2 partial clouds (`python -m oracle.make_golden ppc`)
      pvcnn2.npz            PVCNN2 forward on one cloud (every 16th point kept); `python -m oracle.make_golden pvcnn2`
                            writes only this one
 """
@@ -272,6 +276,64 @@ def dpmpp_golden():
     _save("dpmpp.npz", **out)
 
 
+@torch.no_grad()
+def c5_golden():
+    """BASELINE.json configs[4] on the reference's own graph: the fpc LDM rebuilt with a 4096-point encoder and the
+    DDPM scheduler (fixed_large), ONE partial synthetic cloud (camera-facing side, resampled to 4096 points with
+    duplicates like regularize_pc_point_count), G = 200 grasps, the full 1000-step loop of
+    GaussianDiffusion1D.sample (gaussian_diffusion.py:232-277) + the decoder + the epilogue of rotations.py.
+    The noise is NOT stored (3.2 MB): it is torch.manual_seed(SEED) followed by the reference's draw order
+    (x_T [200,1,4], then one [200,1,4] draw per step with t > 0), which the test regenerates on the CPU."""
+    ref_import.install_shims()
+    import json
+    ldm = ref_import.build_reference_ldm(noise_scheduler_type="ddpm", n_points=4096)
+    synthetic.load_synthetic_weights(ldm, seed=0)
+    _schema("schema_fpc_ldm_n4096.json", ldm)
+    pcs, metas = synthetic.synthetic_batch(1, 4096, partial=True, first_index=50)
+    from grasp_ldm.utils.rotations import tmrp_to_H
+    G = 200
+    torch.manual_seed(SEED)
+    (tm, lg), _ = ldm.generate_grasps(pcs, num_grasps=G, device="cpu")
+    un = tm.view(1, G, 6) * metas["grasp_std"].unsqueeze(-2) + metas["grasp_mean"].unsqueeze(-2)
+    H = tmrp_to_H(un)
+    z = ldm.vae_model.encode_pc(pcs)
+    _save("c5_ldm_e2e.npz", pc=pcs, grasp_mean=metas["grasp_mean"], grasp_std=metas["grasp_std"], z=z,
+          tmrp=tm, logit=lg, H=H, confidence=torch.sigmoid(lg.view(1, G, 1)), seed=SEED, num_grasps=G)
+
+
+@torch.no_grad()
+def ppc_golden():
+    """The reference's second shipped experiment, the partial-cloud config
+    (configs/generation/partial_pc/ppc_1a_..._latentc3_z16_pc256_180k.py): 16-dim grasp latent (the denoiser runs on
+    16 positions), 256-dim cloud latent (3 x 256 conditioning), DDPM fixed_large, 1000 steps.  Two partial clouds,
+    G = 10, full loop + decoder + epilogue; plus single denoiser forwards at 4 timesteps and the encoder latent.
+    Noise: torch.manual_seed(SEED), the reference's draw order (regenerated by the test)."""
+    ref_import.install_shims()
+    rel = "configs/generation/partial_pc/ppc_1a_partial_63cat8k_filtered_latentc3_z16_pc256_180k.py"
+    ldm = ref_import.build_reference_ldm(rel)
+    synthetic.load_synthetic_weights(ldm, seed=0)
+    _schema("schema_ppc_ldm.json", ldm)
+    assert ldm.diffusion_model._noise_scheduler_type == "ddpm"
+    pcs, metas = synthetic.synthetic_batch(2, 1024, partial=True, first_index=60)
+    from grasp_ldm.utils.rotations import tmrp_to_H
+    G = 10
+    z = ldm.vae_model.encode_pc(pcs)
+    den = ldm.diffusion_model.model
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(6, 1, 16, generator=g)
+    zc = torch.randn(6, 3, 256, generator=g)
+    ts = [0, 7, 500, 999]
+    eps = torch.stack([den(x, time=torch.full((6,), t, dtype=torch.long), z_cond=zc) for t in ts])
+    zh = torch.randn(6, 16, generator=g)
+    d_tm, d_lg = ldm.vae_model.decoder(zh, zc)
+    torch.manual_seed(SEED)
+    (tm, lg), _ = ldm.generate_grasps(pcs, num_grasps=G, device="cpu")
+    un = tm.view(2, G, 6) * metas["grasp_std"].unsqueeze(-2) + metas["grasp_mean"].unsqueeze(-2)
+    _save("ppc_ldm_e2e.npz", pc=pcs, grasp_mean=metas["grasp_mean"], grasp_std=metas["grasp_std"], z=z,
+          den_x=x, den_zc=zc, den_t=np.array(ts), den_eps=eps, dec_zh=zh, dec_tmrp=d_tm, dec_logit=d_lg,
+          tmrp=tm, logit=lg, H=tmrp_to_H(un), confidence=torch.sigmoid(lg.view(2, G, 1)), seed=SEED, num_grasps=G)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dpmpp":
         os.makedirs(OUT, exist_ok=True)
@@ -280,6 +342,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "class_cond":
         os.makedirs(OUT, exist_ok=True)
         class_cond_golden()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] in ("c5", "ppc"):
+        os.makedirs(OUT, exist_ok=True)
+        torch.set_num_threads(8)
+        {"c5": c5_golden, "ppc": ppc_golden}[sys.argv[1]]()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "front_end":
         os.makedirs(OUT, exist_ok=True)

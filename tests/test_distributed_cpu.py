@@ -78,3 +78,32 @@ def test_shard_bounds_cover_everything():
 def test_gather_single_process_is_identity():
     rows = torch.arange(21.).view(3, 7)
     assert torch.equal(gather_results(rows, 4, 3), rows)
+
+
+def test_bench_spawns_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no outside launcher starts two ranks itself (gloo here via --dry-run) and
+    prints exactly one JSON line whose n_gpus is the world size the process group saw."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2",
+                        "--clouds-per-gpu", "3", "--grasps", "5"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] and rec["gather_ok"] and rec["rows_gathered"] == 2 * 3 * 5
+
+
+def test_bench_workload_label_follows_arguments():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert "configs[2]" in b.workload_label(256, 20, 1024, 100, "ddim")
+    assert "configs[4]" in b.workload_label(8, 200, 4096, 1000, "ddpm")
+    assert "configs[2]" not in b.workload_label(8, 200, 4096, 1000, "ddpm")
+    assert "custom" in b.workload_label(256, 20, 1024, 50, "ddim")

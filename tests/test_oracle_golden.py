@@ -112,3 +112,43 @@ def test_g8_pointnet2_ssg():
     sd = synthetic_state_dict(load_schema("schema_pointnet2_ssg.json"), seed=3)
     out = R.pointnet2_ssg_forward(sd, "", g["coords"])
     _close(out[:, :, ::8], g["out"], atol=2e-5)
+
+
+def _ddpm_noise(seed, n, dim, steps=1000):
+    torch.manual_seed(seed)
+    x_T = torch.randn(n, 1, dim)
+    return x_T, torch.stack([torch.randn(n, 1, dim) for _ in range(steps - 1)])
+
+
+def test_ppc_config_forwards_and_end_to_end(fpc_spec):
+    """The reference's partial-cloud experiment (z16, pc256, DDPM 1000 steps): oracle vs the reference's vectors."""
+    g = load_golden("ppc_ldm_e2e.npz")
+    sd = synthetic_state_dict(load_schema("schema_ppc_ldm.json"), seed=0)
+    z = R.pvcnn_encoder_forward(sd, "vae_model.encoder.pc_encoder.", g["pc"], fpc_spec)
+    _close(z, g["z"], atol=1e-5)
+    for i, t in enumerate(g["den_t"].tolist()):
+        tb = torch.full((6,), t, dtype=torch.long)
+        _close(R.resnet1d_forward(sd, "diffusion_model.model.", g["den_x"], z_cond=g["den_zc"], time=tb), g["den_eps"][i])
+    tmrp, logit = R.decoder_forward(sd, "vae_model.decoder.", g["dec_zh"], g["den_zc"])
+    _close(tmrp, g["dec_tmrp"])
+    _close(logit, g["dec_logit"])
+    G = int(g["num_grasps"])
+    x_T, noise = _ddpm_noise(int(g["seed"]), 2 * G, 16)
+    tmrp, logit = R.ldm_generate(sd, g["pc"], G, R.make_scheduler("ddpm"), fpc_spec, n_dims=16, x_T=x_T, step_noise=noise)
+    _close(tmrp, g["tmrp"], atol=2e-5)
+    _close(logit, g["logit"], atol=2e-5)
+
+
+def test_config5_end_to_end(fpc_spec):
+    """BASELINE configs[4]: 4096-point partial cloud, 1000 DDPM steps, G = 200 (oracle vs the reference's vectors)."""
+    g = load_golden("c5_ldm_e2e.npz")
+    schema = dict(load_schema("schema_fpc_ldm.json"))
+    schema["vae_model.encoder.pc_encoder.out_layer.1.weight"] = ((64, 4096), torch.float32)
+    sd = synthetic_state_dict(schema, seed=0)
+    G = int(g["num_grasps"])
+    x_T, noise = _ddpm_noise(int(g["seed"]), G, 4)
+    tmrp, logit = R.ldm_generate(sd, g["pc"], G, R.make_scheduler("ddpm"), fpc_spec, x_T=x_T, step_noise=noise)
+    _close(tmrp, g["tmrp"], atol=2e-5)
+    _close(logit, g["logit"], atol=2e-5)
+    out = R.pose_epilogue(tmrp, logit, dict(grasp_mean=g["grasp_mean"], grasp_std=g["grasp_std"]), 1, G)
+    _close(out["grasps"], g["H"], atol=2e-5)
