@@ -39,6 +39,7 @@
 
 #include "gldm.h"
 #include "wstream.h"
+#include "devstate.h"
 
 #define GLDM_API extern "C" __attribute__((visibility("default")))
 
@@ -1743,8 +1744,10 @@ __device__ __forceinline__ float chain_take(unsigned long long *g, unsigned tag,
     if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
     __builtin_amdgcn_s_sleep(16);
   }
-  __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // gldm_r1d_workspace_error()
-  return __uint_as_float((unsigned)x);
+  // The wait expired: the tile's latent is lost.  The error word is what the host reads (R1dEngine checks it after
+  // every chained launch and raises); the NaN makes every output of this tile NaN whether or not anyone looks.
+  __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __builtin_nanf("");
 }
 
 struct RunArgs {
@@ -2467,16 +2470,7 @@ bool pm_supported(const gldm_r1d_desc *d) {
   return true;
 }
 
-int cu_count() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
+using gldm_dev::cu_count;
 
 // Work plan of one launch.  `slots` = workgroups resident at once (two 32-column tiles per CU).  A batch of
 // up to `slots` tiles is one workgroup per tile.  A larger one runs `slots` persistent workgroups: each owns
@@ -2500,6 +2494,7 @@ Plan make_plan(int n_samples, int n_steps, int L, int nc, bool allow_chain = tru
     int g = slots / p.left;
     if (g > 8) g = 8;             // a hand-off is ~3 us; finer cuts buy nothing
     if (g > n_steps) g = n_steps;
+    if (n_steps > 4095) g = 1;  // chain_tag() carries the step in 12 bits: longer loops run their left-over tiles whole
     if (!allow_chain) g = 1;  // DPM++ carries two rows of state per tile (x and the previous denoised): whole tiles only
     p.chain = g < 1 ? 1 : g;
     p.seglen = (n_steps + p.chain - 1) / p.chain;
@@ -2513,12 +2508,8 @@ int launch_one(const RunArgs &a, int tiles, hipStream_t s) {
 #ifdef GLDM_DEBUG_KNOBS
   if (getenv("GLDM_R1D_ONE_WG") && lds_bytes < 100 * 1024) lds_bytes = 100 * 1024;  // one workgroup per CU: phases on their own
 #endif
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&r1d_kernel<NC, L>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr = true;
-  }
+  struct Tag {};
+  gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&r1d_kernel<NC, L>), (int)lds_bytes);
   hipLaunchKernelGGL((r1d_kernel<NC, L>), dim3(tiles), dim3(Geo<NC>::kThreads), lds_bytes, s, a);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
@@ -3016,12 +3007,8 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   if (w0 && (!b0 || cin0 <= 0 || (cin0 & 31) || (cin & 255))) return GLDM_ERR_UNSUPPORTED;
   const size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
   if (lds_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pointwise_mlp_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  struct PwTag { int site; };
+  gldm_dev::allow_dynamic_lds<PwTag>(reinterpret_cast<const void *>(&pointwise_mlp_kernel), 160 * 1024);
   PwArgs a{};
   a.x = x; a.w = w; a.bias = bias; a.head_w = head_w; a.head_b = head_b; a.y = y; a.z = z;
   a.cin = cin; a.cout = cout; a.n = n; a.relu = relu; a.hout = hout;
@@ -3095,12 +3082,8 @@ GLDM_API int gldm_sa_mlp_forward(const float *points, const float *centers, cons
     constexpr bool tile64 = false;  // the shipped library reads no environment
 #endif
     if (ok && lds2 <= 160 * 1024 && !tile64) {
-      static bool attr2 = false;
-      if (!attr2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp2_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr2 = true;
-      }
+      struct Sa2Tag { int site; };
+      gldm_dev::allow_dynamic_lds<Sa2Tag>(reinterpret_cast<const void *>(&sa_mlp2_kernel), 160 * 1024);
       const int cpt2 = 128 / u, tpc = (m + cpt2 - 1) / cpt2, total = tpc * b;
       const int grid = total < cu_count() ? total : cu_count();
       hipLaunchKernelGGL(sa_mlp2_kernel, dim3(grid), dim3(512), lds2, reinterpret_cast<hipStream_t>(stream), a, rows_a,
@@ -3109,12 +3092,8 @@ GLDM_API int gldm_sa_mlp_forward(const float *points, const float *centers, cons
     }
   }
   const size_t lds_bytes = (size_t)(Geo<64>::kBufH + kMaxC * 64) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes);
-    attr = true;
-  }
+  struct SaTag { int site; };
+  gldm_dev::allow_dynamic_lds<SaTag>(reinterpret_cast<const void *>(&sa_mlp_kernel), (int)lds_bytes);
   const int cpt = 64 / u;
   hipLaunchKernelGGL(sa_mlp_kernel, dim3((m + cpt - 1) / cpt, b), dim3(Geo<64>::kThreads), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), a);

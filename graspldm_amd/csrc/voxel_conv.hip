@@ -20,6 +20,7 @@
 
 #include "gldm.h"
 #include "wstream.h"
+#include "devstate.h"
 
 #define GLDM_API extern "C" __attribute__((visibility("default")))
 
@@ -440,12 +441,8 @@ template <int MT, int NTW, int JN>
 int launch_conv_jn(const float *x, const float *wp, const float *bias, int b, int cin, int cout, int r, float *y,
                 float *partial, hipStream_t s) {
   const size_t lds_bytes = (size_t)16 * brick_row_stride(r) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_k3_kernel<MT, NTW, JN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr = true;
-  }
+  struct Tag {};  // one flag array per instantiation
+  gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_kernel<MT, NTW, JN>), (int)lds_bytes);
   const int bpr = r / kBrick;
   hipLaunchKernelGGL((conv3d_k3_kernel<MT, NTW, JN>), dim3(bpr * bpr, b), dim3(kConvThreads), lds_bytes, s, x, wp, bias,
                      cin, cout, r, y, partial);

@@ -49,6 +49,12 @@ class _InferenceBase:
         self.dataset = None
 
     def _results(self, pc, metas, tmrp, cls_logit, num_pcs, num_grasps, all_steps=()):
+        # before anything leaves the device: a lost hand-off inside the fused sampling launch raises here
+        # (status, not silent garbage: the reference exits the process on a CUDA error, cuda_utils.cuh:28-37)
+        for m in self.model.modules():
+            eng = getattr(m, "_engine", None)
+            if eng is not None:
+                eng.check()
         metas = {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in metas.items()}
         # mean [B,6] and std [1,6] (normalize_input and the dataset both build them so) broadcast independently
         mean, std = metas["grasp_mean"], metas["grasp_std"]

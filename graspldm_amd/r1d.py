@@ -19,6 +19,7 @@ class R1dEngine:
         self.cond_b = packed["cond_b"].to(self.device)
         self.seq_len = int(self.desc.seq_len)
         self._ws = {}   # scratch per HIP stream: launches on different streams may run concurrently
+        self._probe = {}  # per workspace: (pinned host copy of its hand-off error word, event of that copy)
 
     # -- helpers
     def _desc_ptr(self):
@@ -38,6 +39,36 @@ class R1dEngine:
     def workspace_errors(self):
         """Sum of the hand-off error words of every workspace (0 unless a bounded wait expired); synchronises."""
         return int(sum(int(ws[12:16].view(torch.int32).item()) for ws in self._ws.values()))
+
+    # A step-segment hand-off whose bounded wait expires (csrc/resnet1d.hip: chain_take) poisons its tile with NaN
+    # and sets the workspace's error word.  The word is copied to pinned host memory behind every multi-step launch
+    # (4 bytes, asynchronous, same stream) and looked at without a host sync at the next launch on that workspace,
+    # and with one in check(), which the inference harness calls before results leave the device.
+    def _arm_probe(self, key, ws):
+        host, _ = self._probe.get(key, (None, None))
+        if host is None:
+            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(ws[12:16].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._probe[key] = (host, ev)
+
+    def _raise_if_failed(self, key, wait):
+        host, ev = self._probe.get(key, (None, None))
+        if ev is None or not (wait or ev.query()):
+            return
+        if wait:
+            ev.synchronize()
+        if int(host[0]) != 0:
+            host[0] = 0
+            self._ws[key][12:16].zero_()
+            raise L.GldmError("gldm_denoise: a step-segment hand-off between workgroups timed out (workspace error word "
+                              "set); the latents of that launch are invalid (NaN) and must be discarded")
+
+    def check(self):
+        """Raise GldmError if any launch so far lost a hand-off (waits for the pending error-word copies only)."""
+        for key in list(self._probe):
+            self._raise_if_failed(key, wait=True)
 
     def cond_embed(self, z_cond):
         """input_emb_layers (Linear + SiLU) on [n, R, Dc] (or [n, Dc]) -> [n, R, E]."""
@@ -65,12 +96,16 @@ class R1dEngine:
         out = torch.empty_like(x_in)
         n_steps = 1 if timesteps is None else int(timesteps.numel())
         ws = self._workspace(n)
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        self._raise_if_failed(key, wait=False)
         with torch.cuda.device(self.device):
             tab = self.temb if temb is None else temb.contiguous().float()
             L.call("gldm_denoise", self._desc_ptr(), L.ptr(self.weights), L.ptr(tab), L.ptr(cemb),
                    int(samples_per_cond), L.ptr(x_in), n, L.ptr(timesteps), L.ptr(sample_t), n_steps, int(sched_kind),
                    1 if clip_sample else 0, L.ptr(coef), L.ptr(step_noise), L.ptr(sample_emb), L.ptr(out), L.ptr(ws),
                    L.current_stream(self.device))
+            if n_steps > 1:   # only multi-step launches can split a tile's steps over workgroups
+                self._arm_probe(key, ws)
         return out
 
     def decode(self, z_h, cemb, samples_per_cond):

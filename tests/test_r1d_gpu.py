@@ -181,6 +181,41 @@ def test_step_split_chain_is_bitwise_batch_invariant(engines, extra_tiles, steps
     assert den.workspace_errors() == 0
 
 
+def test_lost_handoff_raises_instead_of_returning_garbage(engines):
+    """A step-segment hand-off that never arrives (here: the workspace's arrival-ticket counter is pre-set to 1, so the
+    slot that owns the left-over tile's first segment does not exist) must surface as GldmError, not as rc 0 with
+    stale latents: the bounded wait sets the error word (and NaN-poisons the tile), R1dEngine.check() -- called by the
+    inference harness before results leave the device -- raises, and the next launch on the workspace is clean."""
+    from graspldm_amd._lib import GldmError
+    from graspldm_amd.r1d import SCHED_DDIM
+    den, _ = engines
+    n = _slots() * 8 + 16                 # one left-over 16-latent tile (two 8-latent ones on the 32-column engine)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 1, 4, generator=g).cuda()
+    z = torch.randn(n // 8, 3, 64, generator=g).cuda()
+    ts, coef = _ddim_tables(100)
+    ts, coef = ts[-16:].contiguous().cuda(), coef[-16:].contiguous().cuda()
+    cemb = den.cond_embed(z)
+    run = lambda: den.denoise(x, cemb, 8, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef)
+    good = run()
+    den.check()
+    ws = den._ws[torch.cuda.current_stream().cuda_stream]
+    ws[0:4].view(torch.int32).fill_(1)
+    run()
+    with pytest.raises(GldmError, match="hand-off"):
+        den.check()
+    again = run()                          # header re-armed by the kernel, error word cleared by check()
+    den.check()
+    assert torch.equal(again, good) and den.workspace_errors() == 0
+    # the lazy path: without an explicit check(), the NEXT launch on that workspace raises
+    ws[0:4].view(torch.int32).fill_(1)
+    run()
+    torch.cuda.synchronize()
+    with pytest.raises(GldmError):
+        run()
+    assert torch.equal(run(), good)
+
+
 def test_step_split_chain_against_oracle(engines, fpc_state_dict):
     """The spliced tile itself against the CPU oracle (not only against another HIP launch)."""
     from oracle import torch_ref as R
