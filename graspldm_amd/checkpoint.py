@@ -6,8 +6,9 @@ grasp_ldm/utils/torch_utils.py:4-37) and hardens it for files written elsewhere:
 
   * Lightning `.ckpt` files pickle more than tensors (hyper-parameters holding the reference's
     `Config`, callbacks, optimiser states): none of those classes exist here.  `load_checkpoint` unpickles
-    with a class resolver that substitutes an inert placeholder for anything it cannot import, so the
-    tensors are still read; a bare state dict (no "state_dict" wrapper) is accepted too.
+    with an ALLOW-LISTED class resolver (torch tensor / storage rebuild helpers, numpy arrays, plain containers);
+    every other global -- importable or not, `os.system` included -- becomes an inert placeholder, so the tensors are
+    still read and a crafted file cannot execute code through this loader; a bare state dict (no "state_dict" wrapper) is accepted too.
   * weights live under `model.` and, when an EMA copy was kept, `ema_model.online_model.` (the string the
     reference loads for use_ema_model=True, :521; kept verbatim).  Every other key (`ema_model.ema_model.*`,
     `ema_model.initted`, `ema_model.step`, loss buffers) is ignored, exactly like ignore_all_others=True.
@@ -53,12 +54,43 @@ class _Placeholder:
         return (_Placeholder, ())
 
 
+# Globals a Lightning checkpoint legitimately needs to rebuild its TENSORS and plain containers.  Everything else
+# (hyper-parameter objects, callbacks, and anything a crafted file might name: os.system, subprocess.Popen, ...) becomes
+# an inert placeholder, whether or not the class is importable here: the fallback loader never executes foreign code.
+_SAFE_MODULES = ("torch", "collections", "numpy", "_codecs")
+_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
+                  "complex", "slice", "range", "object"}
+_BLOCKED = {("torch", "load"), ("torch", "save"), ("torch.serialization", "load"), ("torch.hub", "load"),
+            ("numpy", "load"), ("numpy", "save"), ("numpy", "fromfile"), ("numpy", "memmap"), ("numpy", "loadtxt")}
+
+
+def _is_safe_global(module, name):
+    if (module, name) in _BLOCKED or name.startswith("_") and module == "builtins":
+        return False
+    if module == "builtins":
+        return name in _SAFE_BUILTINS
+    root = module.split(".", 1)[0]
+    if root not in _SAFE_MODULES:
+        return False
+    if root == "torch":  # storages, dtypes, rebuild helpers, Size, OrderedDict-like containers; no I/O or JIT entry points
+        return module in ("torch", "torch._utils", "torch.storage", "torch._tensor", "torch.nn.parameter",
+                          "torch.serialization") and not name.startswith("load")
+    if root == "numpy":
+        return module in ("numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric",
+                          "numpy._core.numeric", "numpy.dtypes") and name in (
+                              "ndarray", "dtype", "_reconstruct", "scalar", "float32", "float64", "int64", "int32", "bool_",
+                              "uint8", "int8", "int16", "float16", "Float32DType", "Float64DType", "Int64DType", "Int32DType")
+    return True
+
+
 class _TolerantUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        try:
-            return super().find_class(module, name)
-        except Exception:
-            return type(name, (_Placeholder,), {"__module__": module})
+        if _is_safe_global(module, name):
+            try:
+                return super().find_class(module, name)
+            except Exception:
+                pass
+        return type(name, (_Placeholder,), {"__module__": module})
 
 
 class _TolerantPickle:
@@ -82,7 +114,10 @@ def load_checkpoint(path):
         raise FileNotFoundError(f"Could not find any checkpoint in ckpt path: {path}")
     try:
         raw = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
+    except Exception as e:  # Lightning checkpoints carry non-tensor objects (hyper-parameters, callbacks)
+        warnings.warn(f"{os.path.basename(path)}: not loadable with weights_only=True ({type(e).__name__}); reading it with "
+                      "the allow-listed unpickler (tensors and plain containers only, every other object becomes a "
+                      "placeholder)")
         raw = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_TolerantPickle)
     sd = raw["state_dict"] if isinstance(raw, dict) and "state_dict" in raw else raw
     if not isinstance(sd, dict) or not any(isinstance(v, torch.Tensor) for v in sd.values()):

@@ -181,8 +181,20 @@ class ElucidatedDiffusion(nn.Module):
         temb = self._time_table(times).to(device)   # one row per step; the engine indexes it with `timesteps`
         ts = torch.arange(n_steps, dtype=torch.int32, device=device)
         if return_all:
-            raise NotImplementedError("return_all is not built for the DPM++ sampler (its second-order state lives "
-                                      "inside the fused launch)")
+            # the per-step form (elucidated_diffusion.py:287-311 keeps every x): one network launch per step, the
+            # 2M update as elementwise torch ops in the fused launch's operation order (one rounding per operation)
+            cf = coef.to(device)
+            all_x, old = [x], None
+            for i in range(n_steps):
+                net_out = eng.denoise(cf[i, 0] * x, cemb, samples_per_cond, timesteps=ts[i:i + 1], temb=temb)
+                den = cf[i, 1] * x + cf[i, 2] * net_out
+                if clamp:
+                    den = den.clamp(-1.0, 1.0)
+                d = den if (coef[i, 7] == 0 or old is None) else cf[i, 3] * den + cf[i, 4] * old
+                old = den
+                x = cf[i, 5] * x - cf[i, 6] * d
+                all_x.append(x)
+            return x, all_x
         out = eng.denoise(x, cemb, samples_per_cond, timesteps=ts, sched_kind=SCHED_DPMPP, clip_sample=clamp,
                           coef=coef.to(device), temb=temb)
         return out, [x]

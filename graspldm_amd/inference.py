@@ -144,10 +144,9 @@ class InferenceLDM(_InferenceBase):
             default_steps = 100 if not use_elucidated else 32
             self.num_inference_steps = default_steps if num_inference_steps is None else num_inference_steps
         else:
-            if use_elucidated:
-                raise NotImplementedError("the elucidated model is sampled with DPM++ only (use_fast_sampler=True): the "
-                                          "stochastic Heun sampler is not built")
-            self.fast_sampler, self.num_inference_steps = None, num_inference_steps
+            # elucidated + no fast sampler: ElucidatedDiffusion.sample(use_dpmpp=False) = the stochastic Heun sampler
+            # (elucidated_diffusion.py:177-257), one network launch per evaluation
+            self.fast_sampler, self.num_inference_steps = ("HEUN" if use_elucidated else None), num_inference_steps
         if model is not None:
             self.model = model.to(self.device).eval()
         else:
@@ -167,6 +166,11 @@ class InferenceLDM(_InferenceBase):
             extra_sampler = dict(use_dpmpp=True, num_sample_steps=self.num_inference_steps)
             if "noise" in kwargs:
                 extra_sampler["noise"] = kwargs["noise"]
+        elif self.fast_sampler == "HEUN":
+            extra_sampler = dict(use_dpmpp=False)
+            if self.num_inference_steps is not None:
+                extra_sampler["num_sample_steps"] = self.num_inference_steps
+            extra_sampler.update({k: kwargs[k] for k in ("noise",) if k in kwargs})
         elif self.num_inference_steps is not None:
             self.model.set_inference_timesteps(self.num_inference_steps)
         if return_intermediate and batch.shape[0] > 1:  # the reference raises after sampling; fail before the work

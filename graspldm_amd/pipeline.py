@@ -1,5 +1,5 @@
 """Convenience constructors for the shipped `fpc` experiment with synthetic weights
-(no checkpoints exist offline) and the smoke check used by __graft_entry__."""
+(no checkpoints exist offline)."""
 import torch
 
 from .builder import build_model_from_cfg
@@ -36,21 +36,3 @@ def build_fpc_ldm(n_points=1024, scheduler="ddim", seed=0, device=None, **kw):
     ldm.eval()
     return ldm.to(device) if device is not None else ldm
 
-
-def smoke_check(device="cuda:0"):
-    """One tiny LDM generation (1 cloud, 4 grasps, 10 DDIM steps) on the HIP path, checked
-    against the torch-CPU oracle on the same inputs, weights and noise."""
-    from oracle import torch_ref as R  # checker only
-    ldm = build_fpc_ldm(device=device)
-    ldm.set_inference_timesteps(10)
-    from .synthetic import synthetic_batch
-    pcs, metas = synthetic_batch(1, 1024)
-    x_T = torch.randn(4, 1, 4, generator=torch.Generator().manual_seed(7))
-    (tm, lg), _ = ldm.generate_grasps(pcs.to(device), num_grasps=4, x_T=x_T)
-    sd = {k: v.detach().cpu() for k, v in ldm.state_dict().items()}
-    sched = R.make_scheduler("ddim")
-    sched.set_timesteps(10)
-    etm, elg = R.ldm_generate(sd, pcs, 4, sched, R.pvcnn_block_spec(0.75, 0.75), x_T=x_T)
-    err = max((tm.cpu() - etm).abs().max().item(), (lg.cpu() - elg).abs().max().item())
-    assert err < 1e-4, f"smoke: HIP path deviates from the oracle by {err:.3e}"
-    return err

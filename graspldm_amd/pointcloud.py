@@ -140,3 +140,77 @@ def normalize_input(pc, pc_shift=PC_SHIFT, pc_scale=PC_SCALE, mrp_scale=MRP_SCAL
     metas = dict(pc_mean=pc_mean if pc.ndim == 3 else pc_mean[0], pc_std=sc.to(dev).unsqueeze(0),
                  grasp_mean=gm, grasp_std=gstd, dataset_normalized=True, use_dataset_statistics=False)
     return (out if pc.ndim == 3 else out[0]), metas
+
+
+def read_cloud_file(path):
+    """A sensor cloud from disk -> float32 numpy [N, 3] (metres, sensor / world frame).  `.npy` ([N,3] or [N,>=3]),
+    `.npz` (first of the keys pc / points / xyz / arr_0), `.ply` (ascii or binary_little_endian, vertex x y z) and
+    whitespace-separated text (`.xyz`, `.txt`, `.pts`).  The reference's CLI only iterates dataset items
+    (tools/generate_grasps.py:109-131); `generate_on_pointcloud` (inference_base.py:161-212) is its entry point for
+    such clouds, this is the file front of it."""
+    ext = path.rsplit(".", 1)[-1].lower() if "." in path else ""
+    if ext == "npy":
+        a = np.load(path)
+    elif ext == "npz":
+        with np.load(path) as z:
+            key = next((k for k in ("pc", "points", "xyz", "arr_0") if k in z.files), None)
+            if key is None:
+                raise ValueError(f"{path}: none of the arrays pc / points / xyz / arr_0 found (has {z.files})")
+            a = z[key]
+    elif ext == "ply":
+        a = _read_ply_vertices(path)
+    elif ext in ("xyz", "txt", "pts", "csv"):
+        a = np.loadtxt(path, delimiter="," if ext == "csv" else None, ndmin=2)
+    else:
+        raise ValueError(f"{path}: unknown cloud format (.npy .npz .ply .xyz .txt .pts .csv)")
+    a = np.asarray(a)
+    if a.ndim != 2 or a.shape[1] < 3 or a.shape[0] == 0:
+        raise ValueError(f"{path}: expected an [N, 3] array of points, got {a.shape}")
+    a = a[:, :3].astype(np.float32)
+    if not np.isfinite(a).all():
+        a = a[np.isfinite(a).all(axis=1)]   # depth cameras mark invalid pixels with NaN / inf
+    return np.ascontiguousarray(a)
+
+
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2",
+              "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4",
+              "double": "f8", "float64": "f8"}
+
+
+def _read_ply_vertices(path):
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, n_vert, props, in_vertex = None, 0, [], False
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: PLY header has no end_header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok:
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                in_vertex = tok[1] == "vertex"
+                if in_vertex:
+                    n_vert = int(tok[2])
+                elif not props:
+                    raise ValueError(f"{path}: an element precedes `vertex`; not supported")
+            elif tok[0] == "property" and in_vertex:
+                if tok[1] == "list":
+                    raise ValueError(f"{path}: list property on vertices is not supported")
+                props.append((tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == "end_header":
+                break
+        names = [p[0] for p in props]
+        if not all(k in names for k in ("x", "y", "z")):
+            raise ValueError(f"{path}: vertex element has no x / y / z")
+        if fmt == "ascii":
+            rows = np.loadtxt(f, max_rows=n_vert, ndmin=2)
+            return np.stack([rows[:, names.index(k)] for k in ("x", "y", "z")], axis=1)
+        if fmt != "binary_little_endian":
+            raise ValueError(f"{path}: PLY format {fmt!r} is not supported (ascii, binary_little_endian)")
+        dt = np.dtype([(n, "<" + t) for n, t in props])
+        v = np.frombuffer(f.read(dt.itemsize * n_vert), dtype=dt, count=n_vert)
+        return np.stack([v["x"], v["y"], v["z"]], axis=1)

@@ -53,6 +53,11 @@ def test_fused_dpmpp_golden(fpc_state_dict, name, clamp):
                          noise=g["noise"])
     assert (x.cpu() - g["x_" + name]).abs().max() < 1e-4, (x.cpu() - g["x_" + name]).abs().max()
     assert torch.allclose(first[0].cpu(), 80.0 * g["noise"], rtol=1e-6)
+    # return_all=True (elucidated_diffusion.py:306: every x is kept): the per-step form, same bits as the fused launch
+    x2, trace = ed.sample(use_dpmpp=True, batch_size=8, z_cond=g["z_cond"].cuda(), num_sample_steps=20, clamp=clamp,
+                          noise=g["noise"], return_all=True)
+    assert len(trace) == 21 and torch.equal(trace[-1], x2)
+    assert (x2 - x).abs().max() <= 1e-6, (x2 - x).abs().max()
 
 
 @pytest.mark.gpu
@@ -111,8 +116,16 @@ def test_inference_ldm_elucidated_mode(fpc_state_dict):
     b = inf.generate_grasps(pcs, metas, num_grasps=5, noise=noise)
     assert a["grasps"].shape == (1, 5, 4, 4) and torch.isfinite(a["grasps"]).all()
     assert (a["grasps"] - b["grasps"]).abs().max() < 1e-5
-    with pytest.raises(NotImplementedError):
-        InferenceLDM(model=ldm, use_elucidated=True, use_fast_sampler=False, device="cuda:0")
+    # return_intermediate: the reference decodes 50 of the per-step latents (grasp_ldm.py:223-227)
+    c = inf.generate_grasps(pcs, metas, num_grasps=5, noise=noise, return_intermediate=True)
+    assert len(c["all_steps_grasps"]) == 50 and (c["grasps"] - a["grasps"]).abs().max() < 1e-5
+    assert (c["all_steps_grasps"][-1].cuda() - c["grasps"]).abs().max() < 1e-5
+    # use_fast_sampler=False: the stochastic Heun sampler (elucidated_diffusion.py:177-257)
+    heun = InferenceLDM(model=ldm, use_elucidated=True, use_fast_sampler=False, num_inference_steps=6, device="cuda:0")
+    assert heun.fast_sampler == "HEUN"
+    torch.manual_seed(1)
+    h = heun.generate_grasps(pcs, metas, num_grasps=5, noise=noise)
+    assert h["grasps"].shape == (1, 5, 4, 4) and torch.isfinite(h["grasps"]).all()
 
 
 @pytest.mark.gpu

@@ -3,7 +3,9 @@
 (--exp_path --data_root --mode --split --num_grasps --visualize --no_ema --num_samples
 --conditioning --condition_value --inference_steps) on the MI355X path.
 
-Additive flags: --device, --seed, --synthetic N (run on N-point synthetic object clouds with
+Additive flags: --pc_file FILE [--num_points N] (generate on a sensor cloud read from .npy / .npz / .ply / .xyz:
+the reference's `generate_on_pointcloud`, grasp_ldm/inference/inference_base.py:161-212, which its own CLI does not
+reach -- it only iterates ACRONYM items, tools/generate_grasps.py:109-131), --device, --seed, --synthetic N (run on N-point synthetic object clouds with
 the synthetic weight recipe when no experiment directory / ACRONYM data is available; there is
 no network here for either), --out FILE.npz.  `--inference_steps` is honoured (the reference
 silently ignores it: it passes use_fast_sampler=False, tools/generate_grasps.py:69-79).
@@ -37,6 +39,13 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=None)
     p.add_argument("--synthetic", type=int, default=0, metavar="N",
                    help="use N-point synthetic clouds and synthetic weights (no experiment dir needed)")
+    p.add_argument("--pc_file", type=str, action="append", default=None, metavar="FILE",
+                   help="generate on this raw cloud ([N,3], metres; .npy .npz .ply .xyz); may be repeated. The cloud is "
+                        "brought to the encoder's point count and normalised like generate_on_pointcloud does")
+    p.add_argument("--num_points", type=int, default=None,
+                   help="encoder point count for --pc_file (default: the model's pc encoder n_points)")
+    p.add_argument("--random_resample", action="store_true",
+                   help="with --pc_file: random subsampling instead of farthest-point selection")
     p.add_argument("--out", type=str, default=None, help="write results of all samples to this .npz")
     return p.parse_args(argv)
 
@@ -74,19 +83,45 @@ def main(argv=None):
     model = setup_model(args)
     from graspldm_amd.synthetic import normalize_cloud, synthetic_cloud
     results = []
+    if args.pc_file:
+        from graspldm_amd.pointcloud import read_cloud_file
+        n_pts = args.num_points or encoder_points(model.model)
+        for path in args.pc_file:
+            pc = torch.from_numpy(read_cloud_file(path))
+            res = model.infer_on_pointcloud(pc, num_grasps=args.num_grasps, num_points=n_pts,
+                                            use_farthest_point=not args.random_resample)
+            conf = res["confidence"].flatten()
+            print(f"{path}: {pc.shape[0]} points -> {n_pts}; grasps {tuple(res['grasps'].shape)}  "
+                  f"confidence mean {conf.mean().item():.3f}  best {conf.max().item():.3f}")
+            results.append(res)
+        return finish(args, results)
     for i in range(args.num_samples):
         if args.synthetic:
             idx = int(np.random.randint(0, 1 << 20))
             pc, metas = normalize_cloud(synthetic_cloud(idx, args.synthetic))
             metas = {k: (v.unsqueeze(0) if isinstance(v, torch.Tensor) else v) for k, v in metas.items()}
         else:
-            raise SystemExit("ACRONYM dataset loading is out of scope; run with --synthetic N or call "
-                             "graspldm_amd.inference.InferenceLDM.generate_grasps(pc, metas) from Python")
+            raise SystemExit("ACRONYM dataset loading is out of scope: pass the object's cloud with --pc_file FILE "
+                             "(.npy / .ply / ...), or run on synthetic clouds with --synthetic N")
         res = model.generate_grasps(pc, metas, num_grasps=args.num_grasps)
         conf = res["confidence"].flatten()
         print(f"sample {i}: cloud #{idx}  grasps {tuple(res['grasps'].shape)}  "
               f"confidence mean {conf.mean().item():.3f}  best {conf.max().item():.3f}")
         results.append(res)
+    return finish(args, results)
+
+
+def encoder_points(model):
+    """n_points of the model's cloud encoder (its out_layer[1] is a Linear over the point axis: N is fixed)."""
+    vae = getattr(model, "vae_model", model)
+    enc = vae.encoder.pc_encoder if hasattr(vae, "encoder") else vae.pc_encoder
+    try:
+        return int(enc.out_layer[1].in_features)
+    except (AttributeError, IndexError, TypeError):
+        raise SystemExit("cannot infer the encoder's point count; pass --num_points")
+
+
+def finish(args, results):
     if args.out:
         np.savez_compressed(args.out, grasps=torch.cat([r["grasps"] for r in results]).cpu().numpy(),
                             grasp_tmrp=torch.cat([r["grasp_tmrp"] for r in results]).cpu().numpy(),
