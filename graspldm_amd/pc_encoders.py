@@ -113,7 +113,10 @@ class PVCNN2Encoder(PVCNNEncoder):
     """The reference's PVCNN2Encoder cannot be constructed (it forwards scale_channels /
     num_blocks / ... to PVCNN2.__init__, which does not accept them: pc_encoders.py:188-197 vs
     pvcnn_base.py:204-212).  This is the repaired form: same head, PVCNN2 (set-abstraction +
-    feature-propagation) backbone built from the arguments PVCNN2 does take."""
+    feature-propagation) backbone.  The two scale arguments mean what they mean for PVCNNEncoder and are mapped onto
+    the arguments PVCNN2 does take (scale_channels -> width_multiplier, scale_voxel_resolution ->
+    voxel_resolution_multiplier); the ones PVCNN2 has no counterpart for are rejected instead of silently dropped
+    (its block counts live in the class tables sa_blocks / fp_blocks, and it has no conditioning inputs)."""
 
     def __init__(self, in_features=3, out_features=32, n_points=1024, extra_feature_channels=0, scale_channels=0.25,
                  scale_voxel_resolution=0.75, num_blocks=(1, 1, 1, 1), is_conditioned=False, cond_dims=None,
@@ -121,5 +124,11 @@ class PVCNN2Encoder(PVCNNEncoder):
         nn.Module.__init__(self)
         if use_global_attention or use_local_attention:
             raise NotImplementedError("attention variants are not on the hot path")
-        self.pvcnn_modules = PVCNN2(extra_feature_channels=extra_feature_channels, use_attention=False)
+        if tuple(num_blocks) != (1, 1, 1, 1):
+            raise NotImplementedError("PVCNN2 fixes its block counts in sa_blocks / fp_blocks (pvcnn_base.py:186-202); "
+                                      f"num_blocks={tuple(num_blocks)} cannot be honoured")
+        if is_conditioned or cond_dims is not None or extra_block_channels is not None:
+            raise NotImplementedError("PVCNN2 takes no conditioning / extra block channels (pvcnn_base.py:204-212)")
+        self.pvcnn_modules = PVCNN2(extra_feature_channels=extra_feature_channels, width_multiplier=scale_channels,
+                                    voxel_resolution_multiplier=scale_voxel_resolution, use_attention=False)
         self._finish(in_features, out_features, n_points, out_channels)

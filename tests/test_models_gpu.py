@@ -399,3 +399,41 @@ def test_pointwise_mlp_rejects_unsupported_shapes():
     with pytest.raises(L.GldmError):                           # neither y nor a head
         L.call("gldm_pointwise_mlp", L.ptr(x), L.ptr(w), L.ptr(bias), 1, 64, 256, 64, 1, None, None, 0, None, None,
                L.current_stream(x.device))
+
+
+def test_pvcnn2_encoder_repaired_form():
+    """PVCNN2Encoder (the reference's cannot be constructed: SURVEY F2).  Backbone = PVCNN2 with the golden's weights
+    (pinned to the reference's graph by test_g8_pvcnn2_golden), head = conv_downscale -> out_layer (pc_encoders.py:
+    104-111) recomputed with torch on the CPU from the backbone's features; scale arguments are honoured or rejected."""
+    import torch.nn.functional as F
+    from graspldm_amd.pc_encoders import PVCNN2Encoder
+    from graspldm_amd.synthetic import synthetic_state_dict, synthetic_tensor
+    g = load_golden("pvcnn2.npz")
+    enc = PVCNN2Encoder(in_features=3, out_features=64, n_points=1024, scale_channels=1, scale_voxel_resolution=1,
+                        out_channels=3)
+    bb_sd = synthetic_state_dict(load_schema("schema_pvcnn2.json"), seed=4)
+    enc.pvcnn_modules.load_state_dict(bb_sd, strict=True)
+    head = {k: synthetic_tensor("enc2." + k, v.shape, seed=6) for k, v in enc.state_dict().items()
+            if not k.startswith("pvcnn_modules.")}
+    enc.load_state_dict({**{"pvcnn_modules." + k: v for k, v in bb_sd.items()}, **head}, strict=True)
+    enc = enc.cuda().eval()
+    pc = g["coords"].transpose(1, 2).contiguous()          # [1, N, 3]
+    with torch.no_grad():
+        z = enc(pc.cuda())
+        feat = enc.pvcnn_modules(g["coords"].cuda())
+    assert _err(feat[:, :, ::16], g["out"]) < 1e-4         # same backbone as the golden
+    f = feat.cpu().double()
+    h = F.conv1d(f, head["conv_downscale.weight"].double(), head["conv_downscale.bias"].double())
+    h = F.conv1d(h, head["out_layer.0.weight"].double(), head["out_layer.0.bias"].double())
+    exp = F.linear(h, head["out_layer.1.weight"].double(), head["out_layer.1.bias"].double()).float()
+    assert z.shape == (1, 3, 64) and _err(z, exp) < 5e-5, _err(z, exp)
+    # half width / half resolution builds and runs (the reference's benchmark setting); foreign arguments are rejected
+    small = PVCNN2Encoder(out_features=16, n_points=1024, scale_channels=0.5, scale_voxel_resolution=0.5).cuda().eval()
+    assert small.pvcnn_modules.out_channels == 32
+    with torch.no_grad():
+        zs = small(pc.cuda())
+    assert zs.shape == (1, 16) and torch.isfinite(zs).all()
+    with pytest.raises(NotImplementedError):
+        PVCNN2Encoder(num_blocks=(2, 1, 1, 1))
+    with pytest.raises(NotImplementedError):
+        PVCNN2Encoder(is_conditioned=True, cond_dims=8)
