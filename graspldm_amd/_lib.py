@@ -9,7 +9,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libgldm_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GldmError(RuntimeError):

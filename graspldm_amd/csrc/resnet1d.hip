@@ -375,6 +375,121 @@ __device__ __forceinline__ void gemm_fast_tap3(const Ctx &c, const float *__rest
         acc[mi][ni][r] += tap_left<L>(side[0][mi][ni][r], keepL) + tap_right<L>(side[1][mi][ni][r], keepR);
 }
 
+
+// ---- split-bf16 GEMM core of the position-major engine -------------------------------------------------------
+// f32 matrix products on the bf16 matrix pipe.  v_mfma_f32_16x16x32_bf16 delivers 16x the FLOP/cycle of
+// v_mfma_f32_16x16x4_f32, so an f32 product computed EXACTLY ENOUGH from bf16 pieces still wins: every f32 operand
+// is written as hi + mid + lo, three bf16 numbers (8 significant bits each cover the 24 of an f32: the split is
+// exact), and a product a b is the sum of the partial products of weight >= 2^-16,
+//   a b ~ a_hi b_lo + a_lo b_hi + a_mid b_mid + a_hi b_mid + a_mid b_hi + a_hi b_hi      (six MFMAs, f32 accumulation),
+// the dropped ones (mid lo, lo mid, lo lo) being <= 2^-23 |a b|: the size of one f32 rounding.  6/16 of the f32-MFMA
+// time.  Weights are split once on the host (r1d_pack.py: mfma_a_fragments_bf16x3, layout in gldm.h); activations
+// are split as they are read from LDS (f32 there, like everywhere in the engine): 44 VALU instructions per 8
+// values, which issue in the shadow of the MFMAs they feed (a B fragment of a k = 3 conv serves 3 taps x MT m-tiles).
+// Measured against the reference's vectors: single forwards 5e-7 from the f32 graph, 100 DDIM steps 1.2e-6
+// (tools/study/bf16x3_error.py), well inside the 2e-5 / 1e-4 parity bars.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: element 0 in the low half
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+// x[0..7] (consecutive k of one column) -> the three planes of a B fragment
+__device__ __forceinline__ void split_bf16x3(const float (&x)[8], u32x4 (&pl)[3]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = x[2 * q], b = x[2 * q + 1];
+    const unsigned h = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    pl[0][q] = h;
+    pl[1][q] = m;
+    pl[2][q] = cvt_pk_bf16(sa, sb);
+  }
+}
+__device__ __forceinline__ f32x4 mfma_bf(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc += A B with both operands split: small terms first
+__device__ __forceinline__ f32x4 mfma_split6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 acc) {
+  acc = mfma_bf(a[0], b[2], acc);
+  acc = mfma_bf(a[2], b[0], acc);
+  acc = mfma_bf(a[1], b[1], acc);
+  acc = mfma_bf(a[0], b[1], acc);
+  acc = mfma_bf(a[1], b[0], acc);
+  return mfma_bf(a[0], b[0], acc);
+}
+
+// Position-major k = 3 conv (see gemm_pm3 below for the tile algebra) on split-bf16 operands.  wp3: split fragments
+// of [Cout x 3 Cin], k = tap * Cin + ci, 32-deep k-blocks (Cin % 32 == 0).  One set of A registers per tap: the
+// moment a tap's MFMAs have issued, its registers are refilled with the next channel block's fragments of that tap,
+// which then have the two other taps' MFMAs (and the partner wave's) to arrive.  The raw f32 B values of the next
+// block are read from LDS while the current block's MFMAs run and split at the top of the next trip.
+template <int MT, int P0, int NP>
+__device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restrict__ wp3, int cin, int mt0,
+                                            const float *src, f32x4 (&acc)[MT][NP]) {
+  constexpr int NC = 64;
+  constexpr int PB0 = P0 > 0 ? P0 - 1 : 0, PB1 = P0 + NP < 4 ? P0 + NP : 3, NB = PB1 - PB0 + 1;
+  const int col = c.lane & 15, g = c.lane >> 4;
+  const int kb32 = cin >> 5, kblocks = 3 * kb32;
+  const WStream wv(wp3, c.lane);
+  const lds_f *src3 = (const lds_f *)src;
+  // rows 32 kb + 8 g + j, j = 0..7, of the column (16 (PB0 + q) + col); the row-parity swizzle moves odd rows to the
+  // neighbouring position tile: one base for even j and one for odd j per tile
+  int be[NB], bo[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    be[q] = swz<NC>(8 * g, 16 * (PB0 + q) + col);
+    bo[q] = swz<NC>(8 * g + 1, 16 * (PB0 + q) + col) - NC;
+  }
+  u32x4 a[3][MT][3];
+  float raw[NB][8];
+  auto load_a = [&](int t, int kb) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[t][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kblocks + t * kb32 + kb) * 3 + pl) * 64);
+  };
+  auto load_raw = [&](int kb) {
+    const lds_f *s = src3 + kb * 32 * NC;
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[q][j] = s[((j & 1) ? bo[q] : be[q]) + j * NC];
+  };
+#pragma unroll
+  for (int t = 0; t < 3; ++t) load_a(t, 0);
+  load_raw(0);
+  const int last = kb32 - 1;
+  for (int kb = 0; kb < kb32; ++kb) {
+    const int nb = kb < last ? kb + 1 : last;  // clamped: every load stays unconditional
+    u32x4 bs[NB][3];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) split_bf16x3(raw[q], bs[q]);
+    load_raw(nb);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int sp = P0 + p + t - 1;  // source position of this tap for out tile P0 + p
+          if (sp >= 0 && sp <= 3) {
+            const int qi = sp - PB0 < 0 ? 0 : (sp - PB0 >= NB ? NB - 1 : sp - PB0);
+            acc[mi][p] = mfma_split6(a[t][mi], bs[qi], acc[mi][p]);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(t, nb);
+    }
+  }
+}
+
 // ---- position-major k = 3 convs (L = 4 positions, 64-column tiles of 16 samples) ----------------------
 // Column = 16 * position + sample, so a 16-column n-tile is ONE position of all 16 samples and the conv is
 //   out_tile[p] = W1 * X_tile[p] + W0 * X_tile[p - 1] + W2 * X_tile[p + 1]      (tiles outside 0..3 do not exist)
@@ -842,7 +957,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
 #pragma unroll
     for (int p = 0; p < NP; ++p) acc[mi][p] = bv;
   }
-  gemm_pm3<MT, P0, NP>(c, wp, cin >> 4, mt0, src, acc);
+  gemm_pm3_bf<MT, P0, NP>(c, wp, cin, mt0, src, acc);
   if (g.mode && !kEarly) load_params();
   if (!g.mode) {
     if (alias) __syncthreads();
@@ -1924,9 +2039,10 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
            last_of_pair ? 1 : 0);
       return;
     }
-    emit(OP_CONV, rb.c1_w, rb.c1_b, X, H, C, C, 3 | (1 << 9) | ((toff >> 2) << kFlagTabShift), rb.n1_w, rb.n1_b, rb.ss_w,
-         rb.ss_b);
-    emit(OP_CONV, rb.c2_w, rb.c2_b, H, X, C, C, 3 | (2 << 9), rb.n2_w, rb.n2_b, -1, 0);  // X += act(GN(conv(H)))
+    // the position-major engine reads the split-bf16 copies of the conv weights (gemm_pm3_bf)
+    emit(OP_CONV, NC == 64 ? rb.c1_w3 : rb.c1_w, rb.c1_b, X, H, C, C, 3 | (1 << 9) | ((toff >> 2) << kFlagTabShift), rb.n1_w,
+         rb.n1_b, rb.ss_w, rb.ss_b);
+    emit(OP_CONV, NC == 64 ? rb.c2_w3 : rb.c2_w, rb.c2_b, H, X, C, C, 3 | (2 << 9), rb.n2_w, rb.n2_b, -1, 0);  // X += act(GN(conv(H)))
   };
   // constant indices only: a dynamically indexed kernel argument is copied to scratch memory
 #pragma unroll
@@ -1959,7 +2075,7 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
         emit(OP_CONV, v.out_w, v.out_b, Oa, Y, kHidden, C, 1);
         emit(OP_LN, Y, -1, X, C, v.ln2_g);
       }
-      emit(OP_CONV, v.down_w, v.down_b, X, X, C, Cn, 3 | kFlagAlias);
+      emit(OP_CONV, (NC == 64 && C >= 32) ? v.down_w3 : v.down_w, v.down_b, X, X, C, Cn, 3 | kFlagAlias);
     }
   }
 #pragma unroll
@@ -2462,6 +2578,11 @@ bool pm_supported(const gldm_r1d_desc *d) {
   if (d->dims[0] != 4) return false;
   for (int i = 0; i < d->n_levels; ++i)  // to_qkv with the PreNorm gain folded in (ABI 4 packers provide it)
     if (d->lv[i].qkvn_w <= 0 || d->lv[i].qkvn_s <= 0) return false;
+  for (int i = 1; i < d->n_levels; ++i)  // split-bf16 conv weights (ABI 5 packers provide them)
+    if (d->lv[i].down_w3 <= 0 || d->rb[2 * i].c1_w3 <= 0 || d->rb[2 * i].c2_w3 <= 0 || d->rb[2 * i + 1].c1_w3 <= 0 ||
+        d->rb[2 * i + 1].c2_w3 <= 0)
+      return false;
+  if (d->rb[2 * d->n_levels].c1_w3 <= 0 || d->rb[2 * d->n_levels].c2_w3 <= 0) return false;
   for (int i = 1; i <= d->n_levels; ++i) {
     const int C = d->dims[i];
     if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false;

@@ -22,13 +22,14 @@ SCHED_COEF_STRIDE = 8
 
 class R1dResblock(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("c1_w", "c1_b", "n1_w", "n1_b", "c2_w", "c2_b", "n2_w", "n2_b", "ss_w", "ss_b")]
+                ("c1_w", "c1_b", "n1_w", "n1_b", "c2_w", "c2_b", "n2_w", "n2_b", "ss_w", "ss_b", "c1_w3", "c2_w3")]
 
 
 class R1dLevel(ctypes.Structure):
     _fields_ = [("ln_g", ctypes.c_int32), ("qkv_w", ctypes.c_int32 * 2), ("out_w", ctypes.c_int32),
                 ("out_b", ctypes.c_int32), ("ln2_g", ctypes.c_int32), ("down_w", ctypes.c_int32),
-                ("down_b", ctypes.c_int32), ("qkvn_w", ctypes.c_int32), ("qkvn_s", ctypes.c_int32)]
+                ("down_b", ctypes.c_int32), ("qkvn_w", ctypes.c_int32), ("qkvn_s", ctypes.c_int32),
+                ("qkvn_w3", ctypes.c_int32), ("out_w3", ctypes.c_int32), ("down_w3", ctypes.c_int32)]
 
 
 class R1dDesc(ctypes.Structure):
@@ -53,6 +54,32 @@ def mfma_a_fragments(w2d):
     wp[:m, :k] = w2d
     wp = wp.view(mt, 16, kb, 4, 4)            # (mt, i, kb, j, kq):  k = 16 kb + 4 j + kq
     return wp.permute(0, 2, 4, 1, 3).contiguous().reshape(-1)   # (mt, kb, kq, i, j): lane = 16 kq + i
+
+
+def split_bf16x3(w):
+    """f32 -> (hi, mid, lo) bf16 with hi + mid + lo == w exactly (round to nearest at each stage)."""
+    w = w.detach().float()
+    hi = w.to(torch.bfloat16)
+    r = w - hi.float()
+    mid = r.to(torch.bfloat16)
+    lo = (r - mid.float()).to(torch.bfloat16)
+    return hi, mid, lo
+
+
+def mfma_a_fragments_bf16x3(w2d):
+    """[M, K] (K % 32 == 0) -> f32-typed bit container of the split-bf16 A fragments of v_mfma_f32_16x16x32_bf16:
+    [M/16][K/32][plane hi|mid|lo][lane 64][8 bf16], lane l = W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + j]
+    (include/gldm.h).  768 floats per (m-tile, 32-deep k-block)."""
+    m, k = w2d.shape
+    if k % 32:
+        raise ValueError("split-bf16 fragments need K % 32 == 0")
+    mt = (m + 15) // 16
+    wp = torch.zeros(mt * 16, k, dtype=torch.float32)
+    wp[:m] = w2d
+    planes = torch.stack(split_bf16x3(wp))                         # [3, M, K] bf16
+    planes = planes.view(3, mt, 16, k // 32, 4, 8)                 # (plane, mt, i, kb, g, j): k = 32 kb + 8 g + j
+    frag = planes.permute(1, 3, 0, 4, 2, 5).contiguous()           # (mt, kb, plane, g, i, j): lane = 16 g + i
+    return frag.reshape(-1, 8).view(torch.float32).reshape(-1)     # bit pattern kept: 8 bf16 = 4 floats
 
 
 def conv_as_gemm(w):
@@ -125,6 +152,10 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
         comb[:c] = comb[:c] + cond_rows                                 # sum_r (scale_r + 1)
         rb.ss_w = buf.add(mfma_a_fragments(mw))
         rb.ss_b = buf.add(comb)
+        w1, w2 = (conv_as_gemm(weight_standardize(sd[q + f"block{i}.proj.weight"])) for i in (1, 2))
+        if c % 32 == 0:   # split-bf16 copies for the position-major engine (K = 3 C is then a multiple of 32 per tap)
+            rb.c1_w3 = buf.add(mfma_a_fragments_bf16x3(w1))
+            rb.c2_w3 = buf.add(mfma_a_fragments_bf16x3(w2))
         rb.c1_w = buf.add(mfma_a_fragments(conv_as_gemm(weight_standardize(sd[q + "block1.proj.weight"]))))
         rb.c1_b = buf.add(sd[q + "block1.proj.bias"])
         rb.n1_w = buf.add(sd[q + "block1.norm.weight"])
@@ -161,6 +192,10 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
         lv.out_b = buf.add(sd[q + "2.fn.fn.to_out.0.bias"])
         lv.ln2_g = buf.add(sd[q + "2.fn.fn.to_out.1.g"])
         lv.down_w = buf.add(mfma_a_fragments(conv_as_gemm(sd[q + "3.weight"])))
+        if c % 32 == 0:
+            lv.qkvn_w3 = buf.add(mfma_a_fragments_bf16x3(wn))
+            lv.down_w3 = buf.add(mfma_a_fragments_bf16x3(conv_as_gemm(sd[q + "3.weight"])))
+        lv.out_w3 = buf.add(mfma_a_fragments_bf16x3(sd[q + "2.fn.fn.to_out.0.weight"][:, :, 0]))
         lv.down_b = buf.add(sd[q + "3.bias"])
     resblock(p + "final_res_block.", dims[-1], slot)
     fw = sd[p + "final_conv.weight"]

@@ -152,6 +152,8 @@ typedef struct gldm_r1d_resblock {
   int32_t n2_w, n2_b;   /* block2.norm                                            */
   int32_t ss_w, ss_b;   /* mlp.1 as a [2C x E] GEMM (packed A fragments) and the
                            combined bias R*b (+R on the C scale rows): [2C]       */
+  int32_t c1_w3, c2_w3; /* ABI 5: the two conv weights again as SPLIT-bf16 fragments (see below);
+                           0 = absent                                              */
 } gldm_r1d_resblock;
 
 typedef struct gldm_r1d_level {
@@ -164,7 +166,16 @@ typedef struct gldm_r1d_level {
                            row order (q | k | v, head h at rows 32 h of each third): 384 x C packed;
                            0 / negative = absent (the position-major engine is then not used)       */
   int32_t qkvn_s;       /* ABI 4: row sums of W' [384] (the mean term of the folded LayerNorm)     */
+  int32_t qkvn_w3, out_w3, down_w3; /* ABI 5: qkvn_w / out_w / down_w as split-bf16 fragments; 0 = absent */
 } gldm_r1d_level;
+
+/* Split-bf16 weight fragments (ABI 5; graspldm_amd/r1d_pack.py: mfma_a_fragments_bf16x3).  Every f32 weight is
+ * written as hi + mid + lo, three bf16 numbers (exact: 3 x 8 significant bits cover the 24 of an f32); the matrix
+ * [M, K] (K % 32 == 0) is stored as [M/16][K/32][plane hi|mid|lo][lane 64][8 bf16], lane l holding
+ * W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + j], j = 0..7: the A operand of v_mfma_f32_16x16x32_bf16.  The
+ * position-major engine computes every f32 product as the six partial products of weight >= 2^-16
+ * (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) on the bf16 matrix pipe with f32 accumulation: the dropped terms
+ * are <= 2^-23 of |a||b| per product, the order of an f32 rounding, at 6/16 of the f32-MFMA time. */
 
 typedef struct gldm_r1d_desc {
   int32_t seq_len;      /* L: 4 (latent denoiser) or 16 (pose decoder)            */
