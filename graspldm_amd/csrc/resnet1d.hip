@@ -96,6 +96,12 @@ static_assert(Geo<32>::kLdsFloats * 4 * 2 <= 160 * 1024, "LDS budget (2 WG/CU)")
 template <int NC>
 __device__ __forceinline__ int swz(int row, int col) { return row * NC + (col ^ ((row & 1) << 4)); }
 
+// Position-major engine (64 columns, split-bf16 GEMMs): a B fragment of v_mfma_f32_16x16x32_bf16 is rows 8 g + j
+// (g = lane >> 4, j = 0..7) of one column per lane, so the four lane groups of a read sit 8 rows apart in the same
+// columns.  XOR-ing the column's position tile with bits 3-4 of the row sends them to four different 16-bank groups:
+// every B read is conflict free, with ONE lane base per tile (the XOR does not depend on j or on the 32-row block).
+__device__ __forceinline__ int pswz(int row, int col) { return row * 64 + (col ^ (((row >> 3) & 3) << 4)); }
+
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 
@@ -437,14 +443,10 @@ __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restric
   const int kb32 = cin >> 5, kblocks = 3 * kb32;
   const WStream wv(wp3, c.lane);
   const lds_f *src3 = (const lds_f *)src;
-  // rows 32 kb + 8 g + j, j = 0..7, of the column (16 (PB0 + q) + col); the row-parity swizzle moves odd rows to the
-  // neighbouring position tile: one base for even j and one for odd j per tile
-  int be[NB], bo[NB];
+  // rows 32 kb + 8 g + j, j = 0..7, of the column (16 (PB0 + q) + col): one lane base per tile (pswz)
+  int b0[NB];
 #pragma unroll
-  for (int q = 0; q < NB; ++q) {
-    be[q] = swz<NC>(8 * g, 16 * (PB0 + q) + col);
-    bo[q] = swz<NC>(8 * g + 1, 16 * (PB0 + q) + col) - NC;
-  }
+  for (int q = 0; q < NB; ++q) b0[q] = pswz(8 * g, 16 * (PB0 + q) + col);
   u32x4 a[3][MT][3];
   float raw[NB][8];
   auto load_a = [&](int t, int kb) {
@@ -459,7 +461,7 @@ __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restric
 #pragma unroll
     for (int q = 0; q < NB; ++q)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) raw[q][j] = s[((j & 1) ? bo[q] : be[q]) + j * NC];
+      for (int j = 0; j < 8; ++j) raw[q][j] = s[b0[q] + j * NC];
   };
 #pragma unroll
   for (int t = 0; t < 3; ++t) load_a(t, 0);
@@ -486,6 +488,54 @@ __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restric
         }
       __builtin_amdgcn_sched_barrier(0);
       load_a(t, nb);
+    }
+  }
+}
+
+
+// 1x1 conv / plain GEMM on split-bf16 operands (position-major engine): MT m-tiles x NT n-tiles of
+// W[.. x 32 KB32] * src.  A fragments double buffered over the 32-deep k-blocks (the loop is fully unrolled: KB32 is
+// 1, 2 or 4); the raw B values of a tile are re-read for the next block right after they have been split.
+// pre(): work independent of the GEMM, run once the first loads are out (the folded LayerNorm's column statistics).
+template <int KB32, int MT, int NT, class PRE = NoPre>
+__device__ __forceinline__ void gemm1_bf(const Ctx &c, const float *__restrict__ wp3, int mt0, int nt0, const float *src,
+                                         f32x4 (&acc)[MT][NT], const PRE &pre = PRE()) {
+  constexpr int NC = 64;
+  const int col = c.lane & 15, g = c.lane >> 4;
+  const WStream wv(wp3, c.lane);
+  const lds_f *src3 = (const lds_f *)src;
+  int b0[NT];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) b0[ni] = pswz(8 * g, 16 * (nt0 + ni) + col);
+  u32x4 a[2][MT][3];
+  float raw[NT][8];
+  auto load_a = [&](int buf, int kb) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * KB32 + kb) * 3 + pl) * 64);
+  };
+  load_a(0, 0);
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[ni][j] = src3[b0[ni] + j * NC];
+  __builtin_amdgcn_sched_barrier(0);
+  pre();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kb = 0; kb < KB32; ++kb) {
+    if (kb + 1 < KB32) load_a((kb + 1) & 1, kb + 1);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      u32x4 bs[3];
+      split_bf16x3(raw[ni], bs);
+      if (kb + 1 < KB32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[ni][j] = src3[b0[ni] + (32 * (kb + 1) + j) * NC];
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = mfma_split6(a[kb & 1][mi], bs, acc[mi][ni]);
     }
   }
 }
@@ -922,7 +972,6 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
                                               const float *src, int cin, float *dst, int cout, bool alias,
                                               const GnEpilogue &g) {
   using GG = Geo<64>;
-  constexpr int NC = 64;
   const int kq = c.lane >> 4, sm = c.lane & 15;
   f32x4 acc[MT][NP];
   const bool has_ss = g.ss_w >= 0;
@@ -967,7 +1016,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) d3[swz<NC>(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm)] = acc[mi][p][r];
+        for (int p = 0; p < NP; ++p) d3[pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm)] = acc[mi][p][r];
     return;
   }
   // ---- this wave's share of the statistics, per sample (= lane & 15)
@@ -1055,7 +1104,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
         float y = (acc[mi][p][r] - mean) * gsc + be[mi][r];
         if (has_ss) y = y * sc[mi][r] + sh[mi][r];
         y = silu(y);
-        const int a = swz<NC>(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm);
+        const int a = pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm);
         d3[a] = g.mode == 2 ? d3[a] + y : y;
       }
     }
@@ -1066,13 +1115,12 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
 // MFMA's k order (tap major, channel minor) from the bias.  src may alias dst.
 __device__ __forceinline__ void conv_pm3_cin4(const Ctx &c, const float *wp, const float *bias, const float *src,
                                               float *dst, int cout, bool alias) {
-  constexpr int NC = 64;
   const int n = c.lane, p = n >> 4;
   const lds_f *s3 = (const lds_f *)src;
   float x[3][4];
 #pragma unroll
   for (int ci = 0; ci < 4; ++ci) {
-    const float l = s3[swz<NC>(ci, p > 0 ? n - 16 : n)], m = s3[swz<NC>(ci, n)], r = s3[swz<NC>(ci, p < 3 ? n + 16 : n)];
+    const float l = s3[pswz(ci, p > 0 ? n - 16 : n)], m = s3[pswz(ci, n)], r = s3[pswz(ci, p < 3 ? n + 16 : n)];
     x[0][ci] = p > 0 ? l : 0.f;
     x[1][ci] = m;
     x[2][ci] = p < 3 ? r : 0.f;
@@ -1105,7 +1153,7 @@ __device__ __forceinline__ void conv_pm3_cin4(const Ctx &c, const float *wp, con
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int co = rd * 32 + c.wave * 4 + k;
-      if (co < cout) d3[swz<NC>(co, n)] = out[rd][k];
+      if (co < cout) d3[pswz(co, n)] = out[rd][k];
     }
 }
 
@@ -1115,7 +1163,6 @@ __device__ __forceinline__ void conv_pm3_cin4(const Ctx &c, const float *wp, con
 // weight is wave uniform (scalar loads: nothing queues in the vector-memory path).
 __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInts], int E) {
   using GG = Geo<64>;
-  constexpr int NC = 64;
   if (c.wave != 0) return;
   const int n = c.lane, sm = n & 15, p = n >> 4;
   const bool has_l = p != 0, has_r = p != 3;
@@ -1126,7 +1173,7 @@ __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInt
             ss_w = o[9], ss_b = o[10];
   float x[4];
 #pragma unroll
-  for (int ci = 0; ci < 4; ++ci) x[ci] = X[swz<NC>(ci, n)];
+  for (int ci = 0; ci < 4; ++ci) x[ci] = X[pswz(ci, n)];
   float gq[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) gq[e] = e < E ? G[e] : 0.f;
@@ -1182,7 +1229,7 @@ __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInt
   conv3(y, c2_w, c2_b, z);
   gn_act(z, n2_w, n2_b, false);
 #pragma unroll
-  for (int co = 0; co < 4; ++co) X[swz<NC>(co, n)] = x[co] + z[co];
+  for (int co = 0; co < 4; ++co) X[pswz(co, n)] = x[co] + z[co];
 }
 
 // to_out of LinearAttention: Conv1d(128 -> C, k = 1) -> LayerNorm over the channels -> residual add
@@ -1206,7 +1253,7 @@ __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + row0);
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) acc[0][ni] = bv;
-    gemm_fast<NC, 4, 1, 1, NT>(c, wp, cin >> 4, mt0, nt0, src, acc);
+    gemm1_bf<kHidden / 32, 1, NT>(c, wp, mt0, nt0, src, acc);  // cin = 128: the attention's hidden width
     gv = *reinterpret_cast<const f32x4 *>(gain + row0);
     const float inv_n = __builtin_amdgcn_rcpf((float)nloc);
 #pragma unroll
@@ -1255,7 +1302,7 @@ __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (row0 + r < C) {
-          const int a = swz<NC>(row0 + r, cc);
+          const int a = pswz(row0 + r, cc);
           x3[a] = x3[a] + (acc[0][ni][r] - mean) * rstd * gv[r];
         }
     }
@@ -1279,13 +1326,12 @@ __device__ __forceinline__ void out_ln_pm(const Ctx &c, int w_off, int b_off, co
 // FMAs per lane against wave-uniform weights, fma chain in the MFMA's k order.  Replaces a 3-barrier LayerNorm pass
 // and padded K = 16 MFMA GEMMs.
 __device__ __forceinline__ void qkv4_pm(const Ctx &c, int w_off, const float *src, float *dst) {
-  constexpr int NC = 64;
   const int n = c.lane;
   const lds_f *s3 = (const lds_f *)src;
   lds_f *d3 = (lds_f *)dst;
   float x[4];
 #pragma unroll
-  for (int ci = 0; ci < 4; ++ci) x[ci] = s3[swz<NC>(ci, n)];
+  for (int ci = 0; ci < 4; ++ci) x[ci] = s3[pswz(ci, n)];
   const float mean = (x[0] + x[1] + x[2] + x[3]) * 0.25f;
   float vt = 0.f;
 #pragma unroll
@@ -1313,7 +1359,7 @@ __device__ __forceinline__ void qkv4_pm(const Ctx &c, int w_off, const float *sr
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(fv, q + 16 * k)), y[k], acc);
-      d3[swz<NC>(16 * (t0 + t) + q, n)] = acc;
+      d3[pswz(16 * (t0 + t) + q, n)] = acc;
     }
   }
   __syncthreads();
@@ -1335,7 +1381,7 @@ __device__ __forceinline__ void column_stats8(const Ctx &c, const float *src, fl
   float v[RP], sum = 0.f;
 #pragma unroll
   for (int i = 0; i < RP; ++i) {
-    v[i] = s3[swz<NC>(rp + 8 * i, n)];
+    v[i] = s3[pswz(rp + 8 * i, n)];
     sum += v[i];
   }
   auto all_parts = [](float x) {  // lanes differing in bits 3, 4, 5
@@ -1374,11 +1420,11 @@ __device__ __forceinline__ void qkv_ln_pm(const Ctx &c, int w_off, int s_off, co
   const int cblocks = C >> 4;
   const float inv_c = __builtin_amdgcn_rcpf((float)C);  // C: a power of two -> exact
   if (cblocks == 8) {
-    gemm_fast_pf<NC, 4, 1, MT, NT, 4>(c, wp, cblocks, mt0, 0, src, acc, [&]() { column_stats8<16>(c, src, inv_c); });
+    gemm1_bf<4, MT, NT>(c, wp, mt0, 0, src, acc, [&]() { column_stats8<16>(c, src, inv_c); });
   } else if (cblocks == 4) {
-    gemm_fast_pf<NC, 4, 1, MT, NT, 4>(c, wp, cblocks, mt0, 0, src, acc, [&]() { column_stats8<8>(c, src, inv_c); });
+    gemm1_bf<2, MT, NT>(c, wp, mt0, 0, src, acc, [&]() { column_stats8<8>(c, src, inv_c); });
   } else {
-    gemm_fast_pf<NC, 4, 1, MT, NT, 2>(c, wp, cblocks, mt0, 0, src, acc, [&]() { column_stats8<4>(c, src, inv_c); });
+    gemm1_bf<1, MT, NT>(c, wp, mt0, 0, src, acc, [&]() { column_stats8<4>(c, src, inv_c); });
   }
   __syncthreads();  // every column's (mean, rstd) is in LDS
   const lds_f *mean3 = (const lds_f *)(c.lds + GG::kMiscRed1), *rstd3 = (const lds_f *)(c.lds + GG::kMiscRed2);
@@ -1391,7 +1437,7 @@ __device__ __forceinline__ void qkv_ln_pm(const Ctx &c, int w_off, int s_off, co
     for (int mi = 0; mi < MT; ++mi) {
       const int row0 = 16 * (mt0 + mi) + 4 * kq, cf = 16 * ni + col;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) d3[swz<NC>(row0 + r, cf)] = acc[mi][ni][r] * rstd - mr * sv[mi][r];
+      for (int r = 0; r < 4; ++r) d3[pswz(row0 + r, cf)] = acc[mi][ni][r] * rstd - mr * sv[mi][r];
     }
   }
   __syncthreads();
@@ -1409,7 +1455,6 @@ __device__ __forceinline__ void qkv_ln_pm(const Ctx &c, int w_off, int s_off, co
 // a ds_read_b32 / ds_write_b32.  Phase 1's odd parts walk the positions in the order 1, 0, 3, 2 and phase 2's odd
 // parts walk their channels in that order: opposite row parity or column half, hence the other half of the banks.
 __device__ __forceinline__ void attention_quad_pm(const Ctx &c, float *qkv) {
-  constexpr int NC = 64;
   if (GLDM_SKIP(c, 4)) return;
   lds_f *q3 = (lds_f *)qkv;
   const int sm = c.lane & 15, pt = c.lane >> 4, odd = pt & 1;
@@ -1420,7 +1465,7 @@ __device__ __forceinline__ void attention_quad_pm(const Ctx &c, float *qkv) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) k[u][j] = q3[swz<NC>(row0 + u, (16 * j + sm) ^ cx)];
+      for (int j = 0; j < 4; ++j) k[u][j] = q3[pswz(row0 + u, (16 * j + sm) ^ cx)];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float km = fmaxf(fmaxf(k[u][0], k[u][1]), fmaxf(k[u][2], k[u][3]));
@@ -1428,7 +1473,7 @@ __device__ __forceinline__ void attention_quad_pm(const Ctx &c, float *qkv) {
       for (int j = 0; j < 4; ++j) k[u][j] = fast_exp(k[u][j] - km);
       const float inv = __builtin_amdgcn_rcpf(k[u][0] + k[u][1] + k[u][2] + k[u][3]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q3[swz<NC>(row0 + u, (16 * j + sm) ^ cx)] = k[u][j] * inv;
+      for (int j = 0; j < 4; ++j) q3[pswz(row0 + u, (16 * j + sm) ^ cx)] = k[u][j] * inv;
     }
   }
   const int d0 = kDimHead * head + 8 * pt;
@@ -1442,13 +1487,13 @@ __device__ __forceinline__ void attention_quad_pm(const Ctx &c, float *qkv) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        q[e][i] = q3[swz<NC>(qr + (i ^ odd), n0 + 16 * e)];
+        q[e][i] = q3[pswz(qr + (i ^ odd), n0 + 16 * e)];
         qmax[e] = fmaxf(qmax[e], q[e][i]);
       }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) vv[i][j] = q3[swz<NC>(vr + (i ^ odd), 16 * j + sm)];
+      for (int j = 0; j < 4; ++j) vv[i][j] = q3[pswz(vr + (i ^ odd), 16 * j + sm)];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       qmax[e] = half_max(row_pair_max(qmax[e]));
@@ -1470,7 +1515,7 @@ __device__ __forceinline__ void attention_quad_pm(const Ctx &c, float *qkv) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float kk = q3[swz<NC>(kr + (i ^ odd), 16 * j + sm)];
+      const float kk = q3[pswz(kr + (i ^ odd), 16 * j + sm)];
 #pragma unroll
       for (int e = 0; e < 2; ++e) a[e][j] = fmaf(kk, qe[e][i], a[e][j]);
     }
@@ -1484,7 +1529,7 @@ __device__ __forceinline__ void attention_quad_pm(const Ctx &c, float *qkv) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int e = 0; e < 2; ++e)
-      q3[swz<NC>(qr + (i ^ odd), n0 + 16 * e)] =
+      q3[pswz(qr + (i ^ odd), n0 + 16 * e)] =
           vv[i][0] * a[e][0] + vv[i][1] * a[e][1] + vv[i][2] * a[e][2] + vv[i][3] * a[e][3];
   __syncthreads();
 }
@@ -2059,7 +2104,7 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
       int Oa = O;
       if (NC == 64) {
         if (C == 4) emit(OP_QKV4, v.qkvn_w, X, QKV4H);
-        else emit(OP_QKVLN, v.qkvn_w, v.qkvn_s, X, QKV4H, C);
+        else emit(OP_QKVLN, v.qkvn_w3, v.qkvn_s, X, QKV4H, C);
         emit(OP_ATT, QKV4H);
         Oa = QKV4H;
       } else {
@@ -2070,7 +2115,7 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
         emit(OP_ATT, QKV, O + 64 * NC);
       }
       if (NC == 64 && (C == 4 || C == 32 || C == 64 || C == 128)) {  // to_out conv + LayerNorm + residual: one phase
-        emit(OP_OUTLN, v.out_w, v.out_b, Oa, X, kHidden, C, v.ln2_g);
+        emit(OP_OUTLN, v.out_w3, v.out_b, Oa, X, kHidden, C, v.ln2_g);
       } else {
         emit(OP_CONV, v.out_w, v.out_b, Oa, Y, kHidden, C, 1);
         emit(OP_LN, Y, -1, X, C, v.ln2_g);
@@ -2346,7 +2391,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
           acc += wk[q] * xv;
         }
       }
-      X[swz<NC>(ch, n)] = acc;
+      X[PM ? pswz(ch, n) : swz<NC>(ch, n)] = acc;
     }
     __syncthreads();
 
@@ -2358,7 +2403,8 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       float *red1 = lds + GG::kMiscRed1;
       const int n = c.lane & (NC - 1), slot = c.wave * GG::kRP + c.lane / NC;
       float part = 0.f;
-      for (int row = slot; row < CF; row += GG::kSlots) part += a.weights[d.final_w + row] * X[swz<NC>(row, n)];
+      for (int row = slot; row < CF; row += GG::kSlots)
+        part += a.weights[d.final_w + row] * X[PM ? pswz(row, n) : swz<NC>(row, n)];
       if (GG::kRP == 2) part = half_sum(part);
       red1[c.wave * NC + n] = part;
       __syncthreads();
@@ -2579,10 +2625,10 @@ bool pm_supported(const gldm_r1d_desc *d) {
   for (int i = 0; i < d->n_levels; ++i)  // to_qkv with the PreNorm gain folded in (ABI 4 packers provide it)
     if (d->lv[i].qkvn_w <= 0 || d->lv[i].qkvn_s <= 0) return false;
   for (int i = 1; i < d->n_levels; ++i)  // split-bf16 conv weights (ABI 5 packers provide them)
-    if (d->lv[i].down_w3 <= 0 || d->rb[2 * i].c1_w3 <= 0 || d->rb[2 * i].c2_w3 <= 0 || d->rb[2 * i + 1].c1_w3 <= 0 ||
+    if (d->lv[i].down_w3 <= 0 || d->lv[i].qkvn_w3 <= 0 || d->lv[i].out_w3 <= 0 || d->rb[2 * i].c1_w3 <= 0 || d->rb[2 * i].c2_w3 <= 0 || d->rb[2 * i + 1].c1_w3 <= 0 ||
         d->rb[2 * i + 1].c2_w3 <= 0)
       return false;
-  if (d->rb[2 * d->n_levels].c1_w3 <= 0 || d->rb[2 * d->n_levels].c2_w3 <= 0) return false;
+  if (d->rb[2 * d->n_levels].c1_w3 <= 0 || d->rb[2 * d->n_levels].c2_w3 <= 0 || d->lv[0].out_w3 <= 0) return false;
   for (int i = 1; i <= d->n_levels; ++i) {
     const int C = d->dims[i];
     if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false;
