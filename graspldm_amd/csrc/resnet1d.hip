@@ -102,6 +102,41 @@ __device__ __forceinline__ int swz(int row, int col) { return row * NC + (col ^ 
 // every B read is conflict free, with ONE lane base per tile (the XOR does not depend on j or on the 32-row block).
 __device__ __forceinline__ int pswz(int row, int col) { return row * 64 + (col ^ (((row >> 3) & 3) << 4)); }
 
+// Pre-split activation planes of the position-major engine (levels of up to 128 channels).  A tensor that is only ever
+// read as a GEMM B operand is kept in LDS already split into its three bf16 planes, in B-fragment order:
+//   [32-channel block kb][plane hi|mid|lo][g = 0..3][column 0..63][8 bf16 = channels 32 kb + 8 g + 0..7]
+// (12 KiB per 32 channels).  The producer's epilogue splits each element ONCE (its accumulators hold 4 consecutive
+// channels of a column: one ds_write_b64 per plane); the eight consumer waves read a whole fragment plane with one
+// ds_read_b128 per lane instead of eight ds_read_b32 + 36 VALU instructions of splitting each, and their k-loops are
+// loads + MFMA only.  At 256 channels the planes (96 KiB per tensor) do not fit beside the f32 residual stream: those
+// convs split their B values on the fly (two m-tiles per wave share every split there).
+constexpr int kPlaneH = 128 * 64;                 // H planes: floats [8192, 20480)  (the q|k|v block of the attention
+constexpr int kPlaneX = 128 * 64 + 128 * 96;      // X planes: floats [20480, 32768)  phases overlays both)
+constexpr int kPlaneMaxC = 128;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((address_space(3))) u32x4 lds_u4;
+typedef __attribute__((address_space(3))) u32x2_t lds_u2;
+// rows c0 .. c0 + 3 (c0 % 4 == 0) of column n -> the three planes
+__device__ __forceinline__ void store_planes4(float *planes, int c0, int n, float v0, float v1, float v2, float v3) {
+  const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){v0, v1}, __attribute__((ext_vector_type(2))) __bf16));
+  const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){v2, v3}, __attribute__((ext_vector_type(2))) __bf16));
+  const float r0 = v0 - __uint_as_float(h0 << 16), r1 = v1 - __uint_as_float(h0 & 0xffff0000u);
+  const float r2 = v2 - __uint_as_float(h1 << 16), r3 = v3 - __uint_as_float(h1 & 0xffff0000u);
+  const unsigned m0 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){r0, r1}, __attribute__((ext_vector_type(2))) __bf16));
+  const unsigned m1 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){r2, r3}, __attribute__((ext_vector_type(2))) __bf16));
+  const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xffff0000u);
+  const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xffff0000u);
+  const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){s0, s1}, __attribute__((ext_vector_type(2))) __bf16));
+  const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){s2, s3}, __attribute__((ext_vector_type(2))) __bf16));
+  // dword address: (((kb * 3 + plane) * 4 + g) * 64 + n) * 4 + 2 * (half of the 8-group)
+  const int a = ((((c0 >> 5) * 3) * 4 + ((c0 >> 3) & 3)) * 64 + n) * 4 + ((c0 >> 2) & 1) * 2;
+  lds_u2 *d = (lds_u2 *)(planes + a);
+  d[0] = u32x2_t{h0, h1};
+  d[512] = u32x2_t{m0, m1};    // next plane: 4 * 64 * 4 dwords = 1024 dwords = 512 u2
+  d[1024] = u32x2_t{l0, l1};
+}
+
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 
@@ -397,13 +432,17 @@ __device__ __forceinline__ void gemm_fast_tap3(const Ctx &c, const float *__rest
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: element 0 in the low half
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 // x[0..7] (consecutive k of one column) -> the three planes of a B fragment
 __device__ __forceinline__ void split_bf16x3(const float (&x)[8], u32x4 (&pl)[3]) {
+#ifdef GLDM_BF_NOSPLIT  // timing experiment only: planes = raw bits
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { pl[0][q] = __float_as_uint(x[2 * q]); pl[1][q] = __float_as_uint(x[2 * q + 1]); pl[2][q] = __float_as_uint(x[q]); }
+  return;
+#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float a = x[2 * q], b = x[2 * q + 1];
@@ -421,6 +460,10 @@ __device__ __forceinline__ f32x4 mfma_bf(const u32x4 &a, const u32x4 &b, const f
 }
 // acc += A B with both operands split: small terms first
 __device__ __forceinline__ f32x4 mfma_split6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 acc) {
+#ifdef GLDM_BF_ONEMFMA  // timing experiment only
+  acc[0] += __uint_as_float(b[2][0] ^ b[1][1] ^ b[0][2] ^ b[2][3] ^ b[1][0] ^ b[0][1]);
+  return mfma_bf(a[0], b[0], acc);
+#endif
   acc = mfma_bf(a[0], b[2], acc);
   acc = mfma_bf(a[2], b[0], acc);
   acc = mfma_bf(a[1], b[1], acc);
@@ -447,51 +490,226 @@ __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restric
   int b0[NB];
 #pragma unroll
   for (int q = 0; q < NB; ++q) b0[q] = pswz(8 * g, 16 * (PB0 + q) + col);
-  u32x4 a[3][MT][3];
-  float raw[NB][8];
-  auto load_a = [&](int t, int kb) {
+  // A registers.  One m-tile per wave: a set per tap, refilled with the next block's fragments right after the tap's
+  // MFMAs (a whole block to arrive).  Two m-tiles: 72 registers that way, so two sets alternate over the tap steps
+  // instead (the next step's fragments are requested in front of the current step's MFMAs: 36-48 of them, and the
+  // partner wave's, to arrive); the trip covers two blocks so that the alternation is static.
+  constexpr int NA = MT == 1 ? 3 : 2;
+  u32x4 a[NA][MT][3];
+  float raw[MT == 1 ? NB : 2][8];
+  u32x4 bs[NB][3];
+  auto load_a = [&](int buf, int t, int kb) {
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        a[t][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kblocks + t * kb32 + kb) * 3 + pl) * 64);
+        a[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kblocks + t * kb32 + kb) * 3 + pl) * 64);
   };
   auto load_raw = [&](int kb) {
-    const lds_f *s = src3 + kb * 32 * NC;
+    if constexpr (MT == 1) {
+      const lds_f *s = src3 + kb * 32 * NC;
 #pragma unroll
-    for (int q = 0; q < NB; ++q)
+      for (int q = 0; q < NB; ++q)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) raw[q][j] = s[b0[q] + j * NC];
+        for (int j = 0; j < 8; ++j) raw[q][j] = s[b0[q] + j * NC];
+    }
   };
+  auto split_all = [&]() {
+    if constexpr (MT == 1) {
 #pragma unroll
-  for (int t = 0; t < 3; ++t) load_a(t, 0);
-  load_raw(0);
+      for (int q = 0; q < NB; ++q) split_bf16x3(raw[q], bs[q]);
+    }
+  };
+  auto tap_mfmas = [&](int buf, int t) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int sp = P0 + p + t - 1;  // source position of this tap for out tile P0 + p
+        if (sp >= 0 && sp <= 3) {
+          const int qi = sp - PB0 < 0 ? 0 : (sp - PB0 >= NB ? NB - 1 : sp - PB0);
+          acc[mi][p] = mfma_split6(a[buf][mi], bs[qi], acc[mi][p]);
+        }
+      }
+  };
   const int last = kb32 - 1;
-  for (int kb = 0; kb < kb32; ++kb) {
-    const int nb = kb < last ? kb + 1 : last;  // clamped: every load stays unconditional
-    u32x4 bs[NB][3];
+  if constexpr (MT == 1) {
+    load_raw(0);
 #pragma unroll
-    for (int q = 0; q < NB; ++q) split_bf16x3(raw[q], bs[q]);
-    load_raw(nb);
+    for (int t = 0; t < 3; ++t) load_a(t, t, 0);
+    for (int kb = 0; kb < kb32; ++kb) {
+      const int nb = kb < last ? kb + 1 : last;  // clamped: every load stays unconditional
+      split_all();
+      load_raw(nb);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < 3; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        tap_mfmas(t, t);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(t, t, nb);
+      }
+    }
+  } else {
+    load_a(0, 0, 0);
+    auto step = [&](int st, int kb0) {
+        const int t = st % 3, kb = kb0 + st / 3;
+        const int nt = (st + 1) % 3, nkb = kb0 + (st + 1) / 3;
+        if (t == 0) {
+          // this block's B values: read and split tile by tile, two tiles of raw values in flight (the block-ahead
+          // form of the one-m-tile path costs 32 more registers here)
+          const lds_f *sb = src3 + kb * 32 * NC;
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
+          for (int j = 0; j < 8; ++j) raw[0][j] = sb[b0[0] + j * NC];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int sp = P0 + p + t - 1;  // source position of this tap for out tile P0 + p
-          if (sp >= 0 && sp <= 3) {
-            const int qi = sp - PB0 < 0 ? 0 : (sp - PB0 >= NB ? NB - 1 : sp - PB0);
-            acc[mi][p] = mfma_split6(a[t][mi], bs[qi], acc[mi][p]);
+          for (int q = 0; q < NB; ++q) {
+            if (q + 1 < NB) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) raw[(q + 1) & 1][j] = sb[b0[q + 1] + j * NC];
+            }
+            split_bf16x3(raw[q & 1], bs[q]);
           }
         }
-      __builtin_amdgcn_sched_barrier(0);
-      load_a(t, nb);
+        load_a((st + 1) & 1, nt, nkb < last ? nkb : last);
+        __builtin_amdgcn_sched_barrier(0);
+        tap_mfmas(st & 1, t);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // pairs of blocks: the two A sets alternate statically (this path only sees Cin = 256: smaller inputs have planes)
+    for (int kb0 = 0; kb0 < kb32; kb0 += 2) {
+#pragma unroll
+      for (int st = 0; st < 6; ++st) step(st, kb0);
     }
   }
 }
 
+// The same conv with the B operand read from pre-split planes (Cin <= 128): ds_read_b128 per (tile, plane), no VALU.
+// B planes of the next channel block are requested while the current block's MFMAs run (second register set).
+template <int MT, int P0, int NP>
+__device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restrict__ wp3, int cin, int mt0,
+                                            const float *planes, f32x4 (&acc)[MT][NP]) {
+  constexpr int PB0 = P0 > 0 ? P0 - 1 : 0, PB1 = P0 + NP < 4 ? P0 + NP : 3, NB = PB1 - PB0 + 1;
+  const int col = c.lane & 15, g = c.lane >> 4;
+  const int kb32 = cin >> 5, kblocks = 3 * kb32;
+  const WStream wv(wp3, c.lane);
+  const lds_u4 *pl3 = (const lds_u4 *)planes + g * 64 + 16 * PB0 + col;   // + (kb * 3 + plane) * 256 + 16 q
+  constexpr int NA = MT == 1 ? 3 : 2;  // see gemm_pm3_bf
+  constexpr int NBUF = (MT == 1 && NB <= 3) ? 2 : 1;   // 4 tiles x 2 sets = 96 registers: spills
+  u32x4 a[NA][MT][3];
+  u32x4 bs[NBUF][NB][3];
+  auto load_a = [&](int buf, int t, int kb) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kblocks + t * kb32 + kb) * 3 + pl) * 64);
+  };
+  auto load_b = [&](int buf, int kb) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bs[buf][q][pl] = pl3[(kb * 3 + pl) * 256 + 16 * q];
+  };
+  auto tap_mfmas = [&](int abuf, int bbuf, int t) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int sp = P0 + p + t - 1;
+        if (sp >= 0 && sp <= 3) {
+          const int qi = sp - PB0 < 0 ? 0 : (sp - PB0 >= NB ? NB - 1 : sp - PB0);
+          acc[mi][p] = mfma_split6(a[abuf][mi], bs[bbuf][qi], acc[mi][p]);
+        }
+      }
+  };
+  const int last = kb32 - 1;
+  load_b(0, 0);
+  if constexpr (MT == 1) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) load_a(t, t, 0);
+    auto block = [&](int bbuf, int nb) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        tap_mfmas(t, bbuf, t);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(t, t, nb);
+      }
+    };
+    if (kb32 == 1) {
+      block(0, 0);
+      return;
+    }
+    if constexpr (NBUF == 2) {
+      for (int kb0 = 0; kb0 < kb32; kb0 += 2) {   // kb32 is 2 or 4 here: the two sets of B planes alternate statically
+        load_b(1, kb0 + 1);
+        block(0, kb0 + 1);
+        load_b(0, kb0 + 2 < last ? kb0 + 2 : last);
+        block(NBUF - 1, kb0 + 2 < last ? kb0 + 2 : last);
+      }
+    } else {
+      for (int kb = 0; kb < kb32; ++kb) {
+        if (kb) load_b(0, kb);
+        block(0, kb < last ? kb + 1 : last);
+      }
+    }
+  } else {
+    load_a(0, 0, 0);
+    auto step = [&](int st, int kb0) {
+        const int t = st % 3, kb = kb0 + st / 3;
+        const int nt = (st + 1) % 3, nkb = kb0 + (st + 1) / 3;
+        if (t == 0 && kb > 0) load_b(0, kb);
+        load_a((st + 1) & 1, nt, nkb < last ? nkb : last);
+        __builtin_amdgcn_sched_barrier(0);
+        tap_mfmas(st & 1, 0, t);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (kb32 == 1) {
+      step(0, 0); step(1, 0); step(2, 0);
+    } else {
+      for (int kb0 = 0; kb0 < kb32; kb0 += 2) {
+#pragma unroll
+        for (int st = 0; st < 6; ++st) step(st, kb0);
+      }
+    }
+  }
+}
+
+// 1x1 conv with the B operand from pre-split planes (the folded-LayerNorm qkv conv reads the X planes).
+template <int KB32, int MT, int NT, class PRE = NoPre>
+__device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__ wp3, int mt0, int nt0, const float *planes,
+                                         f32x4 (&acc)[MT][NT], const PRE &pre = PRE()) {
+  const int col = c.lane & 15, g = c.lane >> 4;
+  const WStream wv(wp3, c.lane);
+  const lds_u4 *pl3 = (const lds_u4 *)planes + g * 64 + 16 * nt0 + col;
+  u32x4 a[2][MT][3];
+  u32x4 bs[2][3];
+  auto load_a = [&](int buf, int kb) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * KB32 + kb) * 3 + pl) * 64);
+  };
+  auto load_b = [&](int buf, int kb, int ni) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) bs[buf][pl] = pl3[(kb * 3 + pl) * 256 + 16 * ni];
+  };
+  load_a(0, 0);
+  load_b(0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  pre();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kb = 0; kb < KB32; ++kb) {
+    if (kb + 1 < KB32) load_a((kb + 1) & 1, kb + 1);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const int step = kb * NT + ni, nxt = step + 1;
+      if (nxt < KB32 * NT) load_b(nxt & 1, nxt / NT, nxt % NT);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = mfma_split6(a[kb & 1][mi], bs[step & 1], acc[mi][ni]);
+    }
+  }
+}
 
 // 1x1 conv / plain GEMM on split-bf16 operands (position-major engine): MT m-tiles x NT n-tiles of
 // W[.. x 32 KB32] * src.  A fragments double buffered over the 32-deep k-blocks (the loop is fully unrolled: KB32 is
@@ -1006,17 +1224,30 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
 #pragma unroll
     for (int p = 0; p < NP; ++p) acc[mi][p] = bv;
   }
-  gemm_pm3_bf<MT, P0, NP>(c, wp, cin, mt0, src, acc);
+  // B operand: pre-split planes (Cin <= 128; the X planes or the H planes, by which buffer `src` is) or f32 rows split
+  // on the fly (the 256-channel level)
+  const bool src_is_x = src == c.lds + GG::kBufX;
+  if constexpr (MT == 1) {  // <= 128 output channels: the input has at most as many
+    gemm_pm3_pl<MT, P0, NP>(c, wp, cin, mt0, c.lds + (src_is_x ? kPlaneX : kPlaneH), acc);
+  } else {
+    if (cin <= kPlaneMaxC) gemm_pm3_pl<MT, P0, NP>(c, wp, cin, mt0, c.lds + (src_is_x ? kPlaneX : kPlaneH), acc);
+    else gemm_pm3_bf<MT, P0, NP>(c, wp, cin, mt0, src, acc);
+  }
   if (g.mode && !kEarly) load_params();
-  if (!g.mode) {
+  const bool out_planes = cout <= kPlaneMaxC;  // outputs of up to 128 channels are also (or only) written as planes
+  if (!g.mode) {  // the level's down conv: the new residual stream X (f32) and, up to 128 channels, its planes
     if (alias) __syncthreads();
     lds_f *d3 = (lds_f *)dst;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) d3[pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm)] = acc[mi][p][r];
+        for (int r = 0; r < 4; ++r) d3[pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm)] = acc[mi][p][r];
+        if (out_planes)
+          store_planes4(c.lds + kPlaneX, 16 * (mt0 + mi) + 4 * kq, 16 * (P0 + p) + sm, acc[mi][p][0], acc[mi][p][1],
+                        acc[mi][p][2], acc[mi][p][3]);
+      }
     return;
   }
   // ---- this wave's share of the statistics, per sample (= lane & 15)
@@ -1093,20 +1324,31 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
     m2 += ps2[q] + (float)kNloc * dm * dm;
   }
   const float rstd = __builtin_amdgcn_rsqf(m2 * (1.0f / (float)(kNloc * kParts)) + 1e-5f);
+  // mode 1 (block1): H = y, as planes only up to 128 channels (H is only ever a conv input), f32 rows above;
+  // mode 2 (block2): X += y in f32 (the residual stream), plus the planes of the new X up to 128 channels
   lds_f *d3 = (lds_f *)(g.mode == 2 ? g.res : dst);
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float gsc = rstd * ga[mi][r];
+    for (int p = 0; p < NP; ++p) {
+      float y[4];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        float y = (acc[mi][p][r] - mean) * gsc + be[mi][r];
-        if (has_ss) y = y * sc[mi][r] + sh[mi][r];
-        y = silu(y);
+      for (int r = 0; r < 4; ++r) {
+        float t = (acc[mi][p][r] - mean) * (rstd * ga[mi][r]) + be[mi][r];
+        if (has_ss) t = t * sc[mi][r] + sh[mi][r];
+        t = silu(t);
         const int a = pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm);
-        d3[a] = g.mode == 2 ? d3[a] + y : y;
+        if (g.mode == 2) {
+          t = d3[a] + t;
+          d3[a] = t;
+        } else if (!out_planes) {
+          d3[a] = t;
+        }
+        y[r] = t;
       }
+      if (out_planes)
+        store_planes4(c.lds + (g.mode == 2 ? kPlaneX : kPlaneH), 16 * (mt0 + mi) + 4 * kq, 16 * (P0 + p) + sm, y[0], y[1],
+                      y[2], y[3]);
     }
 }
 
@@ -1149,12 +1391,16 @@ __device__ __forceinline__ void conv_pm3_cin4(const Ctx &c, const float *wp, con
   if (alias) __syncthreads();
   lds_f *d3 = (lds_f *)dst;
 #pragma unroll
-  for (int rd = 0; rd < kMaxRounds; ++rd)
+  for (int rd = 0; rd < kMaxRounds; ++rd) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int co = rd * 32 + c.wave * 4 + k;
       if (co < cout) d3[pswz(co, n)] = out[rd][k];
     }
+    // the new residual stream's planes (a wave's 4 channels are one half of an 8-group; cout % 32 == 0)
+    if (rd * 32 < cout && cout <= kPlaneMaxC)
+      store_planes4(c.lds + kPlaneX, rd * 32 + c.wave * 4, n, out[rd][0], out[rd][1], out[rd][2], out[rd][3]);
+  }
 }
 
 // ResnetBlock of the 4-channel level on the VALU of one wave: lane = column (16 samples x 4 positions), every
@@ -1299,12 +1545,15 @@ __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const
         m2 += q < np ? pm[q] + (float)nloc * dm * dm : 0.f;
       }
       const float rstd = __builtin_amdgcn_rsqf(m2 * inv_c + 1e-5f);
+      float xn[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (row0 + r < C) {
           const int a = pswz(row0 + r, cc);
-          x3[a] = x3[a] + (acc[0][ni][r] - mean) * rstd * gv[r];
+          xn[r] = x3[a] + (acc[0][ni][r] - mean) * rstd * gv[r];
+          x3[a] = xn[r];
         }
+      if (C >= 32) store_planes4(c.lds + kPlaneX, row0, cc, xn[0], xn[1], xn[2], xn[3]);  // the new X's planes
     }
   }
   __syncthreads();
@@ -1419,12 +1668,13 @@ __device__ __forceinline__ void qkv_ln_pm(const Ctx &c, int w_off, int s_off, co
     for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int cblocks = C >> 4;
   const float inv_c = __builtin_amdgcn_rcpf((float)C);  // C: a power of two -> exact
+  const float *xp = c.lds + kPlaneX;  // the conv runs on the X planes, the column statistics on the f32 rows
   if (cblocks == 8) {
-    gemm1_bf<4, MT, NT>(c, wp, mt0, 0, src, acc, [&]() { column_stats8<16>(c, src, inv_c); });
+    gemm1_pl<4, MT, NT>(c, wp, mt0, 0, xp, acc, [&]() { column_stats8<16>(c, src, inv_c); });
   } else if (cblocks == 4) {
-    gemm1_bf<2, MT, NT>(c, wp, mt0, 0, src, acc, [&]() { column_stats8<8>(c, src, inv_c); });
+    gemm1_pl<2, MT, NT>(c, wp, mt0, 0, xp, acc, [&]() { column_stats8<8>(c, src, inv_c); });
   } else {
-    gemm1_bf<1, MT, NT>(c, wp, mt0, 0, src, acc, [&]() { column_stats8<4>(c, src, inv_c); });
+    gemm1_pl<1, MT, NT>(c, wp, mt0, 0, xp, acc, [&]() { column_stats8<4>(c, src, inv_c); });
   }
   __syncthreads();  // every column's (mean, rstd) is in LDS
   const lds_f *mean3 = (const lds_f *)(c.lds + GG::kMiscRed1), *rstd3 = (const lds_f *)(c.lds + GG::kMiscRed2);
