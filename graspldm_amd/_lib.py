@@ -45,6 +45,8 @@ _SIGNATURES = {
     "gldm_devoxelize_fused": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_pointwise_mlp2": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "gldm_pointwise_mlp_bf16x3": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "gldm_pointwise_mlp2_bf16x3": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_sa_mlp_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 

@@ -3118,6 +3118,172 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
   }
 }
 
+// ---- the same layer(s) on split-bf16 operands -------------------------------------------------------------------------
+// pointwise_mlp_kernel with the main GEMM on v_mfma_f32_16x16x32_bf16 (6 partial products per f32 product, see the
+// split-bf16 core of the position-major engine): weights pre-split on the host (mfma_a_fragments_bf16x3), the [cin][32]
+// input tile split ONCE while it is staged and kept in LDS as B-fragment planes
+//   [32-channel block][plane hi|mid|lo][g][32 columns][8 bf16]      (6 KiB per block; cin = 768: 144 KiB)
+// so the eight waves' k-loops are ds_read_b128 + buffer loads + MFMA.  A 32-column tile re-uses a weight fragment
+// for two n-tiles only: the weight stream (6 bytes per weight and tile) runs the CU's 64 B/clk L2 path about as long
+// as the MFMAs run the matrix pipe, so fragments are requested four blocks ahead (ring of four register sets).
+// The optional layer in front (96 -> 768: an eighth of the FLOPs) stays on the f32 pipe and writes its ReLU output
+// straight into those planes; the head product is taken on the accumulators exactly as in the f32 kernel (the C layout
+// of the two MFMA shapes is the same).
+__device__ __forceinline__ void store_planes4_32(float *planes, int c0, int n, float v0, float v1, float v2, float v3) {
+  float x[8] = {v0, v1, v2, v3, 0.f, 0.f, 0.f, 0.f};
+  u32x4 pl[3];
+  split_bf16x3(x, pl);
+  const int a = ((((c0 >> 5) * 3) * 4 + ((c0 >> 3) & 3)) * 32 + n) * 4 + ((c0 >> 2) & 1) * 2;   // dwords
+  lds_u2 *d = (lds_u2 *)(planes + a);
+  d[0] = u32x2_t{pl[0][0], pl[0][1]};
+  d[256] = u32x2_t{pl[1][0], pl[1][1]};   // next plane: 4 * 32 * 4 dwords
+  d[512] = u32x2_t{pl[2][0], pl[2][1]};
+}
+
+__global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a) {
+  constexpr int NC = 32;
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Ctx c{a.w0 ? a.w0 : a.w, lds, tid, wave, lane, 0, 2};
+  const int col = lane & 15, kq = lane >> 4;
+  const int kb32 = a.cin >> 5, mtiles = a.cout >> 4, mt_per_wave = mtiles >> 3;
+  float *planes = lds;                       // [kb32][3][4][32][4 dwords]
+  float *zpart = lds;                        // [8 waves][16 rows][32 cols], over the planes once they are dead
+  float *x0 = lds + a.cin * 48;              // front layer's f32 input tile [cin0][32]
+  const WStream hw(a.head_w ? a.head_w : a.w, lane);
+  const WStream wv(a.w, lane);
+  const lds_u4 *pl3 = (const lds_u4 *)planes + kq * 32 + col;   // + ((kb * 3 + plane) * 4) * 32 + 16 ni
+  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    const int b = tile / a.tiles_per_cloud, c0 = (tile - b * a.tiles_per_cloud) * NC;
+    __syncthreads();  // the previous tile's readers are done
+    if (a.w0) {
+      const float *xb0 = a.x + (size_t)b * a.cin0 * a.n + c0;
+      for (int i = tid; i < a.cin0 * 8; i += 512) {
+        const int row = i >> 3, q = i & 7;
+        *reinterpret_cast<f32x4 *>(x0 + swz<NC>(row, 4 * q)) = *reinterpret_cast<const f32x4 *>(xb0 + (size_t)row * a.n + 4 * q);
+      }
+      __syncthreads();
+      const int cb0 = a.cin0 >> 4, mt_per_wave0 = a.cin >> 7;
+      for (int ps = 0; ps < mt_per_wave0; ps += 2) {
+        const int mt0 = wave * mt_per_wave0 + ps;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias0 + 16 * (mt0 + mi) + 4 * kq);
+          acc[mi][0] = bv;
+          acc[mi][1] = bv;
+        }
+        gemm_fast_pf<NC, 4, 1, 2, 2, 2>(c, a.w0, cb0, mt0, 0, x0, acc);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            store_planes4_32(planes, 16 * (mt0 + mi) + 4 * kq, 16 * ni + col, fmaxf(acc[mi][ni][0], 0.f),
+                             fmaxf(acc[mi][ni][1], 0.f), fmaxf(acc[mi][ni][2], 0.f), fmaxf(acc[mi][ni][3], 0.f));
+      }
+    } else {
+      // stage + split: thread = (8-channel group, column); a pass covers 128 channels
+      const float *xb = a.x + (size_t)b * a.cin * a.n + c0;
+      const int scol = tid & 31, kg = tid >> 5;
+      for (int r0 = 0; r0 < a.cin; r0 += 128) {
+        const int row = r0 + 8 * kg;
+        if (row < a.cin) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = xb[(size_t)(row + j) * a.n + scol];
+          u32x4 pl[3];
+          split_bf16x3(v, pl);
+          lds_u4 *d = (lds_u4 *)planes + (((row >> 5) * 3) * 4 + ((row >> 3) & 3)) * 32 + scol;
+          d[0] = pl[0];
+          d[128] = pl[1];
+          d[256] = pl[2];
+        }
+      }
+    }
+    __syncthreads();
+    f32x4 zacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int ps = 0; ps < mt_per_wave; ps += 2) {
+      const int mt0 = wave * mt_per_wave + ps;
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + 16 * (mt0 + mi) + 4 * kq);
+        acc[mi][0] = bv;
+        acc[mi][1] = bv;
+      }
+      // ---- k-loop: ring of four A sets (requested four blocks ahead), B planes read per block
+      u32x4 af[4][2][3];
+      auto load_a = [&](int buf, int kb) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) af[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kb32 + kb) * 3 + pl) * 64);
+      };
+      const int last = kb32 - 1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load_a(u, u < last ? u : last);
+      for (int kb0 = 0; kb0 < kb32; kb0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kb = kb0 + u;
+          u32x4 bs[2][3];
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bs[ni][pl] = pl3[(kb * 3 + pl) * 128 + 16 * ni];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_split6(af[u][mi], bs[ni], acc[mi][ni]);
+          __builtin_amdgcn_sched_barrier(0);
+          load_a(u, kb + 4 < last ? kb + 4 : last);
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        if (a.relu) {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
+        }
+        if (a.y) {
+          float *yb = a.y + ((size_t)b * a.cout + 16 * (mt0 + mi) + 4 * kq) * a.n + c0 + col;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) __builtin_nontemporal_store(acc[mi][ni][r], yb + (size_t)r * a.n + 16 * ni);
+        }
+        if (a.head_w) {
+          const f32x4 ah = hw[(size_t)(mt0 + mi) * 64];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              zacc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[r], acc[mi][ni][r], zacc[ni], 0, 0, 0);
+        }
+      }
+    }
+    if (a.head_w) {
+      __syncthreads();  // every wave is done with the planes: the z partials go over them
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zpart[(wave * 16 + 4 * kq + r) * NC + 16 * ni + col] = zacc[ni][r];
+      __syncthreads();
+      for (int i = tid; i < a.hout * NC; i += 512) {
+        const int row = i / NC, cc = i - row * NC;
+        float v = a.head_b ? a.head_b[row] : 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += zpart[(w8 * 16 + row) * NC + cc];
+        a.z[((size_t)b * a.hout + row) * a.n + c0 + cc] = v;
+      }
+    }
+  }
+}
+
 
 // ======================================================== fused set abstraction, 128-column tiles ==
 // sa_mlp_kernel at twice the tile: 128 columns = 128 / U centres x U neighbours per workgroup (8 waves, one workgroup
@@ -3416,16 +3582,23 @@ GLDM_API int gldm_pose_epilogue(const float *tmrp, const float *logit, const flo
 namespace {
 int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0, const float *w, const float *bias, int b,
                      int cin, int cout, int n, int relu, const float *head_w, const float *head_b, int hout, float *y,
-                     float *z, hipStream_t stream) {
+                     float *z, hipStream_t stream, bool split_bf16 = false) {
   if (!x || !w || !bias || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
   if (!y && !head_w) return GLDM_ERR_INVALID_ARG;
   if (head_w && (!z || hout <= 0 || hout > 16)) return GLDM_ERR_INVALID_ARG;
   if ((cin & 31) || (cout & 255) || (n & 31)) return GLDM_ERR_UNSUPPORTED;  // k-blocks in pairs, 2 m-tiles x 8 waves, 32-point tiles
   if (w0 && (!b0 || cin0 <= 0 || (cin0 & 31) || (cin & 255))) return GLDM_ERR_UNSUPPORTED;
-  const size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
+  size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
+  if (split_bf16) {  // `w` holds split-bf16 fragments (w0, if any, f32 ones): planes of the tile + the front layer's f32 tile
+    if (cin & 127) return GLDM_ERR_UNSUPPORTED;  // the A ring walks four 32-deep blocks per trip
+    lds_bytes = ((size_t)cin * 48 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
+    if (lds_bytes < (size_t)8 * 16 * 32 * sizeof(float)) lds_bytes = (size_t)8 * 16 * 32 * sizeof(float);
+  }
   if (lds_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
   struct PwTag { int site; };
-  gldm_dev::allow_dynamic_lds<PwTag>(reinterpret_cast<const void *>(&pointwise_mlp_kernel), 160 * 1024);
+  struct PwBfTag { int site; };
+  if (split_bf16) gldm_dev::allow_dynamic_lds<PwBfTag>(reinterpret_cast<const void *>(&pointwise_mlp_bf_kernel), 160 * 1024);
+  else gldm_dev::allow_dynamic_lds<PwTag>(reinterpret_cast<const void *>(&pointwise_mlp_kernel), 160 * 1024);
   PwArgs a{};
   a.x = x; a.w = w; a.bias = bias; a.head_w = head_w; a.head_b = head_b; a.y = y; a.z = z;
   a.cin = cin; a.cout = cout; a.n = n; a.relu = relu; a.hout = hout;
@@ -3435,7 +3608,8 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
   int grid = cu_count() * per_cu;
   if (grid > a.total_tiles) grid = a.total_tiles;
-  hipLaunchKernelGGL(pointwise_mlp_kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
+  if (split_bf16) hipLaunchKernelGGL(pointwise_mlp_bf_kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
+  else hipLaunchKernelGGL(pointwise_mlp_kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 }  // namespace
@@ -3454,6 +3628,22 @@ GLDM_API int gldm_pointwise_mlp2(const float *x, const float *w0_packed, const f
   if (!w0_packed) return GLDM_ERR_INVALID_ARG;
   return launch_pointwise(x, w0_packed, bias0, cin0, w_packed, bias, b, cin, cout, n, 1, head_w_packed, head_bias,
                           hout, y, z, reinterpret_cast<hipStream_t>(stream));
+}
+
+GLDM_API int gldm_pointwise_mlp_bf16x3(const float *x, const float *w_split, const float *bias, int b, int cin, int cout,
+                                       int n, int relu, const float *head_w_packed, const float *head_bias, int hout,
+                                       float *y, float *z, gldm_stream_t stream) {
+  return launch_pointwise(x, nullptr, nullptr, 0, w_split, bias, b, cin, cout, n, relu, head_w_packed, head_bias, hout,
+                          y, z, reinterpret_cast<hipStream_t>(stream), true);
+}
+
+GLDM_API int gldm_pointwise_mlp2_bf16x3(const float *x, const float *w0_packed, const float *bias0, int cin0,
+                                        const float *w_split, const float *bias, int b, int cin, int cout, int n,
+                                        const float *head_w_packed, const float *head_bias, int hout, float *y, float *z,
+                                        gldm_stream_t stream) {
+  if (!w0_packed) return GLDM_ERR_INVALID_ARG;
+  return launch_pointwise(x, w0_packed, bias0, cin0, w_split, bias, b, cin, cout, n, 1, head_w_packed, head_bias,
+                          hout, y, z, reinterpret_cast<hipStream_t>(stream), true);
 }
 
 GLDM_API int gldm_sa_mlp_forward(const float *points, const float *centers, const float *features,

@@ -59,6 +59,12 @@ def pack_head(wh):
     return mfma_a_fragments(w)
 
 
+def split_supported(cin, cin0=0):
+    """The split-bf16 form of the fused launch (gldm_pointwise_mlp*_bf16x3): A ring of four 32-deep blocks, the tile
+    as planes (48 floats per channel) + the front layer's f32 tile."""
+    return cin % 128 == 0 and 4 * (48 * cin + 32 * cin0) <= 160 * 1024
+
+
 def fused_mlp_supported(x, cin, cout):
     return (x.ndim == 3 and x.is_contiguous() and cin % 32 == 0 and cout % 256 == 0 and x.shape[-1] % 32 == 0
             and 4 * (32 * cin + 4096) <= 160 * 1024)
@@ -70,10 +76,12 @@ def fused_mlp2_supported(x, cin0, cin, cout):
             and x.shape[-1] % 32 == 0 and 4 * (32 * (cin + cin0) + 4096) <= 160 * 1024)
 
 
-def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True, front=None):
-    """One fused launch: y = act(W x + b) over [B, Cin, N] (hand-written f32-MFMA GEMM, csrc/resnet1d.hip:
-    pointwise_mlp_kernel) and optionally z = Wh y + bh on the accumulators.  head = (packed Wh, bh, hout).
-    front = (packed W0, b0, cin): a ReLU layer x -> relu(W0 x + b0) in front, its output kept in LDS only."""
+def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True, front=None, split=False):
+    """One fused launch: y = act(W x + b) over [B, Cin, N] (hand-written MFMA GEMM, csrc/resnet1d.hip:
+    pointwise_mlp_kernel / pointwise_mlp_bf_kernel) and optionally z = Wh y + bh on the accumulators.
+    head = (packed Wh, bh, hout).  front = (packed W0, b0, cin): a ReLU layer x -> relu(W0 x + b0) in front, its output
+    kept in LDS only.  split=True: `w_packed` holds split-bf16 fragments (the GEMM runs on the bf16 matrix pipe with
+    six partial products per f32 product)."""
     from . import _lib as L
     b, cin, n = x.shape
     y = torch.empty((b, cout, n), dtype=torch.float32, device=x.device) if keep_y or head is None else None
@@ -83,11 +91,12 @@ def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True, front=N
         if front is not None:
             if not relu:
                 raise ValueError("the two-layer launch applies ReLU after both layers")
-            L.call("gldm_pointwise_mlp2", L.ptr(x), L.ptr(front[0]), L.ptr(front[1]), cin, L.ptr(w_packed), L.ptr(bias),
-                   b, front[2], cout, n, *hp, L.ptr(y), L.ptr(z), L.current_stream(x.device))
+            L.call("gldm_pointwise_mlp2_bf16x3" if split else "gldm_pointwise_mlp2", L.ptr(x), L.ptr(front[0]),
+                   L.ptr(front[1]), cin, L.ptr(w_packed), L.ptr(bias), b, front[2], cout, n, *hp, L.ptr(y), L.ptr(z),
+                   L.current_stream(x.device))
         else:
-            L.call("gldm_pointwise_mlp", L.ptr(x), L.ptr(w_packed), L.ptr(bias), b, cin, cout, n, int(relu), *hp,
-                   L.ptr(y), L.ptr(z), L.current_stream(x.device))
+            L.call("gldm_pointwise_mlp_bf16x3" if split else "gldm_pointwise_mlp", L.ptr(x), L.ptr(w_packed), L.ptr(bias),
+                   b, cin, cout, n, int(relu), *hp, L.ptr(y), L.ptr(z), L.current_stream(x.device))
     return y, z
 
 
@@ -104,25 +113,27 @@ def pointwise_conv(x, conv):
 
 
 def folded_conv_bn(conv, bn, device):
-    """BatchNorm(eval) folded into the k = 1 conv: (W', b', W' packed for gldm_pointwise_mlp or None), on `device`,
-    computed once per (weights, statistics) version and kept on the conv module."""
+    """BatchNorm(eval) folded into the k = 1 conv: (W', b', W' packed for gldm_pointwise_mlp or None, W' as split-bf16
+    fragments or None), on `device`, computed once per (weights, statistics) version and kept on the conv module."""
     from ._cache import params_key, publish
     src = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv.bias] if conv.bias is not None else [])
     key = params_key(src, device)
     hit = conv.__dict__.get("_gldm_folded")  # lives and dies with the module
     if hit is None or hit[0] != key:
-        from .r1d_pack import mfma_a_fragments
+        from .r1d_pack import mfma_a_fragments, mfma_a_fragments_bf16x3
         s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
         w = (conv.weight.reshape(conv.weight.shape[0], -1) * s.view(-1, 1)).contiguous()
         cb = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
         b = ((cb - bn.running_mean) * s + bn.bias).contiguous()
-        wp = None
+        wp = ws = None
         if w.shape[1] % 32 == 0 and w.shape[0] % 256 == 0:
             wp = mfma_a_fragments(w.detach().float().cpu()).to(device)
-        hit = (key, w, b, wp)
+            if split_supported(w.shape[1]):
+                ws = mfma_a_fragments_bf16x3(w.detach().float().cpu()).to(device)
+        hit = (key, w, b, wp, ws)
         conv.__dict__["_gldm_folded"] = hit
         publish(device)
-    return hit[1], hit[2], hit[3]
+    return hit[1], hit[2], hit[3], hit[4]
 
 
 def pointwise_conv_bn_relu(x, conv, bn):
@@ -130,9 +141,11 @@ def pointwise_conv_bn_relu(x, conv, bn):
     cout % 256 == 0) run as ONE hand-written launch (GEMM + bias + ReLU in the native layout); the others as a
     library GEMM + the fused bias/ReLU pass."""
     _need_cuda(x)
-    w, b, wp = folded_conv_bn(conv, bn, x.device)
+    w, b, wp, ws = folded_conv_bn(conv, bn, x.device)
     x = x.float()
     if wp is not None and fused_mlp_supported(x, w.shape[1], w.shape[0]):
+        if ws is not None:
+            return pointwise_mlp(x, ws, b, w.shape[0], True, split=True)[0]
         return pointwise_mlp(x, wp, b, w.shape[0], True)[0]
     return _gemm_bias_act(x, w, b, True)
 

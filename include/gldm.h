@@ -298,6 +298,20 @@ int gldm_pointwise_mlp2(const float *x /*[b,cin0,n]*/, const float *w0_packed, c
                         const float *head_w_packed, const float *head_bias, int hout,
                         float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
 
+/* The same two entry points with the MAIN layer's weights as split-bf16 fragments (graspldm_amd/r1d_pack.py:
+ * mfma_a_fragments_bf16x3; layout above): the GEMM runs on the bf16 matrix pipe with six partial products per f32
+ * product and f32 accumulation (error of the order of one f32 rounding per product, 6/16 of the f32-MFMA time).  The
+ * input tile is split once while it is staged.  `w0_packed` (front layer) and `head_w_packed` stay f32 fragments.
+ * cin % 128 == 0, cout % 256 == 0, n % 32 == 0, 4 (48 cin + 32 cin0) <= 160 KiB. */
+int gldm_pointwise_mlp_bf16x3(const float *x /*[b,cin,n]*/, const float *w_split, const float *bias /*[cout]*/,
+                              int b, int cin, int cout, int n, int relu,
+                              const float *head_w_packed, const float *head_bias, int hout,
+                              float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
+int gldm_pointwise_mlp2_bf16x3(const float *x /*[b,cin0,n]*/, const float *w0_packed, const float *bias0, int cin0,
+                               const float *w_split, const float *bias /*[cout]*/, int b, int cin, int cout, int n,
+                               const float *head_w_packed, const float *head_bias, int hout,
+                               float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
+
 /* ---------------------------------------------------------- voxel branch of PVConv */
 
 /* ref: grasp_ldm/models/modules/ext/pvcnn/modules/pvconv.py:48-66 (nn.Conv3d k=3 p=1 on the

@@ -15,6 +15,8 @@ from graspldm_amd.synthetic import synthetic_state_dict
 
 TERMS = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 PAIRS = {3: [(0, 0), (0, 1), (1, 0)], 6: [(0, 0), (0, 1), (1, 0), (0, 2), (2, 0), (1, 1)],
+         5: [(0, 0), (0, 1), (1, 0), (0, 2), (1, 1)],   # (weight plane, activation plane): weights kept to hi + mid only
+         4: [(0, 0), (0, 1), (1, 0), (1, 1)],
          9: [(i, j) for i in range(3) for j in range(3)]}[TERMS]
 
 def split3(x):
