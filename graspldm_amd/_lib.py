@@ -39,6 +39,7 @@ _SIGNATURES = {
     "gldm_decode": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "gldm_pose_epilogue": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gldm_conv3d_k3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "gldm_conv3d_k3_bf16x3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_groupnorm_swish": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "gldm_se_gate": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "gldm_bias_act": [_vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp],

@@ -319,6 +319,232 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
   GLDM_C3_STAMP(21);
 }
 
+// ---- the same conv on split-bf16 operands (the shipped encoder's two shapes: 48 ch @ 24^3 and 96 ch @ 12^3) ------------
+// v_mfma_f32_16x16x32_bf16 with every f32 operand written as hi + mid + lo (three bf16 numbers, exact) and the six
+// partial products of weight >= 2^-16 accumulated in f32: the error of an f32 rounding per product at 6/16 of the
+// f32-MFMA time (see csrc/resnet1d.hip, "split-bf16 GEMM core").  K is walked as (16-channel block, PAIR of taps):
+// lane group g of a fragment = (tap 2 p + (g >> 1), channels 8 (g & 1) .. + 7); 27 taps = 13 pairs + one half-empty
+// (zero weights).  The brick stays f32 in LDS (same staging as the f32 kernel); a lane reads its 8 channels of a voxel
+// (8 ds_read_b32, one LDS row apart) and splits them (36 VALU) once per (pair, n-tile), and the planes then serve three
+// m-tiles x six MFMAs: work is walked in groups of 3 m-tiles x 3 n-tiles so that the A sets (double buffered), the B
+// planes and the 72 accumulators fit 256 registers.  Weights: graspldm_amd/voxel.py: pack_conv3d_bf16x3.
+typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 c3_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float c3_f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned c3_u32x4;
+
+__device__ __forceinline__ unsigned c3_cvt_pk(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(c3_f32x2{a, b}, c3_bf16x2));
+}
+__device__ __forceinline__ void c3_split(const float (&x)[8], c3_u32x4 (&pl)[3]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = x[2 * q], b = x[2 * q + 1];
+    const unsigned h = c3_cvt_pk(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = c3_cvt_pk(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    pl[0][q] = h;
+    pl[1][q] = m;
+    pl[2][q] = c3_cvt_pk(sa, sb);
+  }
+}
+__device__ __forceinline__ f32x4 c3_mfma(const c3_u32x4 &a, const c3_u32x4 &b, const f32x4 &c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(c3_bf16x8, a), __builtin_bit_cast(c3_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 c3_mfma6(const c3_u32x4 (&a)[3], const c3_u32x4 (&b)[3], f32x4 acc) {
+  acc = c3_mfma(a[0], b[2], acc);
+  acc = c3_mfma(a[2], b[0], acc);
+  acc = c3_mfma(a[1], b[1], acc);
+  acc = c3_mfma(a[0], b[1], acc);
+  acc = c3_mfma(a[1], b[0], acc);
+  return c3_mfma(a[0], b[0], acc);
+}
+
+constexpr int kPairs = 14;  // tap pairs per 16-channel block (the last one holds tap 26 and zeros)
+
+template <int MT, int NTW>
+__global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_bf_kernel(const float *__restrict__ x,
+                                                                       const float *__restrict__ wp3,
+                                                                       const float *__restrict__ bias, int cin, int cout,
+                                                                       float *__restrict__ y, float *__restrict__ partial) {
+  constexpr int r = 4 * NTW;
+  static_assert(MT % 3 == 0 && NTW % 3 == 0 && brick_vec4(r), "walked in 3 x 3 tile groups; float4 staging");
+  constexpr int MG = MT / 3, NG = NTW / 3;
+  extern __shared__ float lds[];
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 15, kq = lane >> 4;
+  const int bpr = r / kBrick;
+  const int bx0 = (blockIdx.x / bpr) * kBrick, by0 = (blockIdx.x % bpr) * kBrick;
+  const int b = blockIdx.y;
+  constexpr int r3 = r * r * r, zp = brick_zp(r), bvp = brick_row_stride(r);
+  const int cblocks = (cin + 15) >> 4, kblocks = kPairs * cblocks;
+  x += (size_t)b * cin * r3;
+  y += (size_t)b * cout * r3;
+  const WStream wv(wp3, lane);
+  const lds_f *l3 = (const lds_f *)lds;
+
+  // voxel of (n-tile, lane column): LDS offset of its (0,0,0) tap in channel row 8 (g & 1); global voxel index
+  int vbase[NTW], gvox[NTW];
+#pragma unroll
+  for (int ni = 0; ni < NTW; ++ni) {
+    const int o = 16 * (wave * NTW + ni) + col;
+    const int iz = o % r, ixy = o / r, ix = ixy >> 2, iy = ixy & 3;
+    vbase[ni] = (ix * 6 + iy) * zp + iz + 3 + 8 * (kq & 1) * bvp;
+    gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + iz;
+  }
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    f32x4 bvv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bvv[q] = bias[min(16 * mi + 4 * kq + q, cout - 1)];
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = bvv;
+  }
+  // ---- staging (float4 slots aligned with the grid's z; identical to the f32 kernel)
+  constexpr int kSlotsRow = r / 4, kSlots = 36 * kSlotsRow;
+  static_assert(kSlots <= kConvThreads, "one interior slot per thread");
+  int s_lds = -1, s_glb = -1;
+  if (tid < kSlots) {
+    const int ixy = tid / kSlotsRow, k = tid - ixy * kSlotsRow;
+    const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1;
+    s_lds = ixy * zp + 4 * (k + 1);
+    if ((unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r) s_glb = (gx * r + gy) * r + 4 * k;
+  }
+  {
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 72) {
+      float *lc = lds + (tid >> 1) * zp + ((tid & 1) ? 4 * (kSlotsRow + 1) : 0);
+#pragma unroll
+      for (int ci = 0; ci < 16; ++ci) *reinterpret_cast<f32x4 *>(lc + ci * bvp) = z4;
+    }
+    if (s_lds >= 0 && s_glb < 0) {
+      float *lc = lds + s_lds;
+#pragma unroll
+      for (int ci = 0; ci < 16; ++ci) *reinterpret_cast<f32x4 *>(lc + ci * bvp) = z4;
+    }
+  }
+  f32x4 stv[16];
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, cin * r3 * 4, 0x00020000);
+  auto stage_load = [&](int cb) {
+    const int g0 = s_glb >= 0 ? s_glb : 0;
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci)
+      stv[ci] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((cb * 16 + ci) * r3 + g0) * 4, 0, 0));
+  };
+  auto stage_store = [&]() {
+    if (s_glb >= 0) {
+      float *lc = lds + s_lds;
+#pragma unroll
+      for (int ci = 0; ci < 16; ++ci) *reinterpret_cast<f32x4 *>(lc + ci * bvp) = stv[ci];
+    }
+  };
+  for (int cb = 0; cb < cblocks; ++cb) {
+    // staged in place (no register-held prefetch of the next block: its 64 registers are what lets the tap loop keep
+    // two A sets beside the 72 accumulators; the co-resident workgroup computes while this one waits)
+    __syncthreads();
+    stage_load(cb);
+    stage_store();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    // ---- 14 tap pairs x (MG x NG) groups of 3 x 3 tiles
+    c3_u32x4 a[2][3][3];
+    auto load_a = [&](int buf, int step) {   // step = pair * MG + mg
+      const int p = step / MG, mg = step - p * MG;
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          a[buf][mi][pl] = wv.raw((((size_t)(3 * mg + mi) * kblocks + cb * kPairs + p) * 3 + pl) * 64);
+    };
+    load_a(0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    constexpr int kSteps = kPairs * MG;
+    for (int p0 = 0; p0 < kPairs; p0 += 2) {   // two pairs per trip: the A double buffer alternates statically
+#pragma unroll
+    for (int pu = 0; pu < 2; ++pu) {
+      const int p = p0 + pu;
+      const int ta = 2 * p, tb = 2 * p + 1 < 27 ? 2 * p + 1 : 26;
+      const int offa = ((ta / 9) * 6 + (ta / 3) % 3) * zp + ta % 3, offb = ((tb / 9) * 6 + (tb / 3) % 3) * zp + tb % 3;
+      const int toff = (kq >> 1) ? offb : offa;
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng) {
+        c3_u32x4 bs[3][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          float raw[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) raw[j] = l3[vbase[3 * ng + q] + toff + j * bvp];
+          c3_split(raw, bs[q]);
+        }
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+          const int step = p * MG + mg;
+          constexpr int kPar = MG & 1;  // parity of a step's A set: (pu * MG + mg) & 1 (p0 * MG is even)
+          const int cur = (pu * MG + mg) & 1;
+          (void)kPar;
+          // the A set of the next (pair, m-group); with two n-groups a set serves both (requested in the first)
+          if (ng == 0) load_a(cur ^ 1, step + 1 < kSteps ? step + 1 : step);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[3 * mg + mi][3 * ng + q] = c3_mfma6(a[cur][mi], bs[q], acc[3 * mg + mi][3 * ng + q]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    }
+    __builtin_amdgcn_s_setprio(3);
+  }
+  // ---- epilogue: per-channel partial statistics of this brick, then the stores (as in the f32 kernel)
+  __syncthreads();
+  float *s_part = lds;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = 16 * mi + 4 * kq + q;
+      float s = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < NTW; ++ni) {
+        const float v = acc[mi][ni][q];
+        s += v;
+        s2 += v * v;
+      }
+      s = row16_sum(s);
+      s2 = row16_sum(s2);
+      if (col == 0 && co < cout) {
+        s_part[(wave * MT * 16 + co) * 2] = s;
+        s_part[(wave * MT * 16 + co) * 2 + 1] = s2;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < cout) {
+    float s = 0.f, s2 = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      s += s_part[(w * MT * 16 + tid) * 2];
+      s2 += s_part[(w * MT * 16 + tid) * 2 + 1];
+    }
+    float *p = partial + (((size_t)b * gridDim.x + blockIdx.x) * cout + tid) * 2;
+    p[0] = s;
+    p[1] = s2;
+  }
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = 16 * mi + 4 * kq + q;
+      if (co < cout) {
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
+      }
+    }
+}
+
 // GroupNorm(groups) + Swish over [B, C, r^3]; statistics from the conv's per-brick partials.
 // grid = (groups, B); optional per-channel sum of the OUTPUT (for the SE squeeze).
 __global__ __launch_bounds__(512) void groupnorm_swish_kernel(float *__restrict__ y, const float *__restrict__ partial,
@@ -525,6 +751,29 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
   GLDM_CONV_CASE(4, 1);   // 64 ch @ 4^3
   GLDM_CONV_CASE(8, 1);   // 128 ch @ 4^3
 #undef GLDM_CONV_CASE
+  return GLDM_ERR_UNSUPPORTED;
+}
+
+template <int MT, int NTW>
+int launch_conv_bf(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
+                   hipStream_t s) {
+  constexpr int r = 4 * NTW;
+  const size_t lds_bytes = (size_t)16 * brick_row_stride(r) * sizeof(float);
+  struct Tag {};
+  gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_bf_kernel<MT, NTW>), (int)lds_bytes);
+  const int bpr = r / kBrick;
+  hipLaunchKernelGGL((conv3d_k3_bf_kernel<MT, NTW>), dim3(bpr * bpr, b), dim3(kConvThreads), lds_bytes, s, x, wp3, bias, cin,
+                     cout, y, partial);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const float *bias, int b, int cin, int cout, int r,
+                                   float *y, float *partial, gldm_stream_t stream) {
+  if (!x || !w_split || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
+  if (cin % 16 || cout % 48) return GLDM_ERR_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (cout == 48 && r == 24) return launch_conv_bf<3, 6>(x, w_split, bias, b, cin, cout, y, partial, s);
+  if (cout == 96 && r == 12) return launch_conv_bf<6, 3>(x, w_split, bias, b, cin, cout, y, partial, s);
   return GLDM_ERR_UNSUPPORTED;
 }
 

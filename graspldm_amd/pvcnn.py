@@ -317,7 +317,7 @@ class PVConv(nn.Module):
             from ._cache import params_key, publish
             key = params_key([c.weight for c in convs], vox.device)
             if plan is None or plan.key != key:
-                plan = voxel.VoxelBranchPlan(convs, vox.device)
+                plan = voxel.VoxelBranchPlan(convs, vox.device, self.resolution)
                 plan.key = key
                 self.__dict__["_voxel_plan"] = plan
                 publish(vox.device)

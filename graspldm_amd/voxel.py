@@ -22,11 +22,33 @@ def pack_conv3d(weight):
     return mfma_a_fragments(w.reshape(cout, 27 * cpad))
 
 
-class VoxelBranchPlan:
-    """Packed conv weights of one PVConv on the device."""
+def split_conv_supported(cin, cout, r):
+    """Shapes gldm_conv3d_k3_bf16x3 is built for (the shipped PVCNN encoder's 48 ch @ 24^3 and 96 ch @ 12^3)."""
+    return cin % 16 == 0 and (cout, r) in ((48, 24), (96, 12))
 
-    def __init__(self, convs, device):
-        self.w = [pack_conv3d(c.weight).to(device) for c in convs]
+
+def pack_conv3d_bf16x3(weight):
+    """[cout, cin, 3, 3, 3] (cin % 16 == 0) -> split-bf16 A fragments of [cout, cblocks * 14 * 32]: K is walked as
+    (16-channel block, pair of taps), k = ((cb * 14 + p) * 32 + 16 (tap - 2 p) + ci; tap 27 (second half of the last
+    pair) is zero."""
+    from .r1d_pack import mfma_a_fragments_bf16x3
+    cout, cin = weight.shape[:2]
+    cb = cin // 16
+    w = torch.zeros(cout, cb, 14, 2, 16, dtype=torch.float32)
+    wt = weight.detach().float().cpu().reshape(cout, cb, 16, 27)            # [cout, cb, ci, tap]
+    taps = torch.zeros(cout, cb, 16, 28)
+    taps[..., :27] = wt
+    w[:] = taps.reshape(cout, cb, 16, 14, 2).permute(0, 1, 3, 4, 2)          # [cout, cb, pair, half, ci]
+    return mfma_a_fragments_bf16x3(w.reshape(cout, cb * 14 * 32))
+
+
+class VoxelBranchPlan:
+    """Packed conv weights of one PVConv on the device (f32 fragments, or split-bf16 ones where the conv has that kernel)."""
+
+    def __init__(self, convs, device, r=None):
+        self.split = [r is not None and split_conv_supported(c.in_channels, c.out_channels, r) for c in convs]
+        self.w = [(pack_conv3d_bf16x3(c.weight) if sp else pack_conv3d(c.weight)).to(device)
+                  for c, sp in zip(convs, self.split)]
         self.key = None  # set by the owner (PVConv.forward) from _cache.params_key
 
 
@@ -43,8 +65,8 @@ def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
             y = torch.empty((b, cout, r, r, r), dtype=torch.float32, device=dev)
             nf = L.lib().gldm_conv3d_partial_floats(b, cout, r)
             partial = torch.empty(int(nf), dtype=torch.float32, device=dev)
-            L.call("gldm_conv3d_k3", L.ptr(x), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r, L.ptr(y),
-                   L.ptr(partial), st)
+            L.call("gldm_conv3d_k3_bf16x3" if plan.split[i] else "gldm_conv3d_k3", L.ptr(x), L.ptr(plan.w[i]),
+                   L.ptr(conv.bias), b, cin, cout, r, L.ptr(y), L.ptr(partial), st)
             last = i == len(convs) - 1
             if last and se is not None:
                 chan_sum = torch.empty((b, cout), dtype=torch.float32, device=dev)

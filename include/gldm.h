@@ -325,6 +325,14 @@ int gldm_conv3d_k3(const float *x /*[b,cin,r^3]*/, const float *w_packed, const 
                    int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/, float *partial,
                    gldm_stream_t stream);
 
+/* The same conv with split-bf16 weights (graspldm_amd/voxel.py: pack_conv3d_bf16x3: [cout, cblocks * 14 * 32] with
+ * k = ((16-channel block) * 14 + tap pair) * 32 + 16 (tap - 2 pair) + channel, as mfma_a_fragments_bf16x3 fragments):
+ * six bf16 partial products per f32 product on the bf16 matrix pipe, f32 accumulation.  Built for the shipped
+ * encoder's two shapes (cout 48 at r = 24, cout 96 at r = 12; cin % 16 == 0); GLDM_ERR_UNSUPPORTED otherwise. */
+int gldm_conv3d_k3_bf16x3(const float *x /*[b,cin,r^3]*/, const float *w_split, const float *bias /*[cout]*/,
+                          int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/, float *partial,
+                          gldm_stream_t stream);
+
 /* ref: pvconv.py:57-66 (nn.GroupNorm(8, c) + Swish), in place on y; statistics from `partial`
  * (combined in f64 in a fixed order).  chan_sum [b,c] (optional) receives the per-channel sum of
  * the OUTPUT: the squeeze of the SE block that follows. */
