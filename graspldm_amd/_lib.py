@@ -39,6 +39,7 @@ _SIGNATURES = {
     "gldm_decode": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "gldm_pose_epilogue": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gldm_conv3d_k3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "gldm_conv3d_k3_generic": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_conv3d_k3_bf16x3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_groupnorm_swish": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "gldm_se_gate": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
@@ -46,6 +47,8 @@ _SIGNATURES = {
     "gldm_devoxelize_fused": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_pointwise_mlp2": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "gldm_pointwise_small": [_vp, _vp, _vp, _i, _i, _i, ctypes.c_longlong, _i, _vp, _vp],
+    "gldm_linear_rows": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp_bf16x3": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_pointwise_mlp2_bf16x3": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_sa_mlp_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

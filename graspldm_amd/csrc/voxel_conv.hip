@@ -691,6 +691,103 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ y, co
   }
 }
 
+// ---- narrow k = 1 convs and the Linear over the point axis (the pieces of the shipped encoder that used to go to
+// MIOpen / rocBLAS: SharedMLP 3 -> 48 and 48 -> 96 of the PVConv point branches, shared_mlp.py:6-35, and
+// out_layer[1] = Linear(n_points -> latent) over the POINT axis, pc_encoders.py:60-82,104-111).  Too small for the
+// matrix pipe (<= 4.6 k MAC per point): lane = point, the point's cin inputs in registers, weights wave-uniform on the
+// scalar path, fma chain in k order from the bias.
+template <int CIN>
+__global__ __launch_bounds__(256) void pointwise_small_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, int cout, long long n,
+                                                              int relu, float *__restrict__ y) {
+  const int b = blockIdx.y;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float *xb = x + (size_t)b * CIN * n + i;
+  float v[CIN];
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci) v[ci] = xb[(size_t)ci * n];
+  float *yb = y + (size_t)b * cout * n + i;
+  for (int co = 0; co < cout; ++co) {
+    const float *wr = w + (size_t)co * CIN;
+    float acc = bias ? bias[co] : 0.f;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) acc = fmaf(wr[ci], v[ci], acc);
+    yb[(size_t)co * n] = relu ? fmaxf(acc, 0.f) : acc;
+  }
+}
+
+// y[row, o] = bias[o] + sum_n W[o, n] x[row, n]: one workgroup per row (rows = batch x channels: a few hundred),
+// the row staged in LDS, thread = output feature, k in ascending order.
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, int n, int nout,
+                                                          float *__restrict__ y) {
+  extern __shared__ float xs[];
+  const int row = blockIdx.x;
+  for (int i = threadIdx.x; i < n; i += 256) xs[i] = x[(size_t)row * n + i];
+  __syncthreads();
+  for (int o = threadIdx.x; o < nout; o += 256) {
+    const float *wr = w + (size_t)o * n;
+    float acc = bias ? bias[o] : 0.f;
+    for (int i = 0; i < n; i += 4) {
+      const float4 wv = *reinterpret_cast<const float4 *>(wr + i);
+      acc = fmaf(wv.x, xs[i], acc);
+      acc = fmaf(wv.y, xs[i + 1], acc);
+      acc = fmaf(wv.z, xs[i + 2], acc);
+      acc = fmaf(wv.w, xs[i + 3], acc);
+    }
+    y[(size_t)row * nout + o] = acc;
+  }
+}
+
+// ---- any-shape Conv3d(k = 3, p = 1) for voxel shapes without an MFMA instantiation (PVCNN2's 256 ch @ 8^3 and
+// 128 ch @ 16^3 feature-propagation convs: 16 m-tiles of accumulators do not fit a wave).  Direct form on the VALU: a
+// workgroup owns a 4 x 4 x r brick like the MFMA kernels (so the GroupNorm partials have the same layout), a thread a
+// voxel, weights [cout][cin][27] as stored by nn.Conv3d, wave-uniform on the scalar path.  Correctness path, not a fast
+// one: these shapes are outside the shipped encoder.
+__global__ __launch_bounds__(256) void conv3d_k3_generic_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                const float *__restrict__ bias, int cin, int cout, int r,
+                                                                float *__restrict__ y, float *__restrict__ partial) {
+  __shared__ float s_red[2][4];
+  const int bpr = r / kBrick, r3 = r * r * r, nvox = 16 * r;
+  const int bx0 = (blockIdx.x / bpr) * kBrick, by0 = (blockIdx.x % bpr) * kBrick, b = blockIdx.y;
+  x += (size_t)b * cin * r3;
+  y += (size_t)b * cout * r3;
+  const int tid = threadIdx.x;
+  for (int co = 0; co < cout; ++co) {
+    float s = 0.f, s2 = 0.f;
+    for (int v = tid; v < nvox; v += 256) {
+      const int iz = v % r, ixy = v / r, gx = bx0 + (ixy >> 2), gy = by0 + (ixy & 3);
+      float acc = bias[co];
+      for (int ci = 0; ci < cin; ++ci) {
+        const float *xc = x + (size_t)ci * r3;
+        const float *wc = w + ((size_t)co * cin + ci) * 27;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+          const int nx = gx + tap / 9 - 1, ny = gy + (tap / 3) % 3 - 1, nz = iz + tap % 3 - 1;
+          if ((unsigned)nx < (unsigned)r && (unsigned)ny < (unsigned)r && (unsigned)nz < (unsigned)r)
+            acc = fmaf(wc[tap], xc[(nx * r + ny) * r + nz], acc);
+        }
+      }
+      y[(size_t)co * r3 + (gx * r + gy) * r + iz] = acc;
+      s += acc;
+      s2 += acc * acc;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+      s += __shfl_xor(s, off, 64);
+      s2 += __shfl_xor(s2, off, 64);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = s; s_red[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+      float *p = partial + (((size_t)b * gridDim.x + blockIdx.x) * cout + co) * 2;
+      p[0] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+      p[1] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    }
+  }
+}
+
 }  // namespace
 
 GLDM_API long long gldm_conv3d_partial_floats(int b, int cout, int r) {
@@ -800,6 +897,38 @@ GLDM_API int gldm_devoxelize_fused(const float *coords, const float *features, c
   if (!coords || !features || !out || b <= 0 || c <= 0 || n <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(devoxelize_fused_kernel, dim3((n + 255) / 256, (c + 15) / 16, b), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), coords, features, gate, add, c, n, r, out);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_conv3d_k3_generic(const float *x, const float *w, const float *bias, int b, int cin, int cout, int r,
+                                    float *y, float *partial, gldm_stream_t stream) {
+  if (!x || !w || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
+  if (r % kBrick) return GLDM_ERR_UNSUPPORTED;
+  const int bpr = r / kBrick;
+  hipLaunchKernelGGL(conv3d_k3_generic_kernel, dim3(bpr * bpr, b), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w,
+                     bias, cin, cout, r, y, partial);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_pointwise_small(const float *x, const float *w, const float *bias, int b, int cin, int cout, long long n,
+                                  int relu, float *y, gldm_stream_t stream) {
+  if (!x || !w || !y || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)((n + 255) / 256), b);
+#define GLDM_PS_CASE(C) \
+  if (cin == C) { hipLaunchKernelGGL(pointwise_small_kernel<C>, grid, dim3(256), 0, s, x, w, bias, cout, n, relu, y); \
+                  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH; }
+  GLDM_PS_CASE(3) GLDM_PS_CASE(6) GLDM_PS_CASE(16) GLDM_PS_CASE(24) GLDM_PS_CASE(32) GLDM_PS_CASE(48) GLDM_PS_CASE(64)
+#undef GLDM_PS_CASE
+  return GLDM_ERR_UNSUPPORTED;
+}
+
+GLDM_API int gldm_linear_rows(const float *x, const float *w, const float *bias, int rows, int n, int nout, float *y,
+                              gldm_stream_t stream) {
+  if (!x || !w || !y || rows <= 0 || n <= 0 || nout <= 0) return GLDM_ERR_INVALID_ARG;
+  if ((n & 3) || (size_t)n * 4 > 64 * 1024) return GLDM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(linear_rows_kernel, dim3(rows), dim3(256), (size_t)n * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), x, w, bias, n, nout, y);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 

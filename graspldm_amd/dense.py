@@ -1,8 +1,10 @@
-"""Dense layers of the PVCNN encoder that run as plain library GEMMs: k=1 convs (bias-free GEMM +
-the fused gldm_bias_act epilogue) and Linear over points.  The 3x3x3 voxel convs, GroupNorm+Swish, SE and
-devoxelize are hand-written kernels (voxel.py / csrc/voxel_conv.hip); `conv3d_gn_swish` below is only the
-path for voxel shapes those kernels are not instantiated for.  Never a CPU path: CPU tensors are rejected
-like everywhere else in this package.
+"""Dense k = 1 layers of the point-cloud encoders.  On the shipped PVCNN encoder every one of them is a hand-written
+launch: the wide SharedMLP layers + head (gldm_pointwise_mlp*: MFMA GEMMs, the 768 -> 1536 one on split-bf16 operands),
+the narrow point-branch convs (gldm_pointwise_small) and the Linear over the point axis (gldm_linear_rows).  Layer shapes
+outside those kernels' sets (PVCNN2 / PointNet++ widths such as 64 -> 128 over a few hundred centres) are one library
+GEMM + the fused bias/activation pass.  Voxel convs have no library path at all (csrc/voxel_conv.hip, with a direct VALU
+kernel for shapes without an MFMA instantiation).  Never a CPU path: CPU tensors are rejected like everywhere else in
+this package.
 """
 import os
 
@@ -26,12 +28,26 @@ def swish(x):
     return x * torch.sigmoid(x)
 
 
+SMALL_CIN = (3, 6, 16, 24, 32, 48, 64)   # widths gldm_pointwise_small is instantiated for
+
+
 def _gemm_bias_act(x, w2d, bias, relu):
-    """act(W x + b) over [B, Cin, ...]: one library GEMM (the k = 1 convolution without bias: MIOpen hands it to
-    rocBLAS strided-batched) + ONE in-place epilogue pass (gldm_bias_act) instead of a bias pass and a ReLU pass."""
+    """act(W x + b) over [B, Cin, ...].  Narrow inputs (cin in SMALL_CIN: the PVConv point branches of the shipped
+    encoder) run in the hand-written lane-per-point kernel (gldm_pointwise_small); wider layers that the fused
+    MFMA launches are not built for (PVCNN2 / PointNet++ shapes outside the shipped encoder) are one library GEMM (the
+    k = 1 convolution without bias) + ONE in-place epilogue pass (gldm_bias_act)."""
     from . import _lib as L
     shape = x.shape
     x3 = x.reshape(shape[0], shape[1], -1)
+    if shape[1] in SMALL_CIN and x3.is_contiguous():
+        n = x3.shape[-1]
+        y = torch.empty((shape[0], w2d.shape[0], n), dtype=torch.float32, device=x.device)
+        wc = w2d.contiguous()
+        bc = bias.contiguous() if bias is not None else None
+        with torch.cuda.device(x.device):
+            L.call("gldm_pointwise_small", L.ptr(x3), L.ptr(wc), L.ptr(bc), int(shape[0]), int(shape[1]),
+                   int(w2d.shape[0]), n, int(relu), L.ptr(y), L.current_stream(x.device))
+        return y.reshape(shape[0], w2d.shape[0], *shape[2:])
     y = F.conv1d(x3, w2d.unsqueeze(-1))
     n = y.shape[-1]
     if bias is not None or relu:
@@ -151,13 +167,27 @@ def pointwise_conv_bn_relu(x, conv, bn):
 
 
 def conv3d_gn_swish(x, conv, gn):
-    """Swish(GroupNorm(Conv3d_k3(x)))  (pvconv.py:48-66)."""
-    _need_cuda(x)
-    h = F.conv3d(x, conv.weight, conv.bias, padding=conv.padding)
-    h = F.group_norm(h, gn.num_groups, gn.weight, gn.bias, gn.eps)
-    return h * torch.sigmoid(h)
+    """Swish(GroupNorm(Conv3d_k3(x)))  (pvconv.py:48-66) for a voxel shape csrc/voxel_conv.hip has no instantiation
+    for: there is no library fallback on this path, the caller gets a GldmError naming the shape."""
+    from ._lib import GldmError
+    raise GldmError(f"voxel conv {conv.in_channels} -> {conv.out_channels} at resolution {x.shape[-1]} is not instantiated "
+                    "in csrc/voxel_conv.hip (channels % 16 == 0, resolution % 4 == 0 and one of the (channels / 16, "
+                    "resolution / 4) pairs of graspldm_amd.voxel.SUPPORTED): add the instantiation")
 
 
 def linear(x, lin):
+    """nn.Linear over the last axis of [..., n] (the encoder's out_layer[1] over the POINT axis): hand-written row
+    kernel (gldm_linear_rows); n % 4 == 0 and n <= 16384, else the library GEMM."""
     _need_cuda(x)
+    n, nout = lin.weight.shape[1], lin.weight.shape[0]
+    if n % 4 == 0 and n <= 16384:
+        from . import _lib as L
+        xf = x.contiguous().float()
+        rows = xf.numel() // n
+        y = torch.empty((*xf.shape[:-1], nout), dtype=torch.float32, device=x.device)
+        w = lin.weight.contiguous()
+        with torch.cuda.device(x.device):
+            L.call("gldm_linear_rows", L.ptr(xf), L.ptr(w), L.ptr(lin.bias), rows, n, nout, L.ptr(y),
+                   L.current_stream(x.device))
+        return y
     return F.linear(x, lin.weight, lin.bias)

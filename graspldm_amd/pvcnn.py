@@ -310,7 +310,7 @@ class PVConv(nn.Module):
         se = mods[-1] if isinstance(mods[-1], SE3d) else None
         from . import voxel
         pf = self.point_features(features)
-        if all(voxel.conv_supported(c.out_channels, self.resolution) for c in convs):
+        if self.resolution % 4 == 0:
             # hand-written path: implicit-GEMM conv3d on f32 MFMA, GN+Swish, SE gate folded into the
             # devoxelize pass together with the point-branch add
             plan = self.__dict__.get("_voxel_plan")
@@ -322,12 +322,8 @@ class PVConv(nn.Module):
                 self.__dict__["_voxel_plan"] = plan
                 publish(vox.device)
             return voxel.run(plan, convs, norms, se, vox, norm_coords, pf, self.resolution), coords
-        h = dense.conv3d_gn_swish(vox, convs[0], norms[0])
-        h = dense.conv3d_gn_swish(h, convs[1], norms[1])
-        if se is not None:
-            h = se(h)
-        out = trilinear_devoxelize(h, norm_coords, self.resolution, False)
-        return out + pf, coords
+        # resolutions that are not a multiple of the 4 x 4 x r brick: no kernel (raises GldmError naming the shape)
+        return dense.conv3d_gn_swish(vox, convs[0], norms[0]), coords
 
 
 # --------------------------------------------------------------------- builders

@@ -47,8 +47,11 @@ class VoxelBranchPlan:
 
     def __init__(self, convs, device, r=None):
         self.split = [r is not None and split_conv_supported(c.in_channels, c.out_channels, r) for c in convs]
-        self.w = [(pack_conv3d_bf16x3(c.weight) if sp else pack_conv3d(c.weight)).to(device)
-                  for c, sp in zip(convs, self.split)]
+        # shapes without an MFMA instantiation run the direct kernel on the raw nn.Conv3d weight
+        self.generic = [r is not None and not conv_supported(c.out_channels, r) for c in convs]
+        self.w = [(c.weight.detach().float().contiguous() if gen else
+                   (pack_conv3d_bf16x3(c.weight) if sp else pack_conv3d(c.weight))).to(device)
+                  for c, sp, gen in zip(convs, self.split, self.generic)]
         self.key = None  # set by the owner (PVConv.forward) from _cache.params_key
 
 
@@ -65,7 +68,8 @@ def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
             y = torch.empty((b, cout, r, r, r), dtype=torch.float32, device=dev)
             nf = L.lib().gldm_conv3d_partial_floats(b, cout, r)
             partial = torch.empty(int(nf), dtype=torch.float32, device=dev)
-            L.call("gldm_conv3d_k3_bf16x3" if plan.split[i] else "gldm_conv3d_k3", L.ptr(x), L.ptr(plan.w[i]),
+            entry = "gldm_conv3d_k3_generic" if plan.generic[i] else ("gldm_conv3d_k3_bf16x3" if plan.split[i] else "gldm_conv3d_k3")
+            L.call(entry, L.ptr(x), L.ptr(plan.w[i]),
                    L.ptr(conv.bias), b, cin, cout, r, L.ptr(y), L.ptr(partial), st)
             last = i == len(convs) - 1
             if last and se is not None:

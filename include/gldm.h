@@ -298,6 +298,17 @@ int gldm_pointwise_mlp2(const float *x /*[b,cin0,n]*/, const float *w0_packed, c
                         const float *head_w_packed, const float *head_bias, int hout,
                         float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
 
+/* ref: shared_mlp.py:6-35 for NARROW layers (the PVConv point branches 3 -> 48, 48 -> 96): y = act(W x + bias) over
+ * [b, cin, n] with W [cout, cin] row major (BatchNorm folded by the caller); cin in {3, 6, 16, 24, 32, 48, 64}.
+ * VALU kernel (lane = point), k-ordered fma chain from the bias. */
+int gldm_pointwise_small(const float *x /*[b,cin,n]*/, const float *w /*[cout,cin]*/, const float *bias /*[cout] or NULL*/,
+                         int b, int cin, int cout, long long n, int relu, float *y /*[b,cout,n]*/, gldm_stream_t stream);
+
+/* ref: pc_encoders.py:60-82,104-111: out_layer[1] = nn.Linear(n_points, latent) applied over the POINT axis of
+ * [B, C, N]: y[row, :] = W x[row, :] + bias for rows = B * C; n % 4 == 0, n <= 16384. */
+int gldm_linear_rows(const float *x /*[rows,n]*/, const float *w /*[nout,n]*/, const float *bias /*[nout] or NULL*/,
+                     int rows, int n, int nout, float *y /*[rows,nout]*/, gldm_stream_t stream);
+
 /* The same two entry points with the MAIN layer's weights as split-bf16 fragments (graspldm_amd/r1d_pack.py:
  * mfma_a_fragments_bf16x3; layout above): the GEMM runs on the bf16 matrix pipe with six partial products per f32
  * product and f32 accumulation (error of the order of one f32 rounding per product, 6/16 of the f32-MFMA time).  The
@@ -324,6 +335,13 @@ long long gldm_conv3d_partial_floats(int b, int cout, int r);
 int gldm_conv3d_k3(const float *x /*[b,cin,r^3]*/, const float *w_packed, const float *bias /*[cout]*/,
                    int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/, float *partial,
                    gldm_stream_t stream);
+
+/* The same conv for ANY channel counts (r % 4 == 0) with the weight as nn.Conv3d stores it, [cout, cin, 27] f32: a
+ * direct VALU kernel for voxel shapes the MFMA kernels are not instantiated for (PVCNN2's 256 ch @ 8^3, 128 ch @ 16^3);
+ * same `partial` layout.  A correctness path: no shape of the shipped encoder uses it. */
+int gldm_conv3d_k3_generic(const float *x /*[b,cin,r^3]*/, const float *w /*[cout,cin,27]*/, const float *bias,
+                           int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/, float *partial,
+                           gldm_stream_t stream);
 
 /* The same conv with split-bf16 weights (graspldm_amd/voxel.py: pack_conv3d_bf16x3: [cout, cblocks * 14 * 32] with
  * k = ((16-channel block) * 14 + tap pair) * 32 + 16 (tap - 2 pair) + channel, as mfma_a_fragments_bf16x3 fragments):
