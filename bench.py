@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--scheduler", choices=["ddim", "ddpm"], default="ddim",
                     help="ddpm with --ddim-steps 1000 --points 4096 --grasps 200 is BASELINE.json configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--minimal", action="store_true",
+                    help="only the timed steps + the roofline launches of the dominant kernel (no stage split, no "
+                         "set-abstraction / one-object records): what the rocprofv3 --stats run uses, so that the "
+                         "kernel's average duration in the trace is over bench-workload launches only")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective plumbing only, on CPU over gloo (no HIP, no numbers): used by the tests")
     ap.add_argument("--streams", type=int, default=3,
@@ -284,72 +288,74 @@ def main():
                               "never issues those padding products (1/6 of the k=3 conv MFMAs).  Arithmetic: f32 in, f32 "
                               "out, f32 accumulation; products formed from bf16 pieces whose dropped cross terms are "
                               "<= 2^-23 relative (parity bars unchanged: 2e-5 single forward, 1e-4 poses)")
-        # ---- stage split and the set-abstraction gather (north-star HBM kernel), same run
-        t_enc = event_time(lambda: ldm.vae_model.encode_pc(pcs), 6)
-        dec = ldm.vae_model.decoder
-        lat = dn().squeeze(-2)
-        t_dec = event_time(lambda: dec(lat, z, samples_per_cond=G), 10, lead=2)
-        kernels = [dict(kernel="PVCNNEncoder.forward (all launches)", bound="mfma", avg_ms=t_enc * 1e3,
-                        achieved=(B * ENCODER_FLOP_EXECUTED_PER_CLOUD / t_enc / 1e12) if N == 1024 else None,
-                        peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=(B * ENCODER_FLOP_EXECUTED_PER_CLOUD / t_enc / 1e12 / PEAK_F32_MFMA_TFLOPS) if N == 1024 else None,
-                        note="executed FLOP (head convs folded); the reference graph has %.3f GFLOP per cloud; fraction "
-                             "against the f32 MFMA peak (the 48/96-channel voxel convs and the 768 -> 1536 layer run as "
-                             "split-bf16 products, the rest on the f32 pipe)" % (ENCODER_FLOP_PER_CLOUD / 1e9)),
-                   dict(kernel="r1d_kernel<32, 16> (gldm_decode)", bound="mfma", avg_ms=t_dec * 1e3,
-                        achieved=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12 / PEAK_F32_MFMA_TFLOPS)]
-        from graspldm_amd import _lib as L
-        from graspldm_amd.pvcnn import furthest_point_sample
-        pts = (pcs.transpose(1, 2) * (0.05 / 0.12)).contiguous()
-        c1 = furthest_point_sample(pts, 512)
-        c2 = furthest_point_sample(c1, 128)
-        f1 = torch.randn(B, 128, 512, device=dev)
-        Ns, Ms, Us, Cs = 512, 128, 64, 128
-        grouped = torch.empty(B, 3 + Cs, Ms, Us, device=dev)
-        st = L.current_stream(dev)
-        sa = lambda: L.call("gldm_sa_group", L.ptr(c1), L.ptr(c2), L.ptr(f1), B, Cs, Ns, Ms, 0.4, Us, L.ptr(grouped),
-                            None, st)
-        sa()
-        t_sa = event_time(sa, 10)
-        by = B * (12 * Ns + 4 * Cs * Ns + 12 * Ms + 4 * (Cs + 3) * Ms * Us)
-        kernels.append(dict(kernel="sa_group_kernel (PointNet2SSG SA2 gather: N=512 M=128 U=64 C=128)", bound="hbm",
-                            avg_ms=t_sa * 1e3, achieved=by / t_sa / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
-                            frac=by / t_sa / 1e9 / PEAK_HBM_GBS, algorithmic_bytes_per_launch=by))
-        # fused SA module core (gather + grouped MLP + max; the grouped tensor never reaches HBM)
-        from graspldm_amd.pvcnn import PointNetSAModule, ball_query
-        from graspldm_amd.sa_pack import SaMlpPlan
-        from graspldm_amd.synthetic import load_synthetic_weights
-        sa2 = load_synthetic_weights(PointNetSAModule(num_centers=Ms, radius=0.4, num_neighbors=Us, in_channels=Cs,
-                                                      out_channels=(128, 128, 256)).eval(), seed=2).to(dev)
-        plan = SaMlpPlan(sa2.mlps[0], dev)
-        idx = ball_query(c2, c1, 0.4, Us)
-        fsa = lambda: plan.run(c1, c2, f1, idx)
-        fsa()
-        t_fsa = event_time(fsa, 10)
-        sa_flop = B * 2 * Ms * Us * (131 * 128 + 128 * 128 + 128 * 256)
-        kernels.append(dict(kernel="sa_mlp2_kernel (SSG SA2 fused gather + MLP 131-128-128-256 + max, 128-column tiles)", bound="mfma",
-                            avg_ms=t_fsa * 1e3, achieved=sa_flop / t_fsa / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
-                            unit="TFLOP/s", frac=sa_flop / t_fsa / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                            hbm_bytes_avoided=B * 4 * (Cs + 3) * Ms * Us))
-        # ---- BASELINE.json configs[1]: ONE object (B = 1, G grasps), latency per stage and end to end
-        if args.scheduler == "ddim":
-            pc1, x1 = pcs[:1].contiguous(), x_T[:G].contiguous()
-            z1 = ldm.vae_model.encode_pc(pc1)
-            ce1 = eng.cond_embed(z1)
-            dn1 = lambda: eng.denoise(x1, ce1, G, timesteps=ts, sched_kind=kind, coef=coef)
-            lat1 = dn1().squeeze(-2)
-            def obj1():
-                (tm1, lg1), _ = ldm.generate_grasps(pc1, num_grasps=G, x_T=x1)
-                return pose_epilogue(tm1, lg1, gmean[:1], gstd[:1], G)
-            obj1()
-            kernels.append(dict(kernel=f"one object end to end (BASELINE configs[1]: B=1, G={G}, {S} DDIM steps)", bound="latency",
-                                avg_ms=event_time(obj1, 5) * 1e3,
-                                stages_ms=dict(encode=event_time(lambda: ldm.vae_model.encode_pc(pc1), 5) * 1e3,
-                                               denoise=event_time(dn1, 5) * 1e3,
-                                               decode=event_time(lambda: dec(lat1, z1, samples_per_cond=G), 5) * 1e3),
-                                note="latency of a single cloud: the denoise launch is 2 position-major tiles on 2 of 256 CUs, "
-                                     "i.e. the per-step critical path of one workgroup"))
+        kernels = []
+        if not args.minimal:
+          # ---- stage split and the set-abstraction gather (north-star HBM kernel), same run
+          t_enc = event_time(lambda: ldm.vae_model.encode_pc(pcs), 6)
+          dec = ldm.vae_model.decoder
+          lat = dn().squeeze(-2)
+          t_dec = event_time(lambda: dec(lat, z, samples_per_cond=G), 10, lead=2)
+          kernels = [dict(kernel="PVCNNEncoder.forward (all launches)", bound="mfma", avg_ms=t_enc * 1e3,
+                          achieved=(B * ENCODER_FLOP_EXECUTED_PER_CLOUD / t_enc / 1e12) if N == 1024 else None,
+                          peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                          frac=(B * ENCODER_FLOP_EXECUTED_PER_CLOUD / t_enc / 1e12 / PEAK_F32_MFMA_TFLOPS) if N == 1024 else None,
+                          note="executed FLOP (head convs folded); the reference graph has %.3f GFLOP per cloud; fraction "
+                               "against the f32 MFMA peak (the 48/96-channel voxel convs and the 768 -> 1536 layer run as "
+                               "split-bf16 products, the rest on the f32 pipe)" % (ENCODER_FLOP_PER_CLOUD / 1e9)),
+                     dict(kernel="r1d_kernel<32, 16> (gldm_decode)", bound="mfma", avg_ms=t_dec * 1e3,
+                          achieved=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
+                          unit="TFLOP/s", frac=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12 / PEAK_F32_MFMA_TFLOPS)]
+          from graspldm_amd import _lib as L
+          from graspldm_amd.pvcnn import furthest_point_sample
+          pts = (pcs.transpose(1, 2) * (0.05 / 0.12)).contiguous()
+          c1 = furthest_point_sample(pts, 512)
+          c2 = furthest_point_sample(c1, 128)
+          f1 = torch.randn(B, 128, 512, device=dev)
+          Ns, Ms, Us, Cs = 512, 128, 64, 128
+          grouped = torch.empty(B, 3 + Cs, Ms, Us, device=dev)
+          st = L.current_stream(dev)
+          sa = lambda: L.call("gldm_sa_group", L.ptr(c1), L.ptr(c2), L.ptr(f1), B, Cs, Ns, Ms, 0.4, Us, L.ptr(grouped),
+                              None, st)
+          sa()
+          t_sa = event_time(sa, 10)
+          by = B * (12 * Ns + 4 * Cs * Ns + 12 * Ms + 4 * (Cs + 3) * Ms * Us)
+          kernels.append(dict(kernel="sa_group_kernel (PointNet2SSG SA2 gather: N=512 M=128 U=64 C=128)", bound="hbm",
+                              avg_ms=t_sa * 1e3, achieved=by / t_sa / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                              frac=by / t_sa / 1e9 / PEAK_HBM_GBS, algorithmic_bytes_per_launch=by))
+          # fused SA module core (gather + grouped MLP + max; the grouped tensor never reaches HBM)
+          from graspldm_amd.pvcnn import PointNetSAModule, ball_query
+          from graspldm_amd.sa_pack import SaMlpPlan
+          from graspldm_amd.synthetic import load_synthetic_weights
+          sa2 = load_synthetic_weights(PointNetSAModule(num_centers=Ms, radius=0.4, num_neighbors=Us, in_channels=Cs,
+                                                        out_channels=(128, 128, 256)).eval(), seed=2).to(dev)
+          plan = SaMlpPlan(sa2.mlps[0], dev)
+          idx = ball_query(c2, c1, 0.4, Us)
+          fsa = lambda: plan.run(c1, c2, f1, idx)
+          fsa()
+          t_fsa = event_time(fsa, 10)
+          sa_flop = B * 2 * Ms * Us * (131 * 128 + 128 * 128 + 128 * 256)
+          kernels.append(dict(kernel="sa_mlp2_kernel (SSG SA2 fused gather + MLP 131-128-128-256 + max, 128-column tiles)", bound="mfma",
+                              avg_ms=t_fsa * 1e3, achieved=sa_flop / t_fsa / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
+                              unit="TFLOP/s", frac=sa_flop / t_fsa / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                              hbm_bytes_avoided=B * 4 * (Cs + 3) * Ms * Us))
+          # ---- BASELINE.json configs[1]: ONE object (B = 1, G grasps), latency per stage and end to end
+          if args.scheduler == "ddim":
+              pc1, x1 = pcs[:1].contiguous(), x_T[:G].contiguous()
+              z1 = ldm.vae_model.encode_pc(pc1)
+              ce1 = eng.cond_embed(z1)
+              dn1 = lambda: eng.denoise(x1, ce1, G, timesteps=ts, sched_kind=kind, coef=coef)
+              lat1 = dn1().squeeze(-2)
+              def obj1():
+                  (tm1, lg1), _ = ldm.generate_grasps(pc1, num_grasps=G, x_T=x1)
+                  return pose_epilogue(tm1, lg1, gmean[:1], gstd[:1], G)
+              obj1()
+              kernels.append(dict(kernel=f"one object end to end (BASELINE configs[1]: B=1, G={G}, {S} DDIM steps)", bound="latency",
+                                  avg_ms=event_time(obj1, 5) * 1e3,
+                                  stages_ms=dict(encode=event_time(lambda: ldm.vae_model.encode_pc(pc1), 5) * 1e3,
+                                                 denoise=event_time(dn1, 5) * 1e3,
+                                                 decode=event_time(lambda: dec(lat1, z1, samples_per_cond=G), 5) * 1e3),
+                                  note="latency of a single cloud: the denoise launch is 2 position-major tiles on 2 of 256 CUs, "
+                                       "i.e. the per-step critical path of one workgroup"))
         # ---- CPU baseline: the torch-CPU oracle on this box's host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.scheduler == "ddim":

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collects the per-round profile set on the GPU box (run from the repo root through gpurun):
+#   bash tools/collect_profiles.sh r03      -> gpurun_out/profiles_r03/*   (copy what is to be judged into profiles/)
+tag=${1:-rXX}
+root=$GRAFT_REPO_ROOT
+out=$root/gpurun_out/profiles_$tag
+mkdir -p $out
+cd $root
+python bench.py --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/bench.err
+python bench.py --scheduler ddpm --ddim-steps 1000 --points 4096 --grasps 200 --clouds-per-gpu 8 --steps 3 --warmup 1 > $out/${tag}_bench_c5.json 2>> $out/bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_s1 -o run -- /usr/bin/python3 $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --streams 1 --minimal > $out/${tag}_bench_streams1_under_rocprof.json 2> $out/prof.err
+cd $root
+python3 - $out $tag <<'PY'
+import csv, glob, sys
+out, tag = sys.argv[1], sys.argv[2]
+f = glob.glob(out + "/prof_s1/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.reader(open(f)))
+with open(f"{out}/{tag}_bench_streams1_kernel_stats.csv", "w", newline="") as g:
+    w = csv.writer(g)
+    for r in rows:
+        r[0] = r[0][:140]
+        w.writerow(r)
+PY
+bash tools/pmc_denoise.sh $tag > $out/pmc.log 2>&1
+cp gpurun_out/pmc_$tag.json $out/${tag}_denoise_pmc.json
+cp gpurun_out/pmc_$tag.txt $out/${tag}_denoise_pmc_counters.txt
+rm -rf $out/prof_s1
+head -c 600 $out/${tag}_bench.json; echo; head -c 300 $out/${tag}_bench_c5.json; echo; head -5 $out/${tag}_bench_streams1_kernel_stats.csv | cut -c1-160
