@@ -324,10 +324,11 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
 // partial products of weight >= 2^-16 accumulated in f32: the error of an f32 rounding per product at 6/16 of the
 // f32-MFMA time (see csrc/resnet1d.hip, "split-bf16 GEMM core").  K is walked as (16-channel block, PAIR of taps):
 // lane group g of a fragment = (tap 2 p + (g >> 1), channels 8 (g & 1) .. + 7); 27 taps = 13 pairs + one half-empty
-// (zero weights).  The brick stays f32 in LDS (same staging as the f32 kernel); a lane reads its 8 channels of a voxel
-// (8 ds_read_b32, one LDS row apart) and splits them (36 VALU) once per (pair, n-tile), and the planes then serve three
-// m-tiles x six MFMAs: work is walked in groups of 3 m-tiles x 3 n-tiles so that the A sets (double buffered), the B
-// planes and the 72 accumulators fit 256 registers.  Weights: graspldm_amd/voxel.py: pack_conv3d_bf16x3.
+// (zero weights).  Work is walked in groups of 3 m-tiles x 3 n-tiles so that the A sets (double buffered), the B planes
+// and the accumulators fit 256 registers.  Weights: graspldm_amd/voxel.py: pack_conv3d_bf16x3.
+// (First form, measured and replaced: the brick kept f32 in LDS, every lane splitting its 8 channels of a voxel again
+// for each (tap pair, n-tile): 2.4 / 0.9 ms per launch at 256 clouds against 2.1 / 0.8 with the pre-split planes below,
+// 3.55 / 1.25 on the f32 pipe.)
 typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 c3_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float c3_f32x2;
@@ -363,14 +364,29 @@ __device__ __forceinline__ f32x4 c3_mfma6(const c3_u32x4 (&a)[3], const c3_u32x4
 
 constexpr int kPairs = 14;  // tap pairs per 16-channel block (the last one holds tap 26 and zeros)
 
-template <int MT, int NTW>
-__global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_bf_kernel(const float *__restrict__ x,
-                                                                       const float *__restrict__ wp3,
-                                                                       const float *__restrict__ bias, int cin, int cout,
-                                                                       float *__restrict__ y, float *__restrict__ partial) {
-  constexpr int r = 4 * NTW;
-  static_assert(MT % 3 == 0 && NTW % 3 == 0 && brick_vec4(r), "walked in 3 x 3 tile groups; float4 staging");
+// ---- split-bf16 conv with the brick PRE-SPLIT in LDS --------------------------------------------------------------------
+// Splitting a lane's 8 channels of a voxel for every (tap pair, n-tile) that touches it means ~27 splits per element
+// and wave, 36 VALU instructions per 18-36 MFMAs, with the two waves of a SIMD doing it in lock step.  Here the
+// staging threads split each brick element ONCE and keep the three bf16 planes in LDS, channel-minor:
+//   [plane hi|mid|lo][voxel of the 6 x 6 x (r + 2) haloed brick][16 channels]      (32 B per voxel and plane)
+// so a B fragment plane is ONE ds_read_b128 per lane (voxel of its column + the tap of its lane group, channel half)
+// and the tap loop is LDS reads + buffer loads + MFMA.  96 B per voxel instead of 64: the 24^3 brick takes 90 KiB, one
+// workgroup of 8 waves per CU (3 n-tiles each); the 12^3 brick 48 KiB, 4 waves, three workgroups per CU.
+// Staging: an item = (voxel, 8-channel half): 8 dword loads one channel apart (coalesced along z), 36 VALU, three
+// ds_write_b128; the next block's raw values are requested before the tap loop and split / stored after it.
+template <int MT, int R, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) void conv3d_k3_pl_kernel(const float *__restrict__ x,
+                                                                                      const float *__restrict__ wp3,
+                                                                                      const float *__restrict__ bias, int cin,
+                                                                                      int cout, float *__restrict__ y,
+                                                                                      float *__restrict__ partial) {
+  constexpr int r = R, NTW = R / WAVES, kThreads = 64 * WAVES;
+  static_assert(NTW % 3 == 0 && MT % 3 == 0, "tiles walked in 3 x 3 groups");
   constexpr int MG = MT / 3, NG = NTW / 3;
+  // (Measured and kept out: 4 waves x 6 n-tiles on the 24^3 brick -- half the weight-fragment deliveries, but more than
+  // 256 registers, hence one wave per SIMD -- 0.74 ms per launch against 0.67 for 8 waves x 3 n-tiles.)
+  constexpr int zp = r + 2, nvox = 36 * zp, r3 = r * r * r;
+  constexpr int kItems = 2 * nvox, kRounds = (kItems + kThreads - 1) / kThreads;
   extern __shared__ float lds[];
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -378,20 +394,20 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_bf_kernel(const flo
   const int bpr = r / kBrick;
   const int bx0 = (blockIdx.x / bpr) * kBrick, by0 = (blockIdx.x % bpr) * kBrick;
   const int b = blockIdx.y;
-  constexpr int r3 = r * r * r, zp = brick_zp(r), bvp = brick_row_stride(r);
   const int cblocks = (cin + 15) >> 4, kblocks = kPairs * cblocks;
   x += (size_t)b * cin * r3;
   y += (size_t)b * cout * r3;
   const WStream wv(wp3, lane);
-  const lds_f *l3 = (const lds_f *)lds;
+  typedef __attribute__((address_space(3))) c3_u32x4 lds_c4;
+  lds_c4 *pl = (lds_c4 *)lds;   // 16-byte units: plane * 2 nvox + 2 voxel + half
 
-  // voxel of (n-tile, lane column): LDS offset of its (0,0,0) tap in channel row 8 (g & 1); global voxel index
-  int vbase[NTW], gvox[NTW];
+  // fragment read base of (n-tile, lane column): voxel (0,0,0)-tap of the column, this lane's channel half
+  int vb[NTW], gvox[NTW];
 #pragma unroll
   for (int ni = 0; ni < NTW; ++ni) {
     const int o = 16 * (wave * NTW + ni) + col;
     const int iz = o % r, ixy = o / r, ix = ixy >> 2, iy = ixy & 3;
-    vbase[ni] = (ix * 6 + iy) * zp + iz + 3 + 8 * (kq & 1) * bvp;
+    vb[ni] = 2 * ((ix * 6 + iy) * zp + iz) + (kq & 1);
     gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + iz;
   }
   f32x4 acc[MT][NTW];
@@ -403,105 +419,117 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_bf_kernel(const flo
 #pragma unroll
     for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = bvv;
   }
-  // ---- staging (float4 slots aligned with the grid's z; identical to the f32 kernel)
-  constexpr int kSlotsRow = r / 4, kSlots = 36 * kSlotsRow;
-  static_assert(kSlots <= kConvThreads, "one interior slot per thread");
-  int s_lds = -1, s_glb = -1;
-  if (tid < kSlots) {
-    const int ixy = tid / kSlotsRow, k = tid - ixy * kSlotsRow;
-    const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1;
-    s_lds = ixy * zp + 4 * (k + 1);
-    if ((unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r) s_glb = (gx * r + gy) * r + 4 * k;
+  // ---- staging map: item i = (voxel i >> 1 ... ) ordered so that consecutive threads take consecutive z of one half
+  int s_lds[kRounds], s_glb[kRounds];
+#pragma unroll
+  for (int q = 0; q < kRounds; ++q) {
+    const int it = tid + q * kThreads;
+    s_lds[q] = -1;
+    s_glb[q] = -1;
+    if (it < kItems) {
+      const int h = it / nvox, v = it - h * nvox;       // half-major: a wave's loads run along z
+      const int ixy = v / zp, izp = v - ixy * zp;
+      const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1, gz = izp - 1;
+      s_lds[q] = 2 * v + h;
+      if ((unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r && (unsigned)gz < (unsigned)r)
+        s_glb[q] = (gx * r + gy) * r + gz + 8 * h * r3;
+    }
   }
+  // halo voxels outside the grid stay zero for the whole kernel: written once, all three planes
   {
-    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < 72) {
-      float *lc = lds + (tid >> 1) * zp + ((tid & 1) ? 4 * (kSlotsRow + 1) : 0);
+    const c3_u32x4 z4 = c3_u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int ci = 0; ci < 16; ++ci) *reinterpret_cast<f32x4 *>(lc + ci * bvp) = z4;
-    }
-    if (s_lds >= 0 && s_glb < 0) {
-      float *lc = lds + s_lds;
+    for (int q = 0; q < kRounds; ++q)
+      if (s_lds[q] >= 0 && s_glb[q] < 0) {
 #pragma unroll
-      for (int ci = 0; ci < 16; ++ci) *reinterpret_cast<f32x4 *>(lc + ci * bvp) = z4;
-    }
+        for (int p3 = 0; p3 < 3; ++p3) pl[p3 * 2 * nvox + s_lds[q]] = z4;
+      }
   }
-  f32x4 stv[16];
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, cin * r3 * 4, 0x00020000);
+  float stg[kRounds][8];
   auto stage_load = [&](int cb) {
-    const int g0 = s_glb >= 0 ? s_glb : 0;
+    const float *xc = x + (size_t)(cb * 16) * r3;
 #pragma unroll
-    for (int ci = 0; ci < 16; ++ci)
-      stv[ci] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((cb * 16 + ci) * r3 + g0) * 4, 0, 0));
+    for (int q = 0; q < kRounds; ++q) {
+      const int g0 = s_glb[q] >= 0 ? s_glb[q] : 0;   // unconditional loads on a clamped address
+#pragma unroll
+      for (int j = 0; j < 8; ++j) stg[q][j] = xc[(size_t)j * r3 + g0];
+    }
   };
   auto stage_store = [&]() {
-    if (s_glb >= 0) {
-      float *lc = lds + s_lds;
 #pragma unroll
-      for (int ci = 0; ci < 16; ++ci) *reinterpret_cast<f32x4 *>(lc + ci * bvp) = stv[ci];
-    }
+    for (int q = 0; q < kRounds; ++q)
+      if (s_glb[q] >= 0) {
+        c3_u32x4 p3[3];
+        c3_split(stg[q], p3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pl[k * 2 * nvox + s_lds[q]] = p3[k];
+      }
   };
+  stage_load(0);
   for (int cb = 0; cb < cblocks; ++cb) {
-    // staged in place (no register-held prefetch of the next block: its 64 registers are what lets the tap loop keep
-    // two A sets beside the 72 accumulators; the co-resident workgroup computes while this one waits)
-    __syncthreads();
-    stage_load(cb);
+    __syncthreads();   // the previous block's readers are done
     stage_store();
+    if (cb + 1 < cblocks) stage_load(cb + 1);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    // ---- 14 tap pairs x (MG x NG) groups of 3 x 3 tiles
     c3_u32x4 a[2][3][3];
     auto load_a = [&](int buf, int step) {   // step = pair * MG + mg
       const int p = step / MG, mg = step - p * MG;
 #pragma unroll
       for (int mi = 0; mi < 3; ++mi)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          a[buf][mi][pl] = wv.raw((((size_t)(3 * mg + mi) * kblocks + cb * kPairs + p) * 3 + pl) * 64);
+        for (int k = 0; k < 3; ++k)
+          a[buf][mi][k] = wv.raw((((size_t)(3 * mg + mi) * kblocks + cb * kPairs + p) * 3 + k) * 64);
     };
     load_a(0, 0);
     __builtin_amdgcn_s_setprio(0);
     constexpr int kSteps = kPairs * MG;
-    for (int p0 = 0; p0 < kPairs; p0 += 2) {   // two pairs per trip: the A double buffer alternates statically
-#pragma unroll
-    for (int pu = 0; pu < 2; ++pu) {
-      const int p = p0 + pu;
+    constexpr int kUnits = kPairs * NG;   // (pair, n-group) units: the B planes of unit u + 1 are requested during unit u
+    constexpr bool kBPre = NG > 1;   // a second B set costs 36 registers: only where a wave has two n-groups
+    c3_u32x4 bs[kBPre ? 2 : 1][3][3];
+    auto load_b = [&](int buf, int unit) {
+      const int p = unit / NG, ng = unit - p * NG;
       const int ta = 2 * p, tb = 2 * p + 1 < 27 ? 2 * p + 1 : 26;
       const int offa = ((ta / 9) * 6 + (ta / 3) % 3) * zp + ta % 3, offb = ((tb / 9) * 6 + (tb / 3) % 3) * zp + tb % 3;
-      const int toff = (kq >> 1) ? offb : offa;
+      const int toff = 2 * ((kq >> 1) ? offb : offa);
 #pragma unroll
-      for (int ng = 0; ng < NG; ++ng) {
-        c3_u32x4 bs[3][3];
+      for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          float raw[8];
+        for (int k = 0; k < 3; ++k) bs[buf][q][k] = pl[k * 2 * nvox + vb[3 * ng + q] + toff];
+    };
+    if (kBPre) load_b(0, 0);
+    for (int p0 = 0; p0 < kPairs; p0 += 2) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) raw[j] = l3[vbase[3 * ng + q] + toff + j * bvp];
-          c3_split(raw, bs[q]);
-        }
+      for (int pu = 0; pu < 2; ++pu) {
+        const int p = p0 + pu;
 #pragma unroll
-        for (int mg = 0; mg < MG; ++mg) {
-          const int step = p * MG + mg;
-          constexpr int kPar = MG & 1;  // parity of a step's A set: (pu * MG + mg) & 1 (p0 * MG is even)
-          const int cur = (pu * MG + mg) & 1;
-          (void)kPar;
-          // the A set of the next (pair, m-group); with two n-groups a set serves both (requested in the first)
-          if (ng == 0) load_a(cur ^ 1, step + 1 < kSteps ? step + 1 : step);
-          __builtin_amdgcn_sched_barrier(0);
+        for (int ng = 0; ng < NG; ++ng) {
+          const int unit = p * NG + ng;
+          const int bcur = kBPre ? ((pu * NG + ng) & 1) : 0;   // p0 * NG is even
+          if (kBPre) load_b(bcur ^ 1, unit + 1 < kUnits ? unit + 1 : unit);
+          else load_b(0, unit);
 #pragma unroll
-          for (int mi = 0; mi < 3; ++mi)
+          for (int mg = 0; mg < MG; ++mg) {
+            const int step = p * MG + mg;
+            const int cur = (pu * MG + mg) & 1;
+            // the A set of the next (pair, m-group); with two n-groups a set serves both (requested in the first)
+            if (ng == 0) load_a(cur ^ 1, step + 1 < kSteps ? step + 1 : step);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) acc[3 * mg + mi][3 * ng + q] = c3_mfma6(a[cur][mi], bs[q], acc[3 * mg + mi][3 * ng + q]);
-          __builtin_amdgcn_sched_barrier(0);
+            for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+              for (int q = 0; q < 3; ++q)
+                acc[3 * mg + mi][3 * ng + q] = c3_mfma6(a[cur][mi], bs[bcur][q], acc[3 * mg + mi][3 * ng + q]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }
-    }
     __builtin_amdgcn_s_setprio(3);
   }
-  // ---- epilogue: per-channel partial statistics of this brick, then the stores (as in the f32 kernel)
+  // ---- epilogue: per-channel partial statistics of this brick, then the stores
   __syncthreads();
-  float *s_part = lds;
+  float *s_part = lds;  // [WAVES][MT * 16][2]
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
@@ -525,7 +553,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_bf_kernel(const flo
   __syncthreads();
   if (tid < cout) {
     float s = 0.f, s2 = 0.f;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < WAVES; ++w) {
       s += s_part[(w * MT * 16 + tid) * 2];
       s2 += s_part[(w * MT * 16 + tid) * 2 + 1];
     }
@@ -851,16 +879,15 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
   return GLDM_ERR_UNSUPPORTED;
 }
 
-template <int MT, int NTW>
-int launch_conv_bf(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
+template <int MT, int R, int WAVES>
+int launch_conv_pl(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
                    hipStream_t s) {
-  constexpr int r = 4 * NTW;
-  const size_t lds_bytes = (size_t)16 * brick_row_stride(r) * sizeof(float);
+  const size_t lds_bytes = (size_t)3 * 36 * (R + 2) * 32;
   struct Tag {};
-  gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_bf_kernel<MT, NTW>), (int)lds_bytes);
-  const int bpr = r / kBrick;
-  hipLaunchKernelGGL((conv3d_k3_bf_kernel<MT, NTW>), dim3(bpr * bpr, b), dim3(kConvThreads), lds_bytes, s, x, wp3, bias, cin,
-                     cout, y, partial);
+  gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_pl_kernel<MT, R, WAVES>), (int)lds_bytes);
+  const int bpr = R / kBrick;
+  hipLaunchKernelGGL((conv3d_k3_pl_kernel<MT, R, WAVES>), dim3(bpr * bpr, b), dim3(64 * WAVES), lds_bytes, s, x, wp3, bias,
+                     cin, cout, y, partial);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 
@@ -869,8 +896,8 @@ GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const f
   if (!x || !w_split || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
   if (cin % 16 || cout % 48) return GLDM_ERR_UNSUPPORTED;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (cout == 48 && r == 24) return launch_conv_bf<3, 6>(x, w_split, bias, b, cin, cout, y, partial, s);
-  if (cout == 96 && r == 12) return launch_conv_bf<6, 3>(x, w_split, bias, b, cin, cout, y, partial, s);
+  if (cout == 48 && r == 24) return launch_conv_pl<3, 24, 8>(x, w_split, bias, b, cin, cout, y, partial, s);
+  if (cout == 96 && r == 12) return launch_conv_pl<6, 12, 4>(x, w_split, bias, b, cin, cout, y, partial, s);
   return GLDM_ERR_UNSUPPORTED;
 }
 

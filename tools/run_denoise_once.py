@@ -12,6 +12,13 @@ G = int(sys.argv[3]) if len(sys.argv) > 3 else (20 if n % 20 == 0 else 16)  # la
 dev = torch.device("cuda:0")
 ldm = build_fpc_ldm(device=dev); ldm.set_inference_timesteps(100)
 eng = ldm.diffusion_model.model.engine(dev)
+if os.environ.get("GLDM_BLOCKS"):   # e.g. GLDM_BLOCKS=32,64,128: another width sequence (experiments on the weight footprint)
+    from graspldm_amd.resnets import TimeConditionedResNet1D
+    from graspldm_amd.synthetic import load_synthetic_weights
+    net = TimeConditionedResNet1D(dim=4, channels=1, block_channels=tuple(int(v) for v in os.environ["GLDM_BLOCKS"].split(",")),
+                                  input_conditioning_dims=64, resnet_block_groups=4, dropout=0.1, is_time_conditioned=True,
+                                  learned_variance=False, learned_sinusoidal_cond=False, random_fourier_features=True)
+    eng = load_synthetic_weights(net, seed=1).to(dev).eval().engine(dev)
 z = torch.randn(n // G, 3, 64, device=dev); x = torch.randn(n, 1, 4, device=dev)
 cemb = eng.cond_embed(z); ts, coef = ldm.diffusion_model._schedule(dev)
 ts, coef = ts[:steps].contiguous(), coef[:steps].contiguous()
