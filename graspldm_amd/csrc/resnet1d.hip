@@ -438,11 +438,6 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // v_cvt_pk
 }
 // x[0..7] (consecutive k of one column) -> the three planes of a B fragment
 __device__ __forceinline__ void split_bf16x3(const float (&x)[8], u32x4 (&pl)[3]) {
-#ifdef GLDM_BF_NOSPLIT  // timing experiment only: planes = raw bits
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { pl[0][q] = __float_as_uint(x[2 * q]); pl[1][q] = __float_as_uint(x[2 * q + 1]); pl[2][q] = __float_as_uint(x[q]); }
-  return;
-#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float a = x[2 * q], b = x[2 * q + 1];
@@ -460,10 +455,6 @@ __device__ __forceinline__ f32x4 mfma_bf(const u32x4 &a, const u32x4 &b, const f
 }
 // acc += A B with both operands split: small terms first
 __device__ __forceinline__ f32x4 mfma_split6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 acc) {
-#ifdef GLDM_BF_ONEMFMA  // timing experiment only
-  acc[0] += __uint_as_float(b[2][0] ^ b[1][1] ^ b[0][2] ^ b[2][3] ^ b[1][0] ^ b[0][1]);
-  return mfma_bf(a[0], b[0], acc);
-#endif
   acc = mfma_bf(a[0], b[2], acc);
   acc = mfma_bf(a[2], b[0], acc);
   acc = mfma_bf(a[1], b[1], acc);
@@ -758,99 +749,10 @@ __device__ __forceinline__ void gemm1_bf(const Ctx &c, const float *__restrict__
   }
 }
 
-// ---- position-major k = 3 convs (L = 4 positions, 64-column tiles of 16 samples) ----------------------
-// Column = 16 * position + sample, so a 16-column n-tile is ONE position of all 16 samples and the conv is
-//   out_tile[p] = W1 * X_tile[p] + W0 * X_tile[p - 1] + W2 * X_tile[p + 1]      (tiles outside 0..3 do not exist)
-// The zero-padding products of the sample-major layout (tap 0 on a sample's first position, tap 2 on its last:
-// 2 of every 12 tile-MFMAs) are simply never issued, there are no side accumulators and no halo shift of
-// the results: 10 MFMAs per (m-tile, k-step) instead of 12, straight into the output accumulators.
-// A wave computes out tiles P0 .. P0+NP-1 for MT m-tiles; B tiles PB0 .. PB1 are read once per k-block and
-// shared by the three taps.  Same packed weights as the sample-major path (k = tap * Cin + ci).
-template <int MT, int P0, int NP>
-__device__ __forceinline__ void gemm_pm3(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0,
-                                         const float *src, f32x4 (&acc)[MT][NP]) {
-  constexpr int NC = 64;
-  constexpr int PB0 = P0 > 0 ? P0 - 1 : 0, PB1 = P0 + NP < 4 ? P0 + NP : 3, NB = PB1 - PB0 + 1;
-  const int col = c.lane & 15, kq = c.lane >> 4;
-  const int kblocks = 3 * cblocks;
-  const WStream wv(wp, c.lane);
-  int boff[4][NB];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int q = 0; q < NB; ++q) boff[j][q] = swz<NC>(4 * j + kq, 16 * (PB0 + q) + col);
-  // A fragments double buffered over whole 16-channel blocks: block cb + 1's three taps are requested while
-  // block cb's MFMAs issue (one tap's loads in front of each tap sweep), so every weight load has a full
-  // block of this wave's MFMAs (and its SIMD partner's) to arrive.  One workgroup owns the CU here: there is
-  // no co-resident tile whose short phases a deep weight stream could delay.
-  f32x4 a[2][3][MT];
-  float b[2][4][NB];
-  const lds_f *src3 = (const lds_f *)src;
-  auto load_b = [&](int buf, int cb) {
-    const lds_f *s = src3 + cb * 16 * NC;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int q = 0; q < NB; ++q) b[buf][j][q] = s[boff[j][q]];
-  };
-  const int last = cblocks - 1;
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) a[0][t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks) * 64];
-  load_b(0, 0);
-#ifdef GLDM_PM_NO_A
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) a[1][t][mi] = a[0][t][mi];
-#endif
-#ifdef GLDM_PM_NO_B
-  load_b(1, 0);
-#endif
-  for (int cb0 = 0; cb0 < cblocks; cb0 += 2) {  // two blocks per trip: both double buffers alternate statically
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int cb = cb0 + u;
-      const int nb = cb + 1 < last ? cb + 1 : last;  // clamped: the loads stay unconditional
-#ifndef GLDM_PM_NO_B
-      load_b(1 - u, nb);
-#endif
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-#ifndef GLDM_PM_NO_A
-#pragma unroll
-#ifdef GLDM_PM_SMALL_A
-        for (int mi = 0; mi < MT; ++mi) a[1 - u][t][mi] = wv[(((size_t)(mt0 + mi) * kblocks + t * cblocks + nb) & 3) * 64];
-#else
-        for (int mi = 0; mi < MT; ++mi) a[1 - u][t][mi] = wv[((size_t)(mt0 + mi) * kblocks + t * cblocks + nb) * 64];
-#endif
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-              const int sp = P0 + p + t - 1;  // source position of this tap for out tile P0 + p
-              if (sp >= 0 && sp <= 3)
-                acc[mi][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t][mi][j], b[u][j][sp - PB0 < 0 ? 0 : (sp - PB0 >= NB ? NB - 1 : sp - PB0)],
-                                                                  acc[mi][p], 0, 0, 0);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-}
-
 template <int NC, int L, int TAPS, int MT, int NT>
 __device__ __forceinline__ void gemm_fast(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0, int nt0,
                                           const float *src, f32x4 (&acc)[MT][NT]) {
-#ifndef GLDM_PFMAX6
-#define GLDM_PFMAX6 2
-#endif
-  constexpr int PFMAX = (MT * TAPS > 6) ? 2 : (MT * TAPS > 4 ? GLDM_PFMAX6 : 4);  // register budget
+  constexpr int PFMAX = (MT * TAPS > 6) ? 2 : (MT * TAPS > 4 ? 2 : 4);  // register budget
   if constexpr (TAPS == 3) {
     if ((cblocks & 1) == 0) {
       gemm_fast_tap3<NC, L, MT, NT>(c, wp, cblocks, mt0, nt0, src, acc);
@@ -1182,9 +1084,6 @@ constexpr int kOpInts = 12, kMaxOps = 84;  // op tape: 84 * 12 = 1008 ints; the 
 //   GK 0: partner = the adjacent wave (C = 256: 2 m-tiles per wave, C = 128: 1; all 4 positions)
 //   GK 1: partner = wave ^ 4 (C = 64: one m-tile = one group, positions split in two halves)
 //   GK 2: four waves (one per position) x two groups per m-tile (C = 32: 8 channels per group)
-#ifndef GLDM_PM_EARLY_PARAMS
-#define GLDM_PM_EARLY_PARAMS(MT) false
-#endif
 template <int MT, int P0, int NP, int GK>
 __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, const float *bias, int mt0,
                                               const float *src, int cin, float *dst, int cout, bool alias,
@@ -1215,8 +1114,6 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
       }
     }
   };
-  constexpr bool kEarly = GLDM_PM_EARLY_PARAMS(MT);
-  if (g.mode && kEarly) load_params();
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1233,7 +1130,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
     if (cin <= kPlaneMaxC) gemm_pm3_pl<MT, P0, NP>(c, wp, cin, mt0, c.lds + (src_is_x ? kPlaneX : kPlaneH), acc);
     else gemm_pm3_bf<MT, P0, NP>(c, wp, cin, mt0, src, acc);
   }
-  if (g.mode && !kEarly) load_params();
+  if (g.mode) load_params();
   const bool out_planes = cout <= kPlaneMaxC;  // outputs of up to 128 channels are also (or only) written as planes
   if (!g.mode) {  // the level's down conv: the new residual stream X (f32) and, up to 128 channels, its planes
     if (alias) __syncthreads();
@@ -2867,9 +2764,6 @@ int ss_table_rows(const gldm_r1d_desc *d) {
 // configurations: 4 positions, no input layer / heads, emb_dim 16, a 4-channel first level and 32..256-channel
 // ones after it.  Anything else runs on the sample-major 32-column engine.
 bool pm_supported(const gldm_r1d_desc *d) {
-#ifdef GLDM_R1D_SAMPLE_MAJOR
-  return false;
-#endif
   if (d->seq_len != 4 || d->latent_dim != 0 || d->n_head != 0 || d->emb_dim != 16 || d->groups != 4) return false;
   if (d->dims[0] != 4) return false;
   for (int i = 0; i < d->n_levels; ++i)  // to_qkv with the PreNorm gain folded in (ABI 4 packers provide it)

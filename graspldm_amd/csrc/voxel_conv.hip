@@ -230,25 +230,15 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
 #endif
       if (kLate && tap == 25 && cb + 1 < cblocks) stage_load(cb + 1);
       const int tn = tap + 1 < 27 ? tap + 1 : tap;
-#ifndef GLDM_C3_NO_A
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) a_nxt[mi] = wv[((size_t)mi * kblocks + tn * cblocks + cb) * 64];
-#else
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) a_nxt[mi] = a_cur[mi];
-#endif
       const int toff = ((tap / 9) * 6 + (tap / 3) % 3) * zp + tap % 3;
       const int tnoff = ((tn / 9) * 6 + (tn / 3) % 3) * zp + tn % 3;
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
         const int noff = j + 1 < JN ? toff + 4 * (j + 1) * bvp : tnoff;  // the read after the last one is redundant
-#ifndef GLDM_C3_NO_B
 #pragma unroll
         for (int ni = 0; ni < NTW; ++ni) bn[ni] = l3[obase[ni] + noff];
-#else
-#pragma unroll
-        for (int ni = 0; ni < NTW; ++ni) bn[ni] = bf[ni] + (float)noff * 1e-9f;
-#endif
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -309,11 +299,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
       const int co = 16 * mi + 4 * kq + q;
       if (co < cout) {
 #pragma unroll
-#ifndef GLDM_C3_NO_STORE
         for (int ni = 0; ni < NTW; ++ni) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
-#else
-        for (int ni = 0; ni < NTW; ++ni) if (acc[mi][ni][q] == 1.2345f) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
-#endif
       }
     }
   GLDM_C3_STAMP(21);
@@ -746,7 +732,7 @@ __global__ __launch_bounds__(256) void pointwise_small_kernel(const float *__res
 }
 
 // y[row, o] = bias[o] + sum_n W[o, n] x[row, n]: one workgroup per row (rows = batch x channels: a few hundred),
-// the row staged in LDS, thread = output feature, k in ascending order.
+// the row staged in LDS, thread = output feature, four interleaved k-ordered fma chains.
 __global__ __launch_bounds__(256) void linear_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                           const float *__restrict__ bias, int n, int nout,
                                                           float *__restrict__ y) {
@@ -756,15 +742,15 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float *__restric
   __syncthreads();
   for (int o = threadIdx.x; o < nout; o += 256) {
     const float *wr = w + (size_t)o * n;
-    float acc = bias ? bias[o] : 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four interleaved chains: shorter dependency and error chains
     for (int i = 0; i < n; i += 4) {
       const float4 wv = *reinterpret_cast<const float4 *>(wr + i);
-      acc = fmaf(wv.x, xs[i], acc);
-      acc = fmaf(wv.y, xs[i + 1], acc);
-      acc = fmaf(wv.z, xs[i + 2], acc);
-      acc = fmaf(wv.w, xs[i + 3], acc);
+      a0 = fmaf(wv.x, xs[i], a0);
+      a1 = fmaf(wv.y, xs[i + 1], a1);
+      a2 = fmaf(wv.z, xs[i + 2], a2);
+      a3 = fmaf(wv.w, xs[i + 3], a3);
     }
-    y[(size_t)row * nout + o] = acc;
+    y[(size_t)row * nout + o] = ((a0 + a1) + (a2 + a3)) + (bias ? bias[o] : 0.f);
   }
 }
 

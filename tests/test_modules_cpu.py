@@ -195,3 +195,42 @@ def test_modules_refuse_cpu_tensors():
         ldm.vae_model.encode_pc(torch.zeros(1, 1024, 3))
     with pytest.raises(RuntimeError, match="CUDA tensor|GPU only"):
         ldm.generate_grasps(torch.zeros(1, 1024, 3), num_grasps=2)
+
+
+def test_split_bf16_fragments_are_exact_and_in_mfma_order():
+    """mfma_a_fragments_bf16x3 (include/gldm.h, "Split-bf16 weight fragments"): hi + mid + lo == w bit for bit, and
+    lane l of fragment (mt, kb, plane) holds W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + j]."""
+    from graspldm_amd.r1d_pack import mfma_a_fragments_bf16x3, split_bf16x3
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(40, 96, generator=g) * torch.logspace(-6, 3, 96).unsqueeze(0)   # wide dynamic range
+    hi, mid, lo = split_bf16x3(w)
+    assert torch.equal(hi.float() + mid.float() + lo.float(), w)
+    assert (mid.float().abs() <= hi.float().abs() * 2.0 ** -7 + 1e-45).all()
+    f = mfma_a_fragments_bf16x3(w)
+    assert f.dtype == torch.float32 and f.numel() == 3 * 3 * 3 * 64 * 4          # 3 m-tiles (40 -> 48 rows) x 3 k-blocks
+    fb = f.view(torch.bfloat16).view(3, 3, 3, 64, 8)
+    planes = (hi, mid, lo)
+    for mt, kb, pl, lane, j in [(0, 0, 0, 0, 0), (1, 2, 1, 37, 5), (2, 1, 2, 63, 7), (2, 0, 0, 8, 3)]:
+        row, k = 16 * mt + (lane & 15), 32 * kb + 8 * (lane >> 4) + j
+        exp = planes[pl][row, k].item() if row < 40 else 0.0
+        assert fb[mt, kb, pl, lane, j].item() == exp, (mt, kb, pl, lane, j)
+    with pytest.raises(ValueError):
+        mfma_a_fragments_bf16x3(torch.randn(16, 48))
+
+
+def test_conv3d_split_packing_walks_tap_pairs():
+    """pack_conv3d_bf16x3: k = ((16-channel block) * 14 + pair) * 32 + 16 (tap - 2 pair) + channel; tap 27 is zero."""
+    from graspldm_amd.voxel import pack_conv3d_bf16x3, split_conv_supported
+    from graspldm_amd.r1d_pack import split_bf16x3
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(48, 32, 3, 3, 3, generator=g)
+    f = pack_conv3d_bf16x3(w).view(torch.bfloat16).view(3, 2 * 14, 3, 64, 8)       # [mt][cb * 14 + pair][plane][lane][j]
+    hi = split_bf16x3(w.reshape(48, 32, 27))[0]
+    for co, ci, tap in [(0, 0, 0), (17, 21, 13), (47, 31, 26), (5, 16, 1)]:
+        cb, c16, pair, half = ci // 16, ci % 16, tap // 2, tap % 2
+        k = 16 * half + c16
+        lane, j = (co % 16) + 16 * (k // 8), k % 8
+        assert f[co // 16, cb * 14 + pair, 0, lane, j].item() == hi[co, ci, tap].item()
+    # the empty half of the last pair
+    assert (f[:, 13, :, 32:, :] == 0).all() and (f[:, 27, :, 32:, :] == 0).all()
+    assert split_conv_supported(48, 48, 24) and split_conv_supported(96, 96, 12) and not split_conv_supported(3, 48, 24)
