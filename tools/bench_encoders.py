@@ -8,7 +8,12 @@ Same models, constructor arguments, input distribution (randn [B,3,N]) and metri
 path; no plots (matplotlib / seaborn are not in this image): a JSON file and a markdown table.  `--shipped`
 adds the encoder the shipped configs really use (PVCNNEncoder, scale 0.75/0.75).
 
-    python tools/bench_encoders.py --out profiles/r02_encoder_shootout.json
+Added to the reference's columns: achieved TFLOP/s on the reference graph's FLOP count (tests/golden/encoder_flops.json:
+torch's flop counter over the reference's own modules, oracle/count_flops.py) and its fraction of the f32 MFMA peak
+(157.3 TFLOP/s); `--full-pvcnn2` adds PVCNN2 at width / resolution 1 (42.4 GFLOP per cloud).  Kernel breakdowns:
+`bash tools/prof_kernels.sh <tag> tools/bench_encoders.py --only PVCNN2 --batch-sizes 256 --iterations 5`.
+
+    python tools/bench_encoders.py --shipped --full-pvcnn2 --out profiles/r03_encoder_shootout.json
 """
 import argparse
 import gc
@@ -66,6 +71,8 @@ def main():
     ap.add_argument("--iterations", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shipped", action="store_true", help="also time PVCNNEncoder of the shipped fpc config")
+    ap.add_argument("--full-pvcnn2", action="store_true", help="also time PVCNN2 at width / resolution multiplier 1")
+    ap.add_argument("--only", type=str, default=None, help="run only this model (kernel traces)")
     ap.add_argument("--out", type=str, default=None)
     args = ap.parse_args()
     assert torch.cuda.is_available(), "needs the MI355X"
@@ -88,23 +95,37 @@ def main():
         models["PVCNNEncoder(fpc)"] = _Tr(PVCNNEncoder(in_features=3, out_features=64, n_points=args.points,
                                                        scale_channels=0.75, scale_voxel_resolution=0.75,
                                                        num_blocks=(1, 1, 1, 1), out_channels=3))
+    if args.full_pvcnn2:
+        models["PVCNN2(full)"] = PVCNN2(in_channels=3, extra_feature_channels=0)
+    if args.only:
+        models = {k: v for k, v in models.items() if k == args.only}
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "encoder_flops.json")) as f:
+        flops = {k: v["flop_per_cloud"] for k, v in json.load(f)["models"].items()}
+    PEAK = 157.3
     results = {}
     for name, m in models.items():
         load_synthetic_weights(m, seed=0)
         m = m.cuda().eval()
         results[name] = benchmark_model(m, args.batch_sizes, args.points, 3, args.iterations, args.warmup)
         for b, r in results[name].items():
+            fl = flops.get(name) if args.points == 1024 else None
+            r["reference_gflop_per_cloud"] = fl / 1e9 if fl else None
+            r["achieved_tflops"] = fl * b / (r["avg_latency_ms"] * 1e-3) / 1e12 if fl else None
+            r["frac_f32_mfma_peak"] = r["achieved_tflops"] / PEAK if fl else None
             print(f"{name:18s} B={b:4d}  avg {r['avg_latency_ms']:8.3f} ms  p95 {r['p95_latency_ms']:8.3f}  "
                   f"{r['throughput_samples_per_sec']:10.1f} clouds/s  peak {r['peak_memory_mb']:8.1f} MB", flush=True)
-    ref = "PVCNN"
+    ref = "PVCNN" if "PVCNN" in results else next(iter(results))
     lines = ["| Batch Size | Model | Avg Latency (ms) | P95 (ms) | P99 (ms) | Throughput (clouds/s) | Peak Memory (MB) | "
-             "Relative Speedup | Parameters (MB) |", "|---|---|---|---|---|---|---|---|---|"]
+             "Relative Speedup | Parameters (MB) | GFLOP / cloud (reference graph) | TFLOP/s | of f32 MFMA peak |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for b in args.batch_sizes:
         for name, res in results.items():
             r = res[b]
             lines.append(f"| {b} | {name} | {r['avg_latency_ms']:.3f} | {r['p95_latency_ms']:.3f} | {r['p99_latency_ms']:.3f} | "
                          f"{r['throughput_samples_per_sec']:.1f} | {r['peak_memory_mb']:.1f} | "
-                         f"{results[ref][b]['avg_latency_ms'] / r['avg_latency_ms']:.2f}x | {r['model_parameters_mb']:.1f} |")
+                         f"{results[ref][b]['avg_latency_ms'] / r['avg_latency_ms']:.2f}x | {r['model_parameters_mb']:.1f} | "
+                         + (f"{r['reference_gflop_per_cloud']:.3f} | {r['achieved_tflops']:.2f} | {100 * r['frac_f32_mfma_peak']:.1f} % |"
+                            if r.get("achieved_tflops") else "- | - | - |"))
     table = "\n".join(lines)
     print(table)
     if args.out:
