@@ -69,7 +69,9 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
                                                                     const float *__restrict__ wp,
                                                                     const float *__restrict__ bias, int cin, int cout,
                                                                     int r_arg, float *__restrict__ y,
-                                                                    float *__restrict__ partial) {
+                                                                    float *__restrict__ partial, int cout_total, int co0) {
+  // cout output channels starting at channel co0 of a cout_total-channel conv (wp / bias already point at the slice):
+  // wide convs (256 ch @ 8^3, 128 ch @ 16^3: PVCNN2's feature propagation) run as two launches of half the m-tiles
   constexpr int r = 4 * NTW;  // the instantiation fixes the resolution: every division below is by a constant (with a
   (void)r_arg;                // run-time r the index maps of a workgroup cost 8 k cycles before its first load)
   extern __shared__ float lds[];
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
   constexpr int r3 = r * r * r, zp = brick_zp(r), bv = 36 * zp, bvp = brick_row_stride(r);
   const int cblocks = (cin + 15) >> 4, kblocks = 27 * cblocks;
   x += (size_t)b * cin * r3;
-  y += (size_t)b * cout * r3;
+  y += ((size_t)b * cout_total + co0) * r3;
   const WStream wv(wp, lane);  // weight fragments: buffer loads, scalar offsets (see wstream.h)
   const lds_f *l3 = (const lds_f *)lds;
 
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
       s += s_part[(w * MT * 16 + tid) * 2];
       s2 += s_part[(w * MT * 16 + tid) * 2 + 1];
     }
-    float *p = partial + (((size_t)b * gridDim.x + blockIdx.x) * cout + tid) * 2;
+    float *p = partial + (((size_t)b * gridDim.x + blockIdx.x) * cout_total + co0 + tid) * 2;
     p[0] = s;
     p[1] = s2;
   }
@@ -679,13 +681,13 @@ __global__ __launch_bounds__(256) void devoxelize_fused_kernel(const float *__re
 
 template <int MT, int NTW, int JN>
 int launch_conv_jn(const float *x, const float *wp, const float *bias, int b, int cin, int cout, int r, float *y,
-                float *partial, hipStream_t s) {
+                float *partial, hipStream_t s, int cout_total, int co0) {
   const size_t lds_bytes = (size_t)16 * brick_row_stride(r) * sizeof(float);
   struct Tag {};  // one flag array per instantiation
   gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_kernel<MT, NTW, JN>), (int)lds_bytes);
   const int bpr = r / kBrick;
   hipLaunchKernelGGL((conv3d_k3_kernel<MT, NTW, JN>), dim3(bpr * bpr, b), dim3(kConvThreads), lds_bytes, s, x, wp, bias,
-                     cin, cout, r, y, partial);
+                     cin, cout, r, y, partial, cout_total, co0);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 
@@ -811,10 +813,22 @@ GLDM_API long long gldm_conv3d_partial_floats(int b, int cout, int r) {
 
 template <int MT, int NTW>
 int launch_conv(const float *x, const float *wp, const float *bias, int b, int cin, int cout, int r, float *y,
-                float *partial, hipStream_t s) {
+                float *partial, hipStream_t s, int cout_total = -1, int co0 = 0) {
+  if (cout_total < 0) cout_total = cout;
   // a 3-channel input (the first voxel conv) has one real k-step per tap: skip the three of padding
-  return cin <= 4 ? launch_conv_jn<MT, NTW, 1>(x, wp, bias, b, cin, cout, r, y, partial, s)
-                  : launch_conv_jn<MT, NTW, 4>(x, wp, bias, b, cin, cout, r, y, partial, s);
+  return cin <= 4 ? launch_conv_jn<MT, NTW, 1>(x, wp, bias, b, cin, cout, r, y, partial, s, cout_total, co0)
+                  : launch_conv_jn<MT, NTW, 4>(x, wp, bias, b, cin, cout, r, y, partial, s, cout_total, co0);
+}
+
+// a conv of 2 MH m-tiles as two launches of MH (the accumulators of 16 m-tiles do not fit a wave)
+template <int MH, int NTW>
+int launch_conv_halves(const float *x, const float *wp, const float *bias, int b, int cin, int cout, int r, float *y,
+                       float *partial, hipStream_t s) {
+  const size_t kblocks = 27 * (size_t)((cin + 15) >> 4);
+  const int half = 16 * MH;
+  const int rc = launch_conv<MH, NTW>(x, wp, bias, b, cin, half, r, y, partial, s, cout, 0);
+  if (rc != GLDM_OK) return rc;
+  return launch_conv<MH, NTW>(x, wp + (size_t)MH * kblocks * 256, bias + half, b, cin, cout - half, r, y, partial, s, cout, half);
 }
 
 GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *bias, int b, int cin, int cout, int r,
@@ -862,6 +876,8 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
   GLDM_CONV_CASE(4, 1);   // 64 ch @ 4^3
   GLDM_CONV_CASE(8, 1);   // 128 ch @ 4^3
 #undef GLDM_CONV_CASE
+  if (mt == 16 && ntw == 2) return launch_conv_halves<8, 2>(x, w_packed, bias, b, cin, cout, r, y, partial, s);  // 256 ch @ 8^3
+  if (mt == 8 && ntw == 4) return launch_conv_halves<4, 4>(x, w_packed, bias, b, cin, cout, r, y, partial, s);   // 128 ch @ 16^3
   return GLDM_ERR_UNSUPPORTED;
 }
 

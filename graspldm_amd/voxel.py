@@ -6,7 +6,8 @@ import torch
 from . import _lib as L
 from .r1d_pack import mfma_a_fragments
 
-SUPPORTED = {(3, 6), (6, 3), (2, 8), (4, 4), (8, 2), (4, 8), (2, 4), (4, 2), (1, 4), (2, 2), (4, 1), (8, 1)}  # (cout/16, r/4) instantiated in voxel_conv.hip
+SUPPORTED = {(3, 6), (6, 3), (2, 8), (4, 4), (8, 2), (4, 8), (2, 4), (4, 2), (1, 4), (2, 2), (4, 1), (8, 1),
+             (16, 2), (8, 4)}  # (cout/16, r/4) instantiated in voxel_conv.hip (the last two as two half-width launches)
 
 
 def conv_supported(cout, r):
