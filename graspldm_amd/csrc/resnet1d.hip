@@ -702,53 +702,6 @@ __device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__
   }
 }
 
-// 1x1 conv / plain GEMM on split-bf16 operands (position-major engine): MT m-tiles x NT n-tiles of
-// W[.. x 32 KB32] * src.  A fragments double buffered over the 32-deep k-blocks (the loop is fully unrolled: KB32 is
-// 1, 2 or 4); the raw B values of a tile are re-read for the next block right after they have been split.
-// pre(): work independent of the GEMM, run once the first loads are out (the folded LayerNorm's column statistics).
-template <int KB32, int MT, int NT, class PRE = NoPre>
-__device__ __forceinline__ void gemm1_bf(const Ctx &c, const float *__restrict__ wp3, int mt0, int nt0, const float *src,
-                                         f32x4 (&acc)[MT][NT], const PRE &pre = PRE()) {
-  constexpr int NC = 64;
-  const int col = c.lane & 15, g = c.lane >> 4;
-  const WStream wv(wp3, c.lane);
-  const lds_f *src3 = (const lds_f *)src;
-  int b0[NT];
-#pragma unroll
-  for (int ni = 0; ni < NT; ++ni) b0[ni] = pswz(8 * g, 16 * (nt0 + ni) + col);
-  u32x4 a[2][MT][3];
-  float raw[NT][8];
-  auto load_a = [&](int buf, int kb) {
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * KB32 + kb) * 3 + pl) * 64);
-  };
-  load_a(0, 0);
-#pragma unroll
-  for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) raw[ni][j] = src3[b0[ni] + j * NC];
-  __builtin_amdgcn_sched_barrier(0);
-  pre();
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int kb = 0; kb < KB32; ++kb) {
-    if (kb + 1 < KB32) load_a((kb + 1) & 1, kb + 1);
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-      u32x4 bs[3];
-      split_bf16x3(raw[ni], bs);
-      if (kb + 1 < KB32) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[ni][j] = src3[b0[ni] + (32 * (kb + 1) + j) * NC];
-      }
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = mfma_split6(a[kb & 1][mi], bs, acc[mi][ni]);
-    }
-  }
-}
-
 template <int NC, int L, int TAPS, int MT, int NT>
 __device__ __forceinline__ void gemm_fast(const Ctx &c, const float *__restrict__ wp, int cblocks, int mt0, int nt0,
                                           const float *src, f32x4 (&acc)[MT][NT]) {
@@ -1396,7 +1349,7 @@ __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + row0);
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) acc[0][ni] = bv;
-    gemm1_bf<kHidden / 32, 1, NT>(c, wp, mt0, nt0, src, acc);  // cin = 128: the attention's hidden width
+    gemm1_pl<kHidden / 32, 1, NT>(c, wp, mt0, nt0, c.lds + kPlaneH, acc);  // the attention output's planes (cin = 128)
     gv = *reinterpret_cast<const f32x4 *>(gain + row0);
     const float inv_n = __builtin_amdgcn_rcpf((float)nloc);
 #pragma unroll
@@ -1590,8 +1543,8 @@ __device__ __forceinline__ void qkv_ln_pm(const Ctx &c, int w_off, int s_off, co
   __syncthreads();
 }
 
-// LinearAttention core (resnets.py:223-235) of all four heads, position-major, in place: qkv [384][64] in to_qkv's row
-// order (q | k | v, head h at rows 32 h of each third); the output o [128][64] overwrites q.
+// LinearAttention core (resnets.py:223-235) of all four heads, position-major: qkv [384][64] in to_qkv's row order
+// (q | k | v, head h at rows 32 h of each third); the output o [128][64] leaves as split-bf16 planes (see the end).
 //   out[e][n] = sum_m v[e][m] A[m][n],   A[m][n] = scale / sum_d exp(q[d][n] - max) * sum_d softmax_m(k[d])[m] exp(q[d][n] - max)
 // Phase 1: softmax of k over the sample's 4 positions, once per (head, channel, sample), written back in place (wave =
 // (head, 16 channels), lane = (sample, 4 channels)).  Phase 2: wave = (head, position pair), lane = (sample, part):
@@ -1672,12 +1625,29 @@ __device__ __forceinline__ void attention_quad_pm(const Ctx &c, float *qkv) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[e][j] = half_sum(row_pair_sum(a[e][j])) * sc;
   }
+  // The output is only ever the B operand of to_out: it leaves as split-bf16 planes (over the q rows and the first
+  // key rows, the H-plane region: dead once every wave is past its reads), not as f32 rows.  A lane's 8 channels are one
+  // 8-group of the fragment layout (32-channel block = head, g = part), in the order i ^ odd.
+  float ov[2][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
-      q3[pswz(qr + (i ^ odd), n0 + 16 * e)] =
-          vv[i][0] * a[e][0] + vv[i][1] * a[e][1] + vv[i][2] * a[e][2] + vv[i][3] * a[e][3];
+    for (int e = 0; e < 2; ++e) ov[e][i] = vv[i][0] * a[e][0] + vv[i][1] * a[e][1] + vv[i][2] * a[e][2] + vv[i][3] * a[e][3];
+  __syncthreads();  // all reads of q, k, v are done
+  lds_u4 *op = (lds_u4 *)(c.lds + kPlaneH) + ((head * 3) * 4 + pt) * 64;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    float oj[8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      oj[2 * m] = odd ? ov[e][2 * m + 1] : ov[e][2 * m];
+      oj[2 * m + 1] = odd ? ov[e][2 * m] : ov[e][2 * m + 1];
+    }
+    u32x4 pl[3];
+    split_bf16x3(oj, pl);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) op[k * 256 + n0 + 16 * e] = pl[k];
+  }
   __syncthreads();
 }
 

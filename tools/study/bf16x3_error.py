@@ -31,7 +31,10 @@ def conv1d_split(x, w, b=None, stride=1, padding=0, **kw):
         return real_conv1d(x, w, b, stride=stride, padding=padding)
     xs, ws = split3(x), split3(w)
     out = None
-    for i, j in PAIRS:
+    pairs = PAIRS
+    if os.environ.get("WIDE_TWO_PLANES") and w.shape[0] == 256 and w.shape[2] == 3:
+        pairs = [(0, 0), (0, 1), (1, 0), (0, 2), (1, 1)]   # weights hi + mid only on the 256-output k=3 convs
+    for i, j in pairs:
         t = real_conv1d(xs[j], ws[i], None, padding=padding)
         out = t if out is None else out + t
     return out + b.view(1, -1, 1) if b is not None else out
