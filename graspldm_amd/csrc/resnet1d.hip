@@ -2990,6 +2990,10 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
 // so the eight waves' k-loops are ds_read_b128 + buffer loads + MFMA.  A 32-column tile re-uses a weight fragment
 // for two n-tiles only: the weight stream (6 bytes per weight and tile) runs the CU's 64 B/clk L2 path about as long
 // as the MFMAs run the matrix pipe, so fragments are requested four blocks ahead (ring of four register sets).
+// (Measured and dropped: 64-column tiles with K walked in 256-channel chunks -- planes of a chunk in LDS, accumulators of
+// half the output rows kept across the chunks, two passes, front layer recomputed per pass on the bf16 pipe: half the
+// weight bytes per column, yet the same 0.97-1.04 ms per 329 clouds as this kernel's 1.04: the stream is not what it
+// waits for in the end.)
 // The optional layer in front (96 -> 768: an eighth of the FLOPs) stays on the f32 pipe and writes its ReLU output
 // straight into those planes; the head product is taken on the accumulators exactly as in the f32 kernel (the C layout
 // of the two MFMA shapes is the same).
