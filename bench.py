@@ -305,6 +305,33 @@ def main():
                      dict(kernel="r1d_kernel<32, 16> (gldm_decode)", bound="mfma", avg_ms=t_dec * 1e3,
                           achieved=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
                           unit="TFLOP/s", frac=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12 / PEAK_F32_MFMA_TFLOPS)]
+          # ---- the same launch on the f32 matrix pipe only: a descriptor without the split-bf16 weight copies (what an
+          # ABI-4 packer produces) runs the sample-major engine, exact f32 fma chains -- for comparison with the split
+          # arithmetic of the headline path
+          if args.scheduler == "ddim":
+              import copy
+              from graspldm_amd.r1d import R1dEngine
+              from graspldm_amd.r1d_pack import pack_resnet1d
+              sd32 = {k: v.detach().float().cpu() for k, v in den.state_dict().items()}
+              packed = pack_resnet1d(sd32, "", groups=den.groups, seq_len=den.in_features, num_steps=den.max_timesteps,
+                                     cond_rows=getattr(den, "cond_rows", 3))
+              for i in range(len(packed["desc"].rb)):
+                  packed["desc"].rb[i].c1_w3 = packed["desc"].rb[i].c2_w3 = 0
+              for i in range(len(packed["desc"].lv)):
+                  packed["desc"].lv[i].qkvn_w3 = packed["desc"].lv[i].out_w3 = packed["desc"].lv[i].down_w3 = 0
+              eng32 = R1dEngine(packed, dev)
+              dn32 = lambda: eng32.denoise(x_T, cemb, G, timesteps=ts, sched_kind=kind, coef=coef)
+              x_split, x_f32 = dn(), dn32()
+              t32 = event_time(dn32, 2, lead=0)
+              kernels.append(dict(kernel="gldm_denoise on the f32 matrix pipe only (r1d_kernel<32, 4>, sample-major engine)", bound="mfma",
+                                  avg_ms=t32 * 1e3, achieved=flop / t32 / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                                  frac=flop / t32 / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                  max_abs_diff_vs_split_path=float((x_split - x_f32).abs().max()),
+                                  mean_abs_diff_vs_split_path=float((x_split - x_f32).abs().mean()),
+                                  p999_abs_diff_vs_split_path=float(torch.quantile((x_split - x_f32).abs().flatten().float(), 0.999)),
+                                  note="same weights, inputs and schedule as the headline launch; the *_diff fields compare the "
+                                       "two engines' latents after all steps (different summation orders on both sides; the "
+                                       "sampler's clip of x0 to +-1 makes single elements discontinuous)"))
           from graspldm_amd import _lib as L
           from graspldm_amd.pvcnn import furthest_point_sample
           pts = (pcs.transpose(1, 2) * (0.05 / 0.12)).contiguous()
