@@ -2874,6 +2874,8 @@ struct PwArgs {
   // optional layer in front (x [b, cin0, n] -> relu(W0 x + b0) = the [cin][32] tile of the main layer, never in HBM)
   const float *w0, *bias0;
   int cin0;
+  int dyn_first;   // split-bf16 kernel: units (pairs of m-tiles) >= dyn_first are handed out at run time
+  int ticket_off;  // ... from a ticket at this float index of the LDS plan
 };
 
 __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
@@ -2994,9 +2996,9 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
 // half the output rows kept across the chunks, two passes, front layer recomputed per pass on the bf16 pipe: half the
 // weight bytes per column, yet the same 0.97-1.04 ms per 329 clouds as this kernel's 1.04: the stream is not what it
 // waits for in the end.)
-// The optional layer in front (96 -> 768: an eighth of the FLOPs) stays on the f32 pipe and writes its ReLU output
-// straight into those planes; the head product is taken on the accumulators exactly as in the f32 kernel (the C layout
-// of the two MFMA shapes is the same).
+// The optional layer in front (96 -> 768: an eighth of the FLOPs) runs on the same pipe (pw_front_split: 20-25 k cycles
+// per tile on the f32 pipe before) and writes its ReLU output straight into those planes; the head product is taken on the
+// accumulators exactly as in the f32 kernel (the C layout of the two MFMA shapes is the same).
 __device__ __forceinline__ void store_planes4_32(float *planes, int c0, int n, float v0, float v1, float v2, float v3) {
   float x[8] = {v0, v1, v2, v3, 0.f, 0.f, 0.f, 0.f};
   u32x4 pl[3];
@@ -3008,23 +3010,89 @@ __device__ __forceinline__ void store_planes4_32(float *planes, int c0, int n, f
   d[512] = u32x2_t{pl[2][0], pl[2][1]};
 }
 
+// The layer in front of the split-bf16 main layer, on the same pipe: x0 = the f32 [cin0][32] tile (swizzled), w0s =
+// split fragments of W0 [cin x cin0], KB0 = cin0 / 32.  A wave splits the whole tile ONCE into registers (its B planes
+// serve all of the wave's m-tiles) and walks its m-tiles in pairs; the A registers of a (m-tile, block) are refilled
+// with the next pair's fragments as soon as its MFMAs have issued.  Output: ReLU, split, into the main layer's planes.
+template <int KB0>
+__device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *bias0, const float *x0, float *planes,
+                                               int wave, int lane, int mt_per_wave0) {
+  constexpr int NC = 32;
+  const int col = lane & 15, kq = lane >> 4;
+  u32x4 bp[KB0][2][3];
+#pragma unroll
+  for (int kb = 0; kb < KB0; ++kb)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = x0[swz<NC>(32 * kb + 8 * kq + j, 16 * ni + col)];
+      split_bf16x3(v, bp[kb][ni]);
+    }
+  u32x4 af[2][KB0][3];
+  const int mt_first = wave * mt_per_wave0, mt_last = mt_first + mt_per_wave0 - 2;
+  auto load_a = [&](int mi, int kb, int mt0) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) af[mi][kb][pl] = w0s.raw((((size_t)(mt0 + mi) * KB0 + kb) * 3 + pl) * 64);
+  };
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int kb = 0; kb < KB0; ++kb) load_a(mi, kb, mt_first);
+  for (int mt0 = mt_first; mt0 <= mt_last; mt0 += 2) {
+    const int mtn = mt0 + 2 <= mt_last ? mt0 + 2 : mt_last;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias0 + 16 * (mt0 + mi) + 4 * kq);
+      acc[mi][0] = bv;
+      acc[mi][1] = bv;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int kb = 0; kb < KB0; ++kb) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_split6(af[mi][kb], bp[kb][ni], acc[mi][ni]);
+        load_a(mi, kb, mtn);
+      }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        store_planes4_32(planes, 16 * (mt0 + mi) + 4 * kq, 16 * ni + col, fmaxf(acc[mi][ni][0], 0.f),
+                         fmaxf(acc[mi][ni][1], 0.f), fmaxf(acc[mi][ni][2], 0.f), fmaxf(acc[mi][ni][3], 0.f));
+  }
+}
+
+#ifdef GLDM_DEBUG_KNOBS
+__device__ long long g_pw_stamp[64];
+#define GLDM_PW_STAMP(i) \
+  do { if (blockIdx.x == 5 && tile == 5 + 2 * (int)gridDim.x && (threadIdx.x & 63) == 0 && (wave == 0 || wave == 7)) \
+         g_pw_stamp[(wave ? 32 : 0) + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define GLDM_PW_STAMP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a) {
   constexpr int NC = 32;
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  Ctx c{a.w0 ? a.w0 : a.w, lds, tid, wave, lane, 0, 2};
   const int col = lane & 15, kq = lane >> 4;
   const int kb32 = a.cin >> 5, mtiles = a.cout >> 4, mt_per_wave = mtiles >> 3;
   float *planes = lds;                       // [kb32][3][4][32][4 dwords]
   float *zpart = lds;                        // [8 waves][16 rows][32 cols], over the planes once they are dead
   float *x0 = lds + a.cin * 48;              // front layer's f32 input tile [cin0][32]
+  float *zdyn = x0;                          // head products of the drawn units [unit - dyn_first][hout][32] (x0 is dead then)
+  int *ticket = (int *)(lds + a.ticket_off); // next unit of output rows to hand out (main layer)
   const WStream hw(a.head_w ? a.head_w : a.w, lane);
   const WStream wv(a.w, lane);
   const lds_u4 *pl3 = (const lds_u4 *)planes + kq * 32 + col;   // + ((kb * 3 + plane) * 4) * 32 + 16 ni
   for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_cloud, c0 = (tile - b * a.tiles_per_cloud) * NC;
     __syncthreads();  // the previous tile's readers are done
+    GLDM_PW_STAMP(0);
+    if (tid == 0) *ticket = a.dyn_first;
     if (a.w0) {
       const float *xb0 = a.x + (size_t)b * a.cin0 * a.n + c0;
       for (int i = tid; i < a.cin0 * 8; i += 512) {
@@ -3032,23 +3100,13 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a
         *reinterpret_cast<f32x4 *>(x0 + swz<NC>(row, 4 * q)) = *reinterpret_cast<const f32x4 *>(xb0 + (size_t)row * a.n + 4 * q);
       }
       __syncthreads();
-      const int cb0 = a.cin0 >> 4, mt_per_wave0 = a.cin >> 7;
-      for (int ps = 0; ps < mt_per_wave0; ps += 2) {
-        const int mt0 = wave * mt_per_wave0 + ps;
-        f32x4 acc[2][2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias0 + 16 * (mt0 + mi) + 4 * kq);
-          acc[mi][0] = bv;
-          acc[mi][1] = bv;
-        }
-        gemm_fast_pf<NC, 4, 1, 2, 2, 2>(c, a.w0, cb0, mt0, 0, x0, acc);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            store_planes4_32(planes, 16 * (mt0 + mi) + 4 * kq, 16 * ni + col, fmaxf(acc[mi][ni][0], 0.f),
-                             fmaxf(acc[mi][ni][1], 0.f), fmaxf(acc[mi][ni][2], 0.f), fmaxf(acc[mi][ni][3], 0.f));
+      GLDM_PW_STAMP(1);
+      const int mt_per_wave0 = a.cin >> 7;   // cin / 16 m-tiles over 8 waves
+      const WStream w0s(a.w0, lane);
+      switch (a.cin0 >> 5) {
+        case 1: pw_front_split<1>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0); break;
+        case 2: pw_front_split<2>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0); break;
+        default: pw_front_split<3>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0); break;
       }
     } else {
       // stage + split: thread = (8-channel group, column); a pass covers 128 channels
@@ -3069,54 +3127,82 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a
         }
       }
     }
+    GLDM_PW_STAMP(2);
     __syncthreads();
+    GLDM_PW_STAMP(3);
     f32x4 zacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    for (int ps = 0; ps < mt_per_wave; ps += 2) {
-      const int mt0 = wave * mt_per_wave + ps;
-      f32x4 acc[2][2];
+    // ---- the output rows in units of two m-tiles, handed out at run time.  With a fixed share per wave the older wave
+    // of a SIMD gets the matrix pipe whenever it wants it, finishes its share at 95 % of the pair's rate and then idles
+    // at the tile's last barrier while its partner, alone, cannot hide its own LDS / weight latencies (stamps: wave 0
+    // done after 131 k cycles, wave 7 after 166 k, a lone wave at 58 % of the pipe).  A wave that is done takes the next
+    // unit off an LDS ticket instead; the unit after the current one is drawn before the current k-loop so that its
+    // first weight fragments are requested from inside that loop (the ring of four A sets never drains), and the B
+    // planes of block k + 1 are read in front of the MFMAs of block k.
+    const int units = mtiles >> 1;
+    u32x4 af[4][2][3];
+    auto load_a = [&](int buf, int mt0, int kb) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kb32 + kb) * 3 + pl) * 64);
+    };
+    u32x4 bs[2][2][3];
+    auto load_b = [&](int buf, int kb) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bs[buf][ni][pl] = pl3[(kb * 3 + pl) * 128 + 16 * ni];
+    };
+    auto draw = [&]() {
+      int t = 0;
+      if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return __builtin_amdgcn_readfirstlane(t);
+    };
+    // Units below dyn_first are dealt round robin (wave w: w, w + 8, ...), the rest drawn.  The head sum must not depend
+    // on who drew what: a drawn unit's head product goes to its own LDS slot (zdyn, over the dead front-layer tile), only
+    // the dealt ones accumulate in the wave's zacc, and the final sum walks waves, then slots, in index order.
+    const int dyn_first = a.dyn_first;
+    int unit = wave;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_a(u, 2 * unit, u);
+    load_b(0, 0);
+    while (unit < units) {
+      const int mt0 = 2 * unit;
+      const int nxt = unit + 8 < dyn_first ? unit + 8 : draw();
+      const int mtn = 2 * (nxt < units ? nxt : unit);   // past the end: harmless re-reads of this unit's fragments
+      // bias and head fragments of this unit: requested now, used behind the k-loop (the bias is added last)
+      f32x4 acc[2][2], bv[2], ah[2];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + 16 * (mt0 + mi) + 4 * kq);
-        acc[mi][0] = bv;
-        acc[mi][1] = bv;
+        bv[mi] = *reinterpret_cast<const f32x4 *>(a.bias + 16 * (mt0 + mi) + 4 * kq);
+        ah[mi] = hw[(size_t)(a.head_w ? mt0 + mi : 0) * 64];
+        acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      // ---- k-loop: ring of four A sets (requested four blocks ahead), B planes read per block
-      u32x4 af[4][2][3];
-      auto load_a = [&](int buf, int kb) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) af[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kb32 + kb) * 3 + pl) * 64);
-      };
-      const int last = kb32 - 1;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) load_a(u, u < last ? u : last);
       for (int kb0 = 0; kb0 < kb32; kb0 += 4) {
+        const bool tail = kb0 + 4 >= kb32;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int kb = kb0 + u;
-          u32x4 bs[2][3];
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bs[ni][pl] = pl3[(kb * 3 + pl) * 128 + 16 * ni];
+          load_b((u + 1) & 1, kb + 1 < kb32 ? kb + 1 : 0);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_split6(af[u][mi], bs[ni], acc[mi][ni]);
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_split6(af[u][mi], bs[u & 1][ni], acc[mi][ni]);
           __builtin_amdgcn_sched_barrier(0);
-          load_a(u, kb + 4 < last ? kb + 4 : last);
+          load_a(u, tail ? mtn : mt0, tail ? u : kb + 4);
         }
       }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        if (a.relu) {
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[mi][ni][r] + bv[mi][r];
+            acc[mi][ni][r] = a.relu ? fmaxf(v, 0.f) : v;
+          }
         if (a.y) {
           float *yb = a.y + ((size_t)b * a.cout + 16 * (mt0 + mi) + 4 * kq) * a.n + c0 + col;
 #pragma unroll
@@ -3124,31 +3210,58 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) __builtin_nontemporal_store(acc[mi][ni][r], yb + (size_t)r * a.n + 16 * ni);
         }
-        if (a.head_w) {
-          const f32x4 ah = hw[(size_t)(mt0 + mi) * 64];
+      }
+      if (a.head_w) {
+        const bool drawn = unit >= dyn_first;
+        f32x4 zu[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) zu[ni] = drawn ? f32x4{0.f, 0.f, 0.f, 0.f} : zacc[ni];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-              zacc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[r], acc[mi][ni][r], zacc[ni], 0, 0, 0);
+              zu[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mi][r], acc[mi][ni][r], zu[ni], 0, 0, 0);
+        }
+        if (drawn) {
+          float *slot = zdyn + (unit - dyn_first) * a.hout * NC;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * kq + r < a.hout) {
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni) slot[(4 * kq + r) * NC + 16 * ni + col] = zu[ni][r];
+            }
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) zacc[ni] = zu[ni];
         }
       }
+      unit = nxt;
     }
+    GLDM_PW_STAMP(16);
     if (a.head_w) {
       __syncthreads();  // every wave is done with the planes: the z partials go over them
+      GLDM_PW_STAMP(17);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) zpart[(wave * 16 + 4 * kq + r) * NC + 16 * ni + col] = zacc[ni][r];
       __syncthreads();
-      for (int i = tid; i < a.hout * NC; i += 512) {
-        const int row = i / NC, cc = i - row * NC;
-        float v = a.head_b ? a.head_b[row] : 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) v += zpart[(w8 * 16 + row) * NC + cc];
-        a.z[((size_t)b * a.hout + row) * a.n + c0 + cc] = v;
+      // fixed summation tree: four lanes per output (waves 2p, 2p + 1 and every fourth slot from p), then the quad
+      const int nd = units - dyn_first;
+      for (int i0 = 0; i0 < a.hout * NC * 4; i0 += 512) {
+        const int i = i0 + tid, o = i >> 2, p = i & 3;
+        const bool live = o < a.hout * NC;
+        const int row = live ? o / NC : 0, cc = live ? o - row * NC : 0;
+        float v = zpart[((2 * p) * 16 + row) * NC + cc] + zpart[((2 * p + 1) * 16 + row) * NC + cc];
+        for (int d = p; d < nd; d += 4) v += zdyn[(d * a.hout + row) * NC + cc];
+        v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+        v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+        if (live && p == 0) a.z[((size_t)b * a.hout + row) * a.n + c0 + cc] = v + (a.head_b ? a.head_b[row] : 0.f);
       }
     }
+    GLDM_PW_STAMP(18);
   }
 }
 
@@ -3457,10 +3570,30 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   if ((cin & 31) || (cout & 255) || (n & 31)) return GLDM_ERR_UNSUPPORTED;  // k-blocks in pairs, 2 m-tiles x 8 waves, 32-point tiles
   if (w0 && (!b0 || cin0 <= 0 || (cin0 & 31) || (cin & 255))) return GLDM_ERR_UNSUPPORTED;
   size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
-  if (split_bf16) {  // `w` holds split-bf16 fragments (w0, if any, f32 ones): planes of the tile + the front layer's f32 tile
+  if (split_bf16) {  // `w` and `w0` hold split-bf16 fragments: planes of the tile + the front layer's f32 tile
     if (cin & 127) return GLDM_ERR_UNSUPPORTED;  // the A ring walks four 32-deep blocks per trip
-    lds_bytes = ((size_t)cin * 48 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
-    if (lds_bytes < (size_t)8 * 16 * 32 * sizeof(float)) lds_bytes = (size_t)8 * 16 * 32 * sizeof(float);
+    if (w0 && cin0 > 96) return GLDM_ERR_UNSUPPORTED;  // the front layer keeps its whole split tile in registers (72)
+  }
+  int dyn_first = 0, ticket_off = 0;
+  if (split_bf16) {
+    // LDS plan: planes | front tile, later the head products of the drawn units | ticket.  As many units are drawn as
+    // have room for their head slot (all but the first round when there is no head).
+    const size_t planes = (size_t)cin * 48 * sizeof(float), cap = (size_t)160 * 1024 - 16;
+    size_t region = w0 ? (size_t)cin0 * 32 * sizeof(float) : 0;
+    if (planes + region > cap) return GLDM_ERR_UNSUPPORTED;
+    const int units = cout / 32;
+    int drawn = units - 8;
+    if (head_w) {
+      const size_t slot = (size_t)hout * 32 * sizeof(float);
+      const int room = (int)((cap - planes) / slot);
+      if (drawn > room) drawn = room;
+      if (planes < (size_t)8 * 16 * 32 * sizeof(float)) drawn = 0;   // z partials need the planes' space
+    }
+    dyn_first = (units - drawn + 7) & ~7;   // whole rounds are dealt
+    if (head_w && (size_t)(units - dyn_first) * hout * 32 * sizeof(float) > region)
+      region = (size_t)(units - dyn_first) * hout * 32 * sizeof(float);
+    ticket_off = (int)((planes + region) / sizeof(float));
+    lds_bytes = planes + region + 16;
   }
   if (lds_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
   struct PwTag { int site; };
@@ -3471,6 +3604,7 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   a.x = x; a.w = w; a.bias = bias; a.head_w = head_w; a.head_b = head_b; a.y = y; a.z = z;
   a.cin = cin; a.cout = cout; a.n = n; a.relu = relu; a.hout = hout;
   a.w0 = w0; a.bias0 = b0; a.cin0 = cin0;
+  a.dyn_first = dyn_first; a.ticket_off = ticket_off;
   a.tiles_per_cloud = n / 32;
   a.total_tiles = b * a.tiles_per_cloud;
   const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
@@ -3478,6 +3612,19 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   if (grid > a.total_tiles) grid = a.total_tiles;
   if (split_bf16) hipLaunchKernelGGL(pointwise_mlp_bf_kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
   else hipLaunchKernelGGL(pointwise_mlp_kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
+#ifdef GLDM_DEBUG_KNOBS
+  if (split_bf16 && getenv("GLDM_PW_STAMP")) {   // diagnostic builds: phase clocks of one steady-state tile (waves 0 and 7)
+    long long h[64];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pw_stamp), sizeof(h));
+    for (int w = 0; w < 2; ++w) {
+      const long long *q = h + 32 * w;
+      printf("pointwise split %d(%d)->%d b=%d wave %d: stage %lld front %lld barrier %lld |", cin, cin0, cout, b, w ? 7 : 0,
+             q[1] - q[0], q[2] - q[1], q[3] - q[2]);
+      printf(" main %lld wait %lld head %lld total %lld\n", q[16] - q[3], q[17] - q[16], q[18] - q[17], q[18] - q[0]);
+    }
+  }
+#endif
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 }  // namespace

@@ -376,6 +376,7 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
   constexpr int zp = r + 2, nvox = 36 * zp, r3 = r * r * r;
   constexpr int kItems = 2 * nvox, kRounds = (kItems + kThreads - 1) / kThreads;
   extern __shared__ float lds[];
+  GLDM_C3_STAMP(0);
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 15, kq = lane >> 4;
@@ -453,13 +454,18 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
         for (int k = 0; k < 3; ++k) pl[k * 2 * nvox + s_lds[q]] = p3[k];
       }
   };
+  GLDM_C3_STAMP(1);
   stage_load(0);
+  GLDM_C3_STAMP(2);
   for (int cb = 0; cb < cblocks; ++cb) {
     __syncthreads();   // the previous block's readers are done
+    if (cb < 3) GLDM_C3_STAMP(3 + 4 * cb);
     stage_store();
     if (cb + 1 < cblocks) stage_load(cb + 1);
     __builtin_amdgcn_sched_barrier(0);
+    if (cb < 3) GLDM_C3_STAMP(4 + 4 * cb);
     __syncthreads();
+    if (cb < 3) GLDM_C3_STAMP(5 + 4 * cb);
     c3_u32x4 a[2][3][3];
     auto load_a = [&](int buf, int step) {   // step = pair * MG + mg
       const int p = step / MG, mg = step - p * MG;
@@ -513,10 +519,12 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
         }
       }
     }
+    if (cb < 3) GLDM_C3_STAMP(6 + 4 * cb);
     __builtin_amdgcn_s_setprio(3);
   }
   // ---- epilogue: per-channel partial statistics of this brick, then the stores
   __syncthreads();
+  GLDM_C3_STAMP(20);
   float *s_part = lds;  // [WAVES][MT * 16][2]
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
@@ -559,6 +567,7 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
         for (int ni = 0; ni < NTW; ++ni) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
       }
     }
+  GLDM_C3_STAMP(21);
 }
 
 // GroupNorm(groups) + Swish over [B, C, r^3]; statistics from the conv's per-brick partials.
@@ -898,6 +907,22 @@ GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const f
   if (!x || !w_split || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
   if (cin % 16 || cout % 48) return GLDM_ERR_UNSUPPORTED;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#ifdef GLDM_DEBUG_KNOBS
+  struct StampDump {  // diagnostic builds: GLDM_C3_STAMP=1 prints the phase clocks of one mid-grid workgroup per call
+    hipStream_t s; int cin, cout, r, b;
+    ~StampDump() {
+      if (!getenv("GLDM_C3_STAMP")) return;
+      long long h[32];
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_c3_stamp), sizeof(h));
+      printf("conv3d split %d->%d @%d b=%d: setup %lld, stage0 issue %lld", cin, cout, r, b, h[1] - h[0], h[2] - h[1]);
+      for (int cb = 0; cb < cin / 16 && cb < 3; ++cb)
+        printf(" | cb%d: wait %lld store %lld barrier %lld taps %lld", cb, h[3 + 4 * cb] - (cb ? h[2 + 4 * cb] : h[2]),
+               h[4 + 4 * cb] - h[3 + 4 * cb], h[5 + 4 * cb] - h[4 + 4 * cb], h[6 + 4 * cb] - h[5 + 4 * cb]);
+      printf(" | epilogue %lld, total %lld\n", h[21] - h[20], h[21] - h[0]);
+    }
+  } dump{s, cin, cout, r, b};
+#endif
   if (cout == 48 && r == 24) return launch_conv_pl<3, 24, 8>(x, w_split, bias, b, cin, cout, y, partial, s);
   if (cout == 96 && r == 12) return launch_conv_pl<6, 12, 4>(x, w_split, bias, b, cin, cout, y, partial, s);
   return GLDM_ERR_UNSUPPORTED;

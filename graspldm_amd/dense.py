@@ -77,8 +77,8 @@ def pack_head(wh):
 
 def split_supported(cin, cin0=0):
     """The split-bf16 form of the fused launch (gldm_pointwise_mlp*_bf16x3): A ring of four 32-deep blocks, the tile
-    as planes (48 floats per channel) + the front layer's f32 tile."""
-    return cin % 128 == 0 and 4 * (48 * cin + 32 * cin0) <= 160 * 1024
+    as planes (48 floats per channel) + the front layer's f32 tile (split once per wave into registers: cin0 <= 96)."""
+    return cin % 128 == 0 and cin0 % 32 == 0 and cin0 <= 96 and 4 * (48 * cin + 32 * cin0) + 16 <= 160 * 1024
 
 
 def fused_mlp_supported(x, cin, cout):
@@ -96,8 +96,8 @@ def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True, front=N
     """One fused launch: y = act(W x + b) over [B, Cin, N] (hand-written MFMA GEMM, csrc/resnet1d.hip:
     pointwise_mlp_kernel / pointwise_mlp_bf_kernel) and optionally z = Wh y + bh on the accumulators.
     head = (packed Wh, bh, hout).  front = (packed W0, b0, cin): a ReLU layer x -> relu(W0 x + b0) in front, its output
-    kept in LDS only.  split=True: `w_packed` holds split-bf16 fragments (the GEMM runs on the bf16 matrix pipe with
-    six partial products per f32 product)."""
+    kept in LDS only.  split=True: `w_packed` (and the front layer's W0) hold split-bf16 fragments (the GEMMs run on the
+    bf16 matrix pipe with six partial products per f32 product)."""
     from . import _lib as L
     b, cin, n = x.shape
     y = torch.empty((b, cout, n), dtype=torch.float32, device=x.device) if keep_y or head is None else None
@@ -144,7 +144,8 @@ def folded_conv_bn(conv, bn, device):
         wp = ws = None
         if w.shape[1] % 32 == 0 and w.shape[0] % 256 == 0:
             wp = mfma_a_fragments(w.detach().float().cpu()).to(device)
-            if split_supported(w.shape[1]):
+            # split fragments: main layers of the split launch (cin % 128 == 0) and its narrow front layers (cin <= 128)
+            if split_supported(w.shape[1]) or w.shape[1] <= 128:
                 ws = mfma_a_fragments_bf16x3(w.detach().float().cpu()).to(device)
         hit = (key, w, b, wp, ws)
         conv.__dict__["_gldm_folded"] = hit

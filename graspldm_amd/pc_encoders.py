@@ -63,12 +63,12 @@ class PVCNNEncoder(nn.Module):
             if two:
                 conv0, bn0 = prev.layers[0], prev.layers[1]
                 if w.shape[0] <= 16 and dense.fused_mlp2_supported(feats, conv0.weight.shape[1], cin, cout):
-                    _, b0, wp0, _ = dense.folded_conv_bn(conv0, bn0, feats.device)
+                    _, b0, wp0, ws0 = dense.folded_conv_bn(conv0, bn0, feats.device)
                     _, bf, wp, ws = dense.folded_conv_bn(conv, bn, feats.device)
-                    if ws is not None and dense.split_supported(cin, conv0.weight.shape[1]):
-                        # the 768 -> 1536 GEMM on the bf16 matrix pipe (split-f32 operands), front layer on the f32 pipe
+                    if ws is not None and ws0 is not None and dense.split_supported(cin, conv0.weight.shape[1]):
+                        # both GEMMs on the bf16 matrix pipe (split-f32 operands)
                         return dense.pointwise_mlp(feats, ws, bf, cout, True, head=self._packed_head(w, b), keep_y=False,
-                                                   front=(wp0, b0, cin), split=True)[1]
+                                                   front=(ws0, b0, cin), split=True)[1]
                     return dense.pointwise_mlp(feats, wp, bf, cout, True, head=self._packed_head(w, b), keep_y=False,
                                                front=(wp0, b0, cin))[1]
                 feats = prev(feats).contiguous()

@@ -312,13 +312,14 @@ int gldm_linear_rows(const float *x /*[rows,n]*/, const float *w /*[nout,n]*/, c
 /* The same two entry points with the MAIN layer's weights as split-bf16 fragments (graspldm_amd/r1d_pack.py:
  * mfma_a_fragments_bf16x3; layout above): the GEMM runs on the bf16 matrix pipe with six partial products per f32
  * product and f32 accumulation (error of the order of one f32 rounding per product, 6/16 of the f32-MFMA time).  The
- * input tile is split once while it is staged.  `w0_packed` (front layer) and `head_w_packed` stay f32 fragments.
- * cin % 128 == 0, cout % 256 == 0, n % 32 == 0, 4 (48 cin + 32 cin0) <= 160 KiB. */
+ * input tile is split once while it is staged.  Since ABI 6 the front layer's weights `w0_split` are split-bf16 fragments
+ * too (cin0 % 32 == 0, cin0 <= 96; its f32 input tile is split once per wave into registers); `head_w_packed` stays f32
+ * fragments.  cin % 128 == 0, cout % 256 == 0, n % 32 == 0, 4 (48 cin + 32 cin0) + 16 <= 160 KiB. */
 int gldm_pointwise_mlp_bf16x3(const float *x /*[b,cin,n]*/, const float *w_split, const float *bias /*[cout]*/,
                               int b, int cin, int cout, int n, int relu,
                               const float *head_w_packed, const float *head_bias, int hout,
                               float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
-int gldm_pointwise_mlp2_bf16x3(const float *x /*[b,cin0,n]*/, const float *w0_packed, const float *bias0, int cin0,
+int gldm_pointwise_mlp2_bf16x3(const float *x /*[b,cin0,n]*/, const float *w0_split, const float *bias0, int cin0,
                                const float *w_split, const float *bias /*[cout]*/, int b, int cin, int cout, int n,
                                const float *head_w_packed, const float *head_bias, int hout,
                                float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);

@@ -385,6 +385,47 @@ def test_pointwise_mlp_two_layers_one_launch(b, cin0, cin, cout, n, hout):
         assert torch.equal(z, z2)
 
 
+@pytest.mark.parametrize("b,cin0,cin,cout,n,hout", [(2, 96, 768, 1536, 64, 3), (3, 32, 256, 256, 96, 0),
+                                                    (1, 64, 512, 768, 32, 16), (5, 96, 256, 512, 2048, 3),
+                                                    (2, 0, 128, 256, 64, 0), (1, 0, 768, 1536, 96, 3)])
+def test_pointwise_mlp_split_bf16(b, cin0, cin, cout, n, hout):
+    """gldm_pointwise_mlp_bf16x3 / gldm_pointwise_mlp2_bf16x3 (both layers on the bf16 matrix pipe, every f32 operand
+    split exactly into three bf16 numbers; units of output rows handed out to the waves at run time) against a torch-CPU
+    reference computed in f64: 2e-5 of the output scale, like the f32-pipe form.  (5, ..., 2048): 320 tiles on 256
+    workgroups, i.e. some workgroups take a second tile."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from graspldm_amd import dense
+    from graspldm_amd.r1d_pack import mfma_a_fragments_bf16x3
+    g = torch.Generator().manual_seed(7 + cin0 + cin + cout)
+    c_in = cin0 if cin0 else cin
+    x = torch.randn(b, c_in, n, generator=g)
+    w1, b1 = torch.randn(cout, cin, generator=g) / cin ** 0.5, torch.randn(cout, generator=g)
+    front = None
+    h_ref = x.double()
+    if cin0:
+        w0, b0 = torch.randn(cin, cin0, generator=g) / cin0 ** 0.5, torch.randn(cin, generator=g)
+        h_ref = (torch.einsum("oc,bcn->bon", w0.double(), h_ref) + b0.double().view(1, -1, 1)).relu().float().double()
+        front = (mfma_a_fragments_bf16x3(w0).cuda(), b0.cuda(), cin)
+    y_ref = (torch.einsum("oc,bcn->bon", w1.double(), h_ref) + b1.double().view(1, -1, 1)).relu()
+    head = None
+    if hout:
+        wh, bh = torch.randn(hout, cout, generator=g) / cout ** 0.5, torch.randn(hout, generator=g)
+        z_ref = (torch.einsum("oc,bcn->bon", wh.double(), y_ref) + bh.double().view(1, -1, 1)).float()
+        head = (dense.pack_head(wh).cuda(), bh.cuda(), hout)
+    assert dense.split_supported(cin, cin0)
+    y, z = dense.pointwise_mlp(x.cuda(), mfma_a_fragments_bf16x3(w1).cuda(), b1.cuda(), cout, True, head=head, keep_y=True,
+                               front=front, split=True)
+    assert _err(y, y_ref.float()) < 2e-5 * max(1.0, y_ref.abs().max().item())
+    if hout:
+        assert _err(z, z_ref) < 2e-5 * max(1.0, z_ref.abs().max().item())
+        # the head sum does not depend on which wave drew which unit of output rows: bitwise repeatable
+        for _ in range(3):
+            _, z2 = dense.pointwise_mlp(x.cuda(), mfma_a_fragments_bf16x3(w1).cuda(), b1.cuda(), cout, True, head=head,
+                                        keep_y=False, front=front, split=True)
+            assert torch.equal(z2, z)
+
+
 def test_pointwise_mlp_rejects_unsupported_shapes():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
