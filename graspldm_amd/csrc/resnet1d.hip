@@ -173,6 +173,16 @@ __device__ __forceinline__ float half_max(float x) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+#ifdef GLDM_DEBUG_KNOBS
+__device__ long long g_wv_stamp[8][32][4];   // per wave, ring of the last 32 position-major convs: in, k-loop done, out, shape
+__device__ int g_wv_cnt[8];
+#define GLDM_WV_STAMP(c, k, v) \
+  do { if (blockIdx.x == 0 && (c).lane == 0) g_wv_stamp[(c).wave][g_wv_cnt[(c).wave] & 31][k] = (v); } while (0)
+#define GLDM_WV_NEXT(c) do { if (blockIdx.x == 0 && (c).lane == 0) g_wv_cnt[(c).wave]++; } while (0)
+#else
+#define GLDM_WV_STAMP(c, k, v) do {} while (0)
+#define GLDM_WV_NEXT(c) do {} while (0)
+#endif
 struct Ctx {
   const float *w;   // packed weights
   float *lds;
@@ -468,6 +478,16 @@ __device__ __forceinline__ f32x4 mfma_split6(const u32x4 (&a)[3], const u32x4 (&
 // moment a tap's MFMAs have issued, its registers are refilled with the next channel block's fragments of that tap,
 // which then have the two other taps' MFMAs (and the partner wave's) to arrive.  The raw f32 B values of the next
 // block are read from LDS while the current block's MFMAs run and split at the top of the next trip.
+#if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_EXP_NO_A)   // timing experiments only (wrong results): operands of block 0 reused
+constexpr bool kExpNoA = true;
+#else
+constexpr bool kExpNoA = false;
+#endif
+#if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_EXP_NO_B)
+constexpr bool kExpNoB = true;
+#else
+constexpr bool kExpNoB = false;
+#endif
 template <int MT, int P0, int NP>
 __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restrict__ wp3, int cin, int mt0,
                                             const float *src, f32x4 (&acc)[MT][NP]) {
@@ -490,6 +510,7 @@ __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restric
   float raw[MT == 1 ? NB : 2][8];
   u32x4 bs[NB][3];
   auto load_a = [&](int buf, int t, int kb) {
+    if (kExpNoA && kb > 0) return;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -545,7 +566,7 @@ __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restric
     auto step = [&](int st, int kb0) {
         const int t = st % 3, kb = kb0 + st / 3;
         const int nt = (st + 1) % 3, nkb = kb0 + (st + 1) / 3;
-        if (t == 0) {
+        if (t == 0 && !(kExpNoB && kb > 0)) {
           // this block's B values: read and split tile by tile, two tiles of raw values in flight (the block-ahead
           // form of the one-m-tile path costs 32 more registers here)
           const lds_f *sb = src3 + kb * 32 * NC;
@@ -588,6 +609,7 @@ __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restric
   u32x4 a[NA][MT][3];
   u32x4 bs[NBUF][NB][3];
   auto load_a = [&](int buf, int t, int kb) {
+    if (kExpNoA && kb > 0) return;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -595,6 +617,7 @@ __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restric
         a[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kblocks + t * kb32 + kb) * 3 + pl) * 64);
   };
   auto load_b = [&](int buf, int kb) {
+    if (kExpNoB && kb > 0) return;
 #pragma unroll
     for (int q = 0; q < NB; ++q)
 #pragma unroll
@@ -1076,6 +1099,8 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
   }
   // B operand: pre-split planes (Cin <= 128; the X planes or the H planes, by which buffer `src` is) or f32 rows split
   // on the fly (the 256-channel level)
+  GLDM_WV_STAMP(c, 0, (long long)__builtin_readcyclecounter());
+  GLDM_WV_STAMP(c, 3, (long long)(cin * 1000 + cout));
   const bool src_is_x = src == c.lds + GG::kBufX;
   if constexpr (MT == 1) {  // <= 128 output channels: the input has at most as many
     gemm_pm3_pl<MT, P0, NP>(c, wp, cin, mt0, c.lds + (src_is_x ? kPlaneX : kPlaneH), acc);
@@ -1083,6 +1108,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
     if (cin <= kPlaneMaxC) gemm_pm3_pl<MT, P0, NP>(c, wp, cin, mt0, c.lds + (src_is_x ? kPlaneX : kPlaneH), acc);
     else gemm_pm3_bf<MT, P0, NP>(c, wp, cin, mt0, src, acc);
   }
+  GLDM_WV_STAMP(c, 1, (long long)__builtin_readcyclecounter());
   if (g.mode) load_params();
   const bool out_planes = cout <= kPlaneMaxC;  // outputs of up to 128 channels are also (or only) written as planes
   if (!g.mode) {  // the level's down conv: the new residual stream X (f32) and, up to 128 channels, its planes
@@ -1098,6 +1124,8 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
           store_planes4(c.lds + kPlaneX, 16 * (mt0 + mi) + 4 * kq, 16 * (P0 + p) + sm, acc[mi][p][0], acc[mi][p][1],
                         acc[mi][p][2], acc[mi][p][3]);
       }
+    GLDM_WV_STAMP(c, 2, (long long)__builtin_readcyclecounter());
+    GLDM_WV_NEXT(c);
     return;
   }
   // ---- this wave's share of the statistics, per sample (= lane & 15)
@@ -1200,6 +1228,8 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
         store_planes4(c.lds + (g.mode == 2 ? kPlaneX : kPlaneH), 16 * (mt0 + mi) + 4 * kq, 16 * (P0 + p) + sm, y[0], y[1],
                       y[2], y[3]);
     }
+  GLDM_WV_STAMP(c, 2, (long long)__builtin_readcyclecounter());
+  GLDM_WV_NEXT(c);
 }
 
 // Conv1d(4 -> cout, k = 3) of the first level (Cin = 4 is below the MFMA k-block): VALU, lane = column, wave w
@@ -2851,6 +2881,22 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
     resblock(dims[a.d.n_levels]);
     printf("step total (ops): %lld clk; step prologue (embedding sums, init conv): %lld clk\n", host[op] - host[0],
            host[0] - host[kMaxOps + 1]);
+#ifdef GLDM_DEBUG_KNOBS
+    if (pm) {   // per-wave view of the last 32 position-major convs of workgroup 0: k-loop / epilogue, relative to wave 0's entry
+      static long long wv[8][32][4];
+      int cnt[8];
+      (void)hipMemcpyFromSymbol(wv, HIP_SYMBOL(g_wv_stamp), sizeof(wv));
+      (void)hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_wv_cnt), sizeof(cnt));
+      for (int i = 0; i < 32; ++i) {
+        const int e = (cnt[0] + i) & 31;
+        printf("conv %3lld->%3lld:", wv[0][e][3] / 1000, wv[0][e][3] % 1000);
+        for (int w = 0; w < 8; ++w)
+          printf("  w%d in %+5lld loop %6lld epi %6lld |", w, wv[w][e][0] - wv[0][e][0], wv[w][e][1] - wv[w][e][0],
+                 wv[w][e][2] - wv[w][e][1]);
+        printf("\n");
+      }
+    }
+#endif
   }
   return rc;
 }
