@@ -33,6 +33,7 @@
 //   LinearAttention at n = L is reassociated:  out = V (K^T Q)  (an L x L matrix per sample
 //   and head) instead of (V K^T) Q: 8x fewer FLOPs, same math.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1110,7 +1111,9 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
   }
   GLDM_WV_STAMP(c, 1, (long long)__builtin_readcyclecounter());
   if (g.mode) load_params();
-  const bool out_planes = cout <= kPlaneMaxC;  // outputs of up to 128 channels are also (or only) written as planes
+  // outputs of up to 128 channels are also (or only) written as planes: exactly the one-m-tile instantiations (cout = 16 x
+  // 8, 4 or 2 m-tiles of the workgroup; two m-tiles per wave = 256 channels)
+  constexpr bool out_planes = MT == 1;
   if (!g.mode) {  // the level's down conv: the new residual stream X (f32) and, up to 128 channels, its planes
     if (alias) __syncthreads();
     lds_f *d3 = (lds_f *)dst;
@@ -1203,31 +1206,46 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
   }
   const float rstd = __builtin_amdgcn_rsqf(m2 * (1.0f / (float)(kNloc * kParts)) + 1e-5f);
   // mode 1 (block1): H = y, as planes only up to 128 channels (H is only ever a conv input), f32 rows above;
-  // mode 2 (block2): X += y in f32 (the residual stream), plus the planes of the new X up to 128 channels
+  // mode 2 (block2): X += y in f32 (the residual stream), plus the planes of the new X up to 128 channels.
+  // One straight-line instance per (mode, scale/shift): with the two tested per VALUE (wave-uniform branches inside
+  // the unrolled loops) every value was its own chain of basic blocks -- 61 branches and no overlap between the 16-32
+  // exp / rcp chains of a lane: 3.8-4.9 k cycles for the 16 values of a one-m-tile conv, alone on the SIMD or not.
   lds_f *d3 = (lds_f *)(g.mode == 2 ? g.res : dst);
+  auto finish = [&](auto mode_c, auto ss_c) {
+    constexpr int kMode = decltype(mode_c)::value;
+    constexpr bool kSS = decltype(ss_c)::value;
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      float y[4];
+      for (int p = 0; p < NP; ++p) {
+        float y[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = (acc[mi][p][r] - mean) * (rstd * ga[mi][r]) + be[mi][r];
-        if (has_ss) t = t * sc[mi][r] + sh[mi][r];
-        t = silu(t);
-        const int a = pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm);
-        if (g.mode == 2) {
-          t = d3[a] + t;
-          d3[a] = t;
-        } else if (!out_planes) {
-          d3[a] = t;
+        for (int r = 0; r < 4; ++r) {
+          float t = (acc[mi][p][r] - mean) * (rstd * ga[mi][r]) + be[mi][r];
+          if (kSS) t = t * sc[mi][r] + sh[mi][r];
+          t = silu(t);
+          const int a = pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm);
+          if (kMode == 2) {
+            t = d3[a] + t;
+            d3[a] = t;
+          } else if (!out_planes) {
+            d3[a] = t;
+          }
+          y[r] = t;
         }
-        y[r] = t;
+        if (out_planes)
+          store_planes4(c.lds + (kMode == 2 ? kPlaneX : kPlaneH), 16 * (mt0 + mi) + 4 * kq, 16 * (P0 + p) + sm, y[0], y[1],
+                        y[2], y[3]);
       }
-      if (out_planes)
-        store_planes4(c.lds + (g.mode == 2 ? kPlaneX : kPlaneH), 16 * (mt0 + mi) + 4 * kq, 16 * (P0 + p) + sm, y[0], y[1],
-                      y[2], y[3]);
-    }
+  };
+  using std::integral_constant;
+  if (g.mode == 2) {
+    if (has_ss) finish(integral_constant<int, 2>{}, integral_constant<bool, true>{});
+    else finish(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+  } else {
+    if (has_ss) finish(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+    else finish(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+  }
   GLDM_WV_STAMP(c, 2, (long long)__builtin_readcyclecounter());
   GLDM_WV_NEXT(c);
 }
@@ -1363,9 +1381,11 @@ __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInt
 // statistics of a column are merged across the waves that hold its rows -- per-wave (sum, M2 about the wave's own
 // mean) over its 16 rows, one LDS exchange, parallel-variance merge -- and x += LN(y) g is applied to the
 // accumulators.  Replaces a conv phase that stored y plus a LayerNorm phase that read it back (3 barriers).
-template <int NT>
+// NPW = partner waves of the LayerNorm merge, FULL = every row of the m-tile is a channel (C >= 16): compile-time, so that
+// the per-value code has no wave-uniform branches (each value used to be its own chain of basic blocks)
+template <int NT, int NPW, bool FULL>
 __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const float *bias, int mt0, int nt0,
-                                            bool active, int p0, int np, const float *src, int cin, float *xres, int C,
+                                            bool active, int p0, const float *src, int cin, float *xres, int C,
                                             const float *gain) {
   using GG = Geo<64>;
   constexpr int NC = 64;
@@ -1386,13 +1406,13 @@ __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const
     for (int ni = 0; ni < NT; ++ni) {
       float s1 = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s1 += row0 + r < C ? acc[0][ni][r] : 0.f;
+      for (int r = 0; r < 4; ++r) s1 += (FULL || row0 + r < C) ? acc[0][ni][r] : 0.f;
       s1 = half_sum(row_pair_sum(s1));
       const float ml = s1 * inv_n;
       float s2 = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float d = row0 + r < C ? acc[0][ni][r] - ml : 0.f;
+        const float d = (FULL || row0 + r < C) ? acc[0][ni][r] - ml : 0.f;
         s2 += d * d;
       }
       s2 = half_sum(row_pair_sum(s2));
@@ -1409,31 +1429,30 @@ __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
       const int cc = 16 * (nt0 + ni) + col;
-      float ps[8], pm[8], tot = 0.f;
+      float ps[NPW], pm[NPW], tot = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {  // np <= 8 partner waves (wave uniform); each pair is read once
-        const int pw = p0 + (q < np ? q : 0);
-        ps[q] = red1[pw * NC + cc];
-        pm[q] = red2[pw * NC + cc];
-        tot += q < np ? ps[q] : 0.f;
+      for (int q = 0; q < NPW; ++q) {  // each partner's pair is read once
+        ps[q] = red1[(p0 + q) * NC + cc];
+        pm[q] = red2[(p0 + q) * NC + cc];
+        tot += ps[q];
       }
       const float mean = tot * inv_c;
       float m2 = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < NPW; ++q) {
         const float dm = ps[q] * inv_n - mean;
-        m2 += q < np ? pm[q] + (float)nloc * dm * dm : 0.f;
+        m2 += pm[q] + (float)nloc * dm * dm;
       }
       const float rstd = __builtin_amdgcn_rsqf(m2 * inv_c + 1e-5f);
       float xn[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (row0 + r < C) {
+        if (FULL || row0 + r < C) {
           const int a = pswz(row0 + r, cc);
           xn[r] = x3[a] + (acc[0][ni][r] - mean) * rstd * gv[r];
           x3[a] = xn[r];
         }
-      if (C >= 32) store_planes4(c.lds + kPlaneX, row0, cc, xn[0], xn[1], xn[2], xn[3]);  // the new X's planes
+      if (FULL && C >= 32) store_planes4(c.lds + kPlaneX, row0, cc, xn[0], xn[1], xn[2], xn[3]);  // the new X's planes
     }
   }
   __syncthreads();
@@ -1443,10 +1462,10 @@ __device__ __forceinline__ void out_ln_pm(const Ctx &c, int w_off, int b_off, co
                                           int C, int g_off) {
   const float *wp = c.w + w_off, *bias = c.w + b_off, *gain = c.w + g_off;
   const int mtiles = (C + 15) >> 4, w = c.wave;
-  if (mtiles == 8) out_ln_wave<4>(c, wp, bias, w, 0, true, 0, 8, src, cin, xres, C, gain);
-  else if (mtiles == 4) out_ln_wave<2>(c, wp, bias, w & 3, 2 * (w >> 2), true, 4 * (w >> 2), 4, src, cin, xres, C, gain);
-  else if (mtiles == 2) out_ln_wave<1>(c, wp, bias, w & 1, w >> 1, true, 2 * (w >> 1), 2, src, cin, xres, C, gain);
-  else out_ln_wave<1>(c, wp, bias, 0, w & 3, w < 4, w & 3, 1, src, cin, xres, C, gain);
+  if (mtiles == 8) out_ln_wave<4, 8, true>(c, wp, bias, w, 0, true, 0, src, cin, xres, C, gain);
+  else if (mtiles == 4) out_ln_wave<2, 4, true>(c, wp, bias, w & 3, 2 * (w >> 2), true, 4 * (w >> 2), src, cin, xres, C, gain);
+  else if (mtiles == 2) out_ln_wave<1, 2, true>(c, wp, bias, w & 1, w >> 1, true, 2 * (w >> 1), src, cin, xres, C, gain);
+  else out_ln_wave<1, 1, false>(c, wp, bias, 0, w & 3, w < 4, w & 3, src, cin, xres, C, gain);
 }
 
 // PreNorm LayerNorm + to_qkv 1x1 conv of the 4-channel level (resnets.py:104-124,211-222) as one VALU phase: a column's
