@@ -1020,15 +1020,32 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
                 }
               }
             }
+            // the four values of the lane, without wave-uniform branches between them (mode, scale/shift and the row
+            // bound are tested once per m-tile: tested per value they cut the exp / rcp chains into basic blocks)
+            auto finish4 = [&](auto mode_c, auto ss_c, auto full_c) {
+              constexpr int kMode = decltype(mode_c)::value;
+              constexpr bool kSS = decltype(ss_c)::value, kFull = decltype(full_c)::value;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float y = (acc[p][mi][ni][r] - mean[p][mi][r]) * rstd[p][mi][r] * ga[p][mi][r] + be[p][mi][r];
-              if (has_ss) y = y * sc[r] + sh[r];
-              y = silu(y);
-              if (row0 + r < cout) {
-                const int a = swz<NC>(row0 + r, n);
-                d3[a] = g.mode == 2 ? d3[a] + y : y;
+              for (int r = 0; r < 4; ++r) {
+                float y = (acc[p][mi][ni][r] - mean[p][mi][r]) * rstd[p][mi][r] * ga[p][mi][r] + be[p][mi][r];
+                if (kSS) y = y * sc[r] + sh[r];
+                y = silu(y);
+                if (kFull || row0 + r < cout) {
+                  const int a = swz<NC>(row0 + r, n);
+                  d3[a] = kMode == 2 ? d3[a] + y : y;
+                }
               }
+            };
+            using std::integral_constant;
+            typedef integral_constant<bool, true> T;
+            typedef integral_constant<bool, false> F;
+            const bool full = row0 + 3 < cout;
+            if (g.mode == 2) {
+              if (has_ss) { if (full) finish4(integral_constant<int, 2>{}, T{}, T{}); else finish4(integral_constant<int, 2>{}, T{}, F{}); }
+              else { if (full) finish4(integral_constant<int, 2>{}, F{}, T{}); else finish4(integral_constant<int, 2>{}, F{}, F{}); }
+            } else {
+              if (has_ss) { if (full) finish4(integral_constant<int, 1>{}, T{}, T{}); else finish4(integral_constant<int, 1>{}, T{}, F{}); }
+              else { if (full) finish4(integral_constant<int, 1>{}, F{}, T{}); else finish4(integral_constant<int, 1>{}, F{}, F{}); }
             }
           }
       }

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
   for (int mi = 0; mi < MT; ++mi) {
     f32x4 bvv;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bvv[q] = bias[min(16 * mi + 4 * kq + q, cout - 1)];
+    for (int q = 0; q < 4; ++q) bvv[q] = bias[16 * mi + 4 * kq + q];   // cout == 16 MT (the launcher checks)
 #pragma unroll
     for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = bvv;
   }
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
       }
       s = row16_sum(s);
       s2 = row16_sum(s2);
-      if (col == 0 && co < cout) {
+      if (col == 0) {
         s_part[(wave * MT * 16 + co) * 2] = s;
         s_part[(wave * MT * 16 + co) * 2 + 1] = s2;
       }
@@ -562,10 +562,8 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int co = 16 * mi + 4 * kq + q;
-      if (co < cout) {
 #pragma unroll
-        for (int ni = 0; ni < NTW; ++ni) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
-      }
+      for (int ni = 0; ni < NTW; ++ni) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
     }
   GLDM_C3_STAMP(21);
 }
@@ -905,7 +903,7 @@ int launch_conv_pl(const float *x, const float *wp3, const float *bias, int b, i
 GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const float *bias, int b, int cin, int cout, int r,
                                    float *y, float *partial, gldm_stream_t stream) {
   if (!x || !w_split || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
-  if (cin % 16 || cout % 48) return GLDM_ERR_UNSUPPORTED;
+  if (cin % 16 || cout % 48) return GLDM_ERR_UNSUPPORTED;   // the kernels below: cout == 16 MT exactly, no row guards
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #ifdef GLDM_DEBUG_KNOBS
   struct StampDump {  // diagnostic builds: GLDM_C3_STAMP=1 prints the phase clocks of one mid-grid workgroup per call
