@@ -1270,7 +1270,47 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
 // Conv1d(4 -> cout, k = 3) of the first level (Cin = 4 is below the MFMA k-block): VALU, lane = column, wave w
 // computes output channels 4w .. 4w+3 (cout = 32).  Weights are wave uniform (scalar loads); fma chain in the
 // MFMA's k order (tap major, channel minor) from the bias.  src may alias dst.
-__device__ __forceinline__ void conv_pm3_cin4(const Ctx &c, const float *wp, const float *bias, const float *src,
+template <int ROUNDS>   // 32 output channels per round (4 per wave); cout == 32 ROUNDS exactly: no per-value guards
+__device__ __forceinline__ void conv_pm3_cin4_rounds(const Ctx &c, const float *wp, const float *bias, const float *src,
+                                                     float *dst, bool alias) {
+  const int n = c.lane, p = n >> 4;
+  const lds_f *s3 = (const lds_f *)src;
+  float x[3][4];
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci) {
+    const float l = s3[pswz(ci, p > 0 ? n - 16 : n)], m = s3[pswz(ci, n)], r = s3[pswz(ci, p < 3 ? n + 16 : n)];
+    x[0][ci] = p > 0 ? l : 0.f;
+    x[1][ci] = m;
+    x[2][ci] = p < 3 ? r : 0.f;
+  }
+  // all rounds are computed before the (possibly aliased) destination is written
+  float out[ROUNDS][4];
+#pragma unroll
+  for (int rd = 0; rd < ROUNDS; ++rd) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cc = __builtin_amdgcn_readfirstlane(rd * 32 + c.wave * 4 + k);
+      float acc = bias ? bias[cc] : 0.f;
+      const float *wr = wp + (size_t)(cc >> 4) * 256 + (cc & 15) * 4;  // [(ci * 16 + co % 16) * 4 + tap]
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) acc = fmaf(wr[ci * 64 + t], x[t][ci], acc);
+      out[rd][k] = acc;
+    }
+  }
+  if (alias) __syncthreads();
+  lds_f *d3 = (lds_f *)dst;
+#pragma unroll
+  for (int rd = 0; rd < ROUNDS; ++rd) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d3[pswz(rd * 32 + c.wave * 4 + k, n)] = out[rd][k];
+    // the new residual stream's planes (a wave's 4 channels are one half of an 8-group)
+    if (ROUNDS * 32 <= kPlaneMaxC)
+      store_planes4(c.lds + kPlaneX, rd * 32 + c.wave * 4, n, out[rd][0], out[rd][1], out[rd][2], out[rd][3]);
+  }
+}
+__device__ __forceinline__ void conv_pm3_cin4_any(const Ctx &c, const float *wp, const float *bias, const float *src,
                                               float *dst, int cout, bool alias) {
   const int n = c.lane, p = n >> 4;
   const lds_f *s3 = (const lds_f *)src;
@@ -1316,6 +1356,14 @@ __device__ __forceinline__ void conv_pm3_cin4(const Ctx &c, const float *wp, con
     if (rd * 32 < cout && cout <= kPlaneMaxC)
       store_planes4(c.lds + kPlaneX, rd * 32 + c.wave * 4, n, out[rd][0], out[rd][1], out[rd][2], out[rd][3]);
   }
+}
+
+__device__ __forceinline__ void conv_pm3_cin4(const Ctx &c, const float *wp, const float *bias, const float *src,
+                                              float *dst, int cout, bool alias) {
+  // the shipped 32-channel level without per-value `co < cout` tests (32 branches in the common body); wider first
+  // levels on the common body (an instance per width spilled 361 registers across the kernel)
+  if (cout == 32) conv_pm3_cin4_rounds<1>(c, wp, bias, src, dst, alias);
+  else conv_pm3_cin4_any(c, wp, bias, src, dst, cout, alias);
 }
 
 // ResnetBlock of the 4-channel level on the VALU of one wave: lane = column (16 samples x 4 positions), every
