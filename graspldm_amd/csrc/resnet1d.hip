@@ -489,9 +489,29 @@ constexpr bool kExpNoB = true;
 #else
 constexpr bool kExpNoB = false;
 #endif
-template <int MT, int P0, int NP>
+// First weight fragments of a position-major k = 3 conv, requested by the CALLER ahead of the conv (the fused
+// ResnetBlock op asks for its second conv's while the first conv's epilogue runs): block 0's three tap sets of a
+// one-m-tile wave, tap 0's set of a two-m-tile wave -- what the k-loop would otherwise request cold and wait ~1 k cycles for.
+struct NoPreA { static constexpr bool on = false; };
+template <int MT>
+struct PreA {
+  static constexpr bool on = true;
+  static constexpr int kSets = MT == 1 ? 3 : 1;
+  u32x4 a[kSets][MT][3];
+  __device__ __forceinline__ void request(const WStream &wv, int mt0, int cin) {
+    const int kb32 = cin >> 5, kblocks = 3 * kb32;
+#pragma unroll
+    for (int t = 0; t < kSets; ++t)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[t][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kblocks + t * kb32) * 3 + pl) * 64);
+  }
+};
+
+template <int MT, int P0, int NP, class PRE = NoPreA>
 __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restrict__ wp3, int cin, int mt0,
-                                            const float *src, f32x4 (&acc)[MT][NP]) {
+                                            const float *src, f32x4 (&acc)[MT][NP], const PRE &pre = PRE()) {
   constexpr int NC = 64;
   constexpr int PB0 = P0 > 0 ? P0 - 1 : 0, PB1 = P0 + NP < 4 ? P0 + NP : 3, NB = PB1 - PB0 + 1;
   const int col = c.lane & 15, g = c.lane >> 4;
@@ -546,10 +566,22 @@ __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restric
       }
   };
   const int last = kb32 - 1;
+  auto first_a = [&]() {   // block 0's fragments (three tap sets, or tap 0's with two m-tiles): the caller's, or requested here
+#pragma unroll
+    for (int t = 0; t < (MT == 1 ? 3 : 1); ++t) {
+      if constexpr (PRE::on) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) a[t][mi][pl] = pre.a[t][mi][pl];
+      } else {
+        load_a(t, t, 0);
+      }
+    }
+  };
   if constexpr (MT == 1) {
     load_raw(0);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) load_a(t, t, 0);
+    first_a();
     for (int kb = 0; kb < kb32; ++kb) {
       const int nb = kb < last ? kb + 1 : last;  // clamped: every load stays unconditional
       split_all();
@@ -563,7 +595,7 @@ __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restric
       }
     }
   } else {
-    load_a(0, 0, 0);
+    first_a();
     auto step = [&](int st, int kb0) {
         const int t = st % 3, kb = kb0 + st / 3;
         const int nt = (st + 1) % 3, nkb = kb0 + (st + 1) / 3;
@@ -597,9 +629,9 @@ __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restric
 
 // The same conv with the B operand read from pre-split planes (Cin <= 128): ds_read_b128 per (tile, plane), no VALU.
 // B planes of the next channel block are requested while the current block's MFMAs run (second register set).
-template <int MT, int P0, int NP>
+template <int MT, int P0, int NP, class PRE = NoPreA>
 __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restrict__ wp3, int cin, int mt0,
-                                            const float *planes, f32x4 (&acc)[MT][NP]) {
+                                            const float *planes, f32x4 (&acc)[MT][NP], const PRE &pre = PRE()) {
   constexpr int PB0 = P0 > 0 ? P0 - 1 : 0, PB1 = P0 + NP < 4 ? P0 + NP : 3, NB = PB1 - PB0 + 1;
   const int col = c.lane & 15, g = c.lane >> 4;
   const int kb32 = cin >> 5, kblocks = 3 * kb32;
@@ -638,9 +670,21 @@ __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restric
   };
   const int last = kb32 - 1;
   load_b(0, 0);
-  if constexpr (MT == 1) {
+  auto first_a = [&]() {   // block 0's fragments (three tap sets, or tap 0's with two m-tiles): the caller's, or requested here
 #pragma unroll
-    for (int t = 0; t < 3; ++t) load_a(t, t, 0);
+    for (int t = 0; t < (MT == 1 ? 3 : 1); ++t) {
+      if constexpr (PRE::on) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) a[t][mi][pl] = pre.a[t][mi][pl];
+      } else {
+        load_a(t, t, 0);
+      }
+    }
+  };
+  if constexpr (MT == 1) {
+    first_a();
     auto block = [&](int bbuf, int nb) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
@@ -668,7 +712,7 @@ __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restric
       }
     }
   } else {
-    load_a(0, 0, 0);
+    first_a();
     auto step = [&](int st, int kb0) {
         const int t = st % 3, kb = kb0 + st / 3;
         const int nt = (st + 1) % 3, nkb = kb0 + (st + 1) / 3;
@@ -1078,14 +1122,18 @@ constexpr int kOpInts = 12, kMaxOps = 84;  // op tape: 84 * 12 = 1008 ints; the 
 //   GK 0: partner = the adjacent wave (C = 256: 2 m-tiles per wave, C = 128: 1; all 4 positions)
 //   GK 1: partner = wave ^ 4 (C = 64: one m-tile = one group, positions split in two halves)
 //   GK 2: four waves (one per position) x two groups per m-tile (C = 32: 8 channels per group)
-template <int MT, int P0, int NP, int GK>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// FIN: which epilogues this instance carries (code size: the kernel's straight-line phases must stay inside the instruction
+// cache): 0 = none (the level's down conv, mode 0), 1 = block1 (H = act(GN(conv)), scale/shift at run time), 2 = block2
+// (X += act(GN(conv)), no scale/shift).  Modes 1 and 2 only ever run inside the fused ResnetBlock op.
+template <int MT, int P0, int NP, int GK, int FIN = 0, class PRE = NoPreA, class HOOK = NoHook>
 __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, const float *bias, int mt0,
                                               const float *src, int cin, float *dst, int cout, bool alias,
-                                              const GnEpilogue &g) {
+                                              const GnEpilogue &g, const PRE &pre = PRE(), const HOOK &hook = HOOK()) {
   using GG = Geo<64>;
   const int kq = c.lane >> 4, sm = c.lane & 15;
   f32x4 acc[MT][NP];
-  const bool has_ss = g.ss_w >= 0;
+  const bool has_ss = FIN == 1 && g.ss_w >= 0;
   const int ekb = g.E >> 4;
   const WStream wss(c.w + (has_ss ? g.ss_w : 0), c.lane);
   f32x4 ga[MT], be[MT], sc[MT], sh[MT], a_sc[MT], a_sh[MT];
@@ -1121,17 +1169,18 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
   GLDM_WV_STAMP(c, 3, (long long)(cin * 1000 + cout));
   const bool src_is_x = src == c.lds + GG::kBufX;
   if constexpr (MT == 1) {  // <= 128 output channels: the input has at most as many
-    gemm_pm3_pl<MT, P0, NP>(c, wp, cin, mt0, c.lds + (src_is_x ? kPlaneX : kPlaneH), acc);
+    gemm_pm3_pl<MT, P0, NP, PRE>(c, wp, cin, mt0, c.lds + (src_is_x ? kPlaneX : kPlaneH), acc, pre);
   } else {
-    if (cin <= kPlaneMaxC) gemm_pm3_pl<MT, P0, NP>(c, wp, cin, mt0, c.lds + (src_is_x ? kPlaneX : kPlaneH), acc);
-    else gemm_pm3_bf<MT, P0, NP>(c, wp, cin, mt0, src, acc);
+    if (cin <= kPlaneMaxC) gemm_pm3_pl<MT, P0, NP, PRE>(c, wp, cin, mt0, c.lds + (src_is_x ? kPlaneX : kPlaneH), acc, pre);
+    else gemm_pm3_bf<MT, P0, NP, PRE>(c, wp, cin, mt0, src, acc, pre);
   }
   GLDM_WV_STAMP(c, 1, (long long)__builtin_readcyclecounter());
-  if (g.mode) load_params();
+  if (FIN != 0) load_params();
+  hook();   // the fused ResnetBlock's request for its second conv's first fragments: in flight under this epilogue
   // outputs of up to 128 channels are also (or only) written as planes: exactly the one-m-tile instantiations (cout = 16 x
   // 8, 4 or 2 m-tiles of the workgroup; two m-tiles per wave = 256 channels)
   constexpr bool out_planes = MT == 1;
-  if (!g.mode) {  // the level's down conv: the new residual stream X (f32) and, up to 128 channels, its planes
+  if constexpr (FIN == 0) {  // the level's down conv: the new residual stream X (f32) and, up to 128 channels, its planes
     if (alias) __syncthreads();
     lds_f *d3 = (lds_f *)dst;
 #pragma unroll
@@ -1148,6 +1197,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
     GLDM_WV_NEXT(c);
     return;
   }
+  if constexpr (FIN != 0) {
   // ---- this wave's share of the statistics, per sample (= lane & 15)
   constexpr int kNloc = GK == 2 ? 8 * NP : 16 * MT * NP;  // values behind one published pair
   constexpr int kParts = GK == 2 ? 4 : 2;
@@ -1227,7 +1277,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
   // One straight-line instance per (mode, scale/shift): with the two tested per VALUE (wave-uniform branches inside
   // the unrolled loops) every value was its own chain of basic blocks -- 61 branches and no overlap between the 16-32
   // exp / rcp chains of a lane: 3.8-4.9 k cycles for the 16 values of a one-m-tile conv, alone on the SIMD or not.
-  lds_f *d3 = (lds_f *)(g.mode == 2 ? g.res : dst);
+  lds_f *d3 = (lds_f *)(FIN == 2 ? g.res : dst);
   auto finish = [&](auto mode_c, auto ss_c) {
     constexpr int kMode = decltype(mode_c)::value;
     constexpr bool kSS = decltype(ss_c)::value;
@@ -1256,12 +1306,12 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
       }
   };
   using std::integral_constant;
-  if (g.mode == 2) {
-    if (has_ss) finish(integral_constant<int, 2>{}, integral_constant<bool, true>{});
-    else finish(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+  if constexpr (FIN == 2) {
+    finish(integral_constant<int, 2>{}, integral_constant<bool, false>{});
   } else {
     if (has_ss) finish(integral_constant<int, 1>{}, integral_constant<bool, true>{});
     else finish(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+  }
   }
   GLDM_WV_STAMP(c, 2, (long long)__builtin_readcyclecounter());
   GLDM_WV_NEXT(c);
@@ -1380,27 +1430,57 @@ __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInt
   const float *w = c.w;
   const int c1_w = o[1], c1_b = o[2], n1_w = o[3], n1_b = o[4], c2_w = o[5], c2_b = o[6], n2_w = o[7], n2_b = o[8],
             ss_w = o[9], ss_b = o[10];
+  // Every weight of the phase is staged by explicit 16-byte loads issued in two batches in front of their use (wave-uniform
+  // addresses; all offsets are multiples of 4 floats in the packed buffer).  Left to the scheduler, one build of this
+  // kernel issued them one by one with a full wait each (18.7 k cycles for the phase instead of 5.8 k).
+  struct ConvW { f32x4 wt[16], b, g, be; };   // W[co][ci][tap] at f32x4 index ci * 16 + co (co < 4), taps in .xyz
+  auto load_conv = [&](ConvW &cw, int w_off, int b_off, int g_off, int be_off) {
+    const f32x4 *wv = reinterpret_cast<const f32x4 *>(w + w_off);
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int co = 0; co < 4; ++co) cw.wt[4 * ci + co] = wv[ci * 16 + co];
+    cw.b = *reinterpret_cast<const f32x4 *>(w + b_off);
+    cw.g = *reinterpret_cast<const f32x4 *>(w + g_off);
+    cw.be = *reinterpret_cast<const f32x4 *>(w + be_off);
+  };
+  f32x4 wss[4][8], bss[2];   // scale/shift Linear: W[row][e] at ((e & 3) * 16 + row) * 4 + (e >> 2): f32x4 (e & 3) * 16 + row
+  {
+    const f32x4 *wv = reinterpret_cast<const f32x4 *>(w + ss_w);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+      for (int row = 0; row < 8; ++row) wss[kq][row] = wv[kq * 16 + row];
+    bss[0] = *reinterpret_cast<const f32x4 *>(w + ss_b);
+    bss[1] = *reinterpret_cast<const f32x4 *>(w + ss_b + 4);
+  }
+  ConvW k1, k2;
+  load_conv(k1, c1_w, c1_b, n1_w, n1_b);
   float x[4];
 #pragma unroll
   for (int ci = 0; ci < 4; ++ci) x[ci] = X[pswz(ci, n)];
   float gq[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) gq[e] = e < E ? G[e] : 0.f;
+  __builtin_amdgcn_sched_barrier(0);
   float sc[4], sh[4];
 #pragma unroll
   for (int co = 0; co < 4; ++co) {
-    float a = w[ss_b + co], b = w[ss_b + 4 + co];
+    float a = bss[0][co], b = bss[1][co];
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {  // W[row][e] at ((e & 3) * 16 + row) * 4 + (e >> 2), e = 4 j + kq
-        a += w[ss_w + (kq * 16 + co) * 4 + j] * gq[4 * j + kq];
-        b += w[ss_w + (kq * 16 + 4 + co) * 4 + j] * gq[4 * j + kq];
+      for (int j = 0; j < 4; ++j) {
+        a += wss[kq][co][j] * gq[4 * j + kq];
+        b += wss[kq][4 + co][j] * gq[4 * j + kq];
       }
     sc[co] = a;
     sh[co] = b;
   }
-  auto conv3 = [&](const float (&in)[4], int cw, int cb, float (&out)[4]) {
+  __builtin_amdgcn_sched_barrier(0);
+  load_conv(k2, c2_w, c2_b, n2_w, n2_b);   // in flight under the first conv
+  __builtin_amdgcn_sched_barrier(0);
+  auto conv3 = [&](const float (&in)[4], const ConvW &cw, float (&out)[4]) {
     float lft[4], rgt[4];
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci) {
@@ -1410,10 +1490,10 @@ __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInt
     }
 #pragma unroll
     for (int co = 0; co < 4; ++co) {
-      float acc = w[cb + co];
+      float acc = cw.b[co];
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci) {  // W[co][ci][tap] at (ci * 16 + co) * 4 + tap
-        const float *wr = w + cw + (ci * 16 + co) * 4;
+      for (int ci = 0; ci < 4; ++ci) {
+        const f32x4 wr = cw.wt[4 * ci + co];
         acc += wr[0] * lft[ci];
         acc += wr[1] * in[ci];
         acc += wr[2] * rgt[ci];
@@ -1421,22 +1501,22 @@ __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInt
       out[co] = acc;
     }
   };
-  auto gn_act = [&](float (&v)[4], int gw, int gb, bool ss) {
+  auto gn_act = [&](float (&v)[4], const ConvW &cw, bool ss) {
 #pragma unroll
     for (int co = 0; co < 4; ++co) {
       const float m = half_sum(row_pair_sum(v[co])) * 0.25f;
       const float d = v[co] - m;
       const float rs = __builtin_amdgcn_rsqf(half_sum(row_pair_sum(d * d)) * 0.25f + 1e-5f);
-      float y = d * rs * w[gw + co] + w[gb + co];
+      float y = d * rs * cw.g[co] + cw.be[co];
       if (ss) y = y * sc[co] + sh[co];
       v[co] = silu(y);
     }
   };
   float y[4], z[4];
-  conv3(x, c1_w, c1_b, y);
-  gn_act(y, n1_w, n1_b, true);
-  conv3(y, c2_w, c2_b, z);
-  gn_act(z, n2_w, n2_b, false);
+  conv3(x, k1, y);
+  gn_act(y, k1, true);
+  conv3(y, k2, z);
+  gn_act(z, k2, false);
 #pragma unroll
   for (int co = 0; co < 4; ++co) X[pswz(co, n)] = x[co] + z[co];
 }
@@ -1765,6 +1845,42 @@ __device__ __forceinline__ void attention_quad_pm(const Ctx &c, float *qkv) {
   __syncthreads();
 }
 
+
+// A whole ResnetBlock of the position-major engine as ONE op: conv1 (GroupNorm, scale/shift, SiLU -> H), barrier, conv2
+// (GroupNorm, SiLU, X += ...).  Straight-line code, so the first weight fragments of conv2 can be requested while conv1's
+// epilogue runs and be there when its k-loop starts: requested cold at the top of the loop they cost ~1.8 k cycles per
+// conv (a build that loads no fragments at all runs the step 8 % faster; across two tape ops the compiler waits for
+// such loads at the op switch).  One tape decode and dispatch less, too.
+template <int MT, int P0, int NP, int GK>
+__device__ __forceinline__ void resblock_pm_wave(const Ctx &c, const float *wp1, const float *b1, const float *wp2,
+                                                 const float *b2, int mt0, float *X, float *H, int C,
+                                                 const GnEpilogue &g1, const GnEpilogue &g2, long long *stamp2) {
+  PreA<MT> pa;
+  const WStream wv2(wp2, c.lane);
+  auto ask = [&]() { pa.request(wv2, mt0, C); };
+  conv_pm3_wave<MT, P0, NP, GK, 1, NoPreA, decltype(ask)>(c, wp1, b1, mt0, X, C, H, C, false, g1, NoPreA(), ask);
+  __syncthreads();
+  if (stamp2 && c.tid == 0) *stamp2 = (long long)__builtin_readcyclecounter();
+  conv_pm3_wave<MT, P0, NP, GK, 2, PreA<MT>>(c, wp2, b2, mt0, H, C, X, C, false, g2, pa);
+}
+__device__ __forceinline__ void resblock_pm(const Ctx &c, int w1, int b1, int w2, int b2, float *X, float *H, int C,
+                                            const GnEpilogue &g1, const GnEpilogue &g2, long long *stamp2) {
+  const float *wp1 = c.w + w1, *bp1 = c.w + b1, *wp2 = c.w + w2, *bp2 = c.w + b2;
+  const int w = c.wave;
+  if (C == 256) resblock_pm_wave<2, 0, 4, 0>(c, wp1, bp1, wp2, bp2, 2 * w, X, H, C, g1, g2, stamp2);
+  else if (C == 128) resblock_pm_wave<1, 0, 4, 0>(c, wp1, bp1, wp2, bp2, w, X, H, C, g1, g2, stamp2);
+  else if (C == 64) {
+    if (w < 4) resblock_pm_wave<1, 0, 2, 1>(c, wp1, bp1, wp2, bp2, w & 3, X, H, C, g1, g2, stamp2);
+    else resblock_pm_wave<1, 2, 2, 1>(c, wp1, bp1, wp2, bp2, w & 3, X, H, C, g1, g2, stamp2);
+  } else {
+    const int pw = w >> 1;
+    if (pw == 0) resblock_pm_wave<1, 0, 1, 2>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
+    else if (pw == 1) resblock_pm_wave<1, 1, 1, 2>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
+    else if (pw == 2) resblock_pm_wave<1, 2, 1, 2>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
+    else resblock_pm_wave<1, 3, 1, 2>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
+  }
+  __syncthreads();
+}
 
 // dst[cout][NC] = W * im2col(src[cin][NC]) + bias: the waves split the output rows (all n-tiles each).
 // Ends with a barrier.  alias: dst overlaps src -> all reads complete (barrier) before any store.
@@ -2178,6 +2294,10 @@ struct RunArgs {
 enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKV4 = 5, OP_OUTLN = 6, OP_QKVLN = 7 };
 // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9 | (scale/shift table offset / 4) << 12
 constexpr int kFlagAlias = 1 << 8;
+#ifndef GLDM_NO_FUSE
+#define GLDM_NO_FUSE 0
+#endif
+constexpr int kFlagFused = 1 << 11;   // position-major engine: this conv and the next tape entry are one ResnetBlock op
 constexpr int kFlagTabShift = 12;
 
 // ResnetBlock of a 4-channel level with 4-position samples (the first level of the latent denoiser) on the
@@ -2316,8 +2436,8 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
       return;
     }
     // the position-major engine reads the split-bf16 copies of the conv weights (gemm_pm3_bf)
-    emit(OP_CONV, NC == 64 ? rb.c1_w3 : rb.c1_w, rb.c1_b, X, H, C, C, 3 | (1 << 9) | ((toff >> 2) << kFlagTabShift), rb.n1_w,
-         rb.n1_b, rb.ss_w, rb.ss_b);
+    emit(OP_CONV, NC == 64 ? rb.c1_w3 : rb.c1_w, rb.c1_b, X, H, C, C,
+         3 | (1 << 9) | (NC == 64 && !GLDM_NO_FUSE ? kFlagFused : 0) | ((toff >> 2) << kFlagTabShift), rb.n1_w, rb.n1_b, rb.ss_w, rb.ss_b);
     emit(OP_CONV, NC == 64 ? rb.c2_w3 : rb.c2_w, rb.c2_b, H, X, C, C, 3 | (2 << 9), rb.n2_w, rb.n2_b, -1, 0);  // X += act(GN(conv(H)))
   };
   // constant indices only: a dynamically indexed kernel argument is copied to scratch memory
@@ -2383,6 +2503,22 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
     else __builtin_amdgcn_s_setprio(3);
     switch (o[0]) {
       case OP_CONV: {
+        if constexpr (NC == 64) {
+          if (o[7] & kFlagFused) {   // ResnetBlock: this entry is conv1, the next one conv2 (same width, H -> X)
+            int q[kOpInts];
+            const int4 *t4 = reinterpret_cast<const int4 *>(tape + kOpInts * (op + 1));
+            const int4 q0 = t4[0], q1 = t4[1], q2 = t4[2];
+            q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w; q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+            q[8] = q2.x; q[9] = q2.y; q[10] = q2.z; q[11] = q2.w;
+#pragma unroll
+            for (int i = 0; i < kOpInts; ++i) q[i] = __builtin_amdgcn_readfirstlane(q[i]);
+            const GnEpilogue g1{1, o[8], o[9], o[10], o[11], E, o[6], o[6] / 4, c.lds + o[4], (o[7] >> kFlagTabShift) << 2};
+            const GnEpilogue g2{2, q[8], q[9], -1, 0, E, q[6], q[6] / 4, c.lds + q[4], 0};
+            resblock_pm(c, o[1], o[2], q[1], q[2], c.lds + o[3], c.lds + o[4], o[6], g1, g2, stamps ? stamps + op + 1 : nullptr);
+            ++op;
+            break;
+          }
+        }
         const int mode = GLDM_SKIP(c, 1) ? 0 : (o[7] >> 9) & 3;
         const GnEpilogue g{mode, o[8], o[9], GLDM_SKIP(c, 16) ? -1 : o[10], o[11], E, o[6], o[6] / 4, c.lds + o[4],
                            (o[7] >> kFlagTabShift) << 2};
