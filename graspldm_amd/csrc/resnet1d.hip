@@ -2749,14 +2749,17 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       const int l = pos_of(n), sm = samp_of(n);
       float acc = a.weights[d.init_b + ch];
       const float *wk = a.weights + d.init_w + ch * 7;
+      // the seven taps are requested together, in range or not: behind the range test each was a round trip of its own
+      float wq[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) wq[q] = wk[q];
 #pragma unroll
       for (int q = 0; q < 7; ++q) {
         const int p = l + q - 3;
-        if (p >= 0 && p < L) {
-          float xv = lat[col_of(sm, p)];
-          if (scale_in) xv = in_scale * xv;
-          acc += wk[q] * xv;
-        }
+        const bool in = p >= 0 && p < L;
+        float xv = lat[col_of(sm, in ? p : l)];
+        if (scale_in) xv = in_scale * xv;
+        acc = in ? acc + wq[q] * xv : acc;
       }
       X[PM ? pswz(ch, n) : swz<NC>(ch, n)] = acc;
     }
@@ -2767,6 +2770,15 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
 
     // ---- final 1x1 conv to one channel: eps[n] = b + sum_c w[c] X[c][n]
     if (!GLDM_SKIP(c, 128)) {
+      // this step's scheduler coefficients, requested now (two 16-byte loads, in flight under the reduction): read one
+      // by one where the update uses them they were six dependent L2 round trips per step
+      f32x4 cf_lo = f32x4{0.f, 1.f, 0.f, 0.f}, cf_hi = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.sched_kind != GLDM_SCHED_NONE) {
+        const f32x4 *cfp = reinterpret_cast<const f32x4 *>(a.sched_coef + (size_t)step * GLDM_SCHED_COEF_STRIDE);
+        cf_lo = cfp[0];
+        cf_hi = cfp[1];
+      }
+      const float final_b = a.weights[d.final_b];
       float *red1 = lds + GG::kMiscRed1;
       const int n = c.lane & (NC - 1), slot = c.wave * GG::kRP + c.lane / NC;
       float part = 0.f;
@@ -2776,14 +2788,14 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       red1[c.wave * NC + n] = part;
       __syncthreads();
       if (c.tid < NC) {
-        float e = a.weights[d.final_b];
+        float e = final_b;
 #pragma unroll
         for (int q = 0; q < GG::kWaves; ++q) e += red1[q * NC + c.tid];
         epsr[c.tid] = e;
         if (a.sched_kind != GLDM_SCHED_NONE) {
           const int s = samp_of(c.tid), l = pos_of(c.tid);
           const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
-          const float *cf = a.sched_coef + (size_t)step * GLDM_SCHED_COEF_STRIDE;
+          const float cf[8] = {cf_lo[0], cf_lo[1], cf_lo[2], cf_lo[3], cf_hi[0], cf_hi[1], cf_hi[2], cf_hi[3]};
           float nz = 0.f;
           if (a.sched_kind == GLDM_SCHED_DDPM && cf[7] != 0.f && a.step_noise)
             nz = a.step_noise[((size_t)step * a.n_samples + gi) * L + l];
@@ -3772,7 +3784,7 @@ GLDM_API int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const
     return GLDM_ERR_INVALID_ARG;
   if (desc->latent_dim != 0) return GLDM_ERR_INVALID_ARG;
   if (temb && !timesteps && !sample_t) return GLDM_ERR_INVALID_ARG;
-  if (sched_kind != GLDM_SCHED_NONE && !sched_coef) return GLDM_ERR_INVALID_ARG;
+  if (sched_kind != GLDM_SCHED_NONE && (!sched_coef || ((unsigned long long)sched_coef & 15))) return GLDM_ERR_INVALID_ARG;  // rows are read as 16-byte loads
   if (sched_kind == GLDM_SCHED_NONE && n_steps != 1) return GLDM_ERR_INVALID_ARG;
   RunArgs a{};
   a.d = *desc;

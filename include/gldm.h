@@ -199,7 +199,7 @@ typedef struct gldm_r1d_desc {
 
 enum gldm_sched_kind { GLDM_SCHED_NONE = 0, GLDM_SCHED_DDIM = 1, GLDM_SCHED_DDPM = 2, GLDM_SCHED_DPMPP = 3 };
 #define GLDM_SCHED_COEF_STRIDE 8
-/* per-step coefficient row (f32, computed on the host exactly like the
+/* per-step coefficient row (f32, the table 16-byte aligned; computed on the host exactly like the
  * scheduler library does on 0-dim f32 tensors):
  *   [0] sqrt(1-abar_t) [1] sqrt(abar_t)
  *   DDIM: [2] sqrt(abar_prev) [3] sqrt(1-abar_prev-sigma^2)
