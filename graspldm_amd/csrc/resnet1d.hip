@@ -2294,9 +2294,6 @@ struct RunArgs {
 enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKV4 = 5, OP_OUTLN = 6, OP_QKVLN = 7 };
 // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9 | (scale/shift table offset / 4) << 12
 constexpr int kFlagAlias = 1 << 8;
-#ifndef GLDM_NO_FUSE
-#define GLDM_NO_FUSE 0
-#endif
 constexpr int kFlagFused = 1 << 11;   // position-major engine: this conv and the next tape entry are one ResnetBlock op
 constexpr int kFlagTabShift = 12;
 
@@ -2437,7 +2434,7 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
     }
     // the position-major engine reads the split-bf16 copies of the conv weights (gemm_pm3_bf)
     emit(OP_CONV, NC == 64 ? rb.c1_w3 : rb.c1_w, rb.c1_b, X, H, C, C,
-         3 | (1 << 9) | (NC == 64 && !GLDM_NO_FUSE ? kFlagFused : 0) | ((toff >> 2) << kFlagTabShift), rb.n1_w, rb.n1_b, rb.ss_w, rb.ss_b);
+         3 | (1 << 9) | (NC == 64 ? kFlagFused : 0) | ((toff >> 2) << kFlagTabShift), rb.n1_w, rb.n1_b, rb.ss_w, rb.ss_b);
     emit(OP_CONV, NC == 64 ? rb.c2_w3 : rb.c2_w, rb.c2_b, H, X, C, C, 3 | (2 << 9), rb.n2_w, rb.n2_b, -1, 0);  // X += act(GN(conv(H)))
   };
   // constant indices only: a dynamically indexed kernel argument is copied to scratch memory
@@ -3268,8 +3265,9 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
 // input tile split ONCE while it is staged and kept in LDS as B-fragment planes
 //   [32-channel block][plane hi|mid|lo][g][32 columns][8 bf16]      (6 KiB per block; cin = 768: 144 KiB)
 // so the eight waves' k-loops are ds_read_b128 + buffer loads + MFMA.  A 32-column tile re-uses a weight fragment
-// for two n-tiles only: the weight stream (6 bytes per weight and tile) runs the CU's 64 B/clk L2 path about as long
-// as the MFMAs run the matrix pipe, so fragments are requested four blocks ahead (ring of four register sets).
+// for two n-tiles only: 7 MB of fragments per tile, 62 B/clk if the MFMAs were never to wait -- above the 50 B/clk a CU
+// draws from L2 (tools/micro/l2_stream), so fragments are requested four blocks ahead (ring of four register sets: 24 KiB
+// in flight per wave) and the ring is kept full across the units of output rows.
 // (Measured and dropped: 64-column tiles with K walked in 256-channel chunks -- planes of a chunk in LDS, accumulators of
 // half the output rows kept across the chunks, two passes, front layer recomputed per pass on the bf16 pipe: half the
 // weight bytes per column, yet the same 0.97-1.04 ms per 329 clouds as this kernel's 1.04: the stream is not what it
