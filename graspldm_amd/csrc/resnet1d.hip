@@ -3336,7 +3336,9 @@ __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *
       for (int kb = 0; kb < KB0; ++kb) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_split6(af[mi][kb], bp[kb][ni], acc[mi][ni]);
-        load_a(mi, kb, mtn);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(mi, kb, mtn);   // pinned here: the scheduler sinks such requests to their first use otherwise
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
