@@ -234,6 +234,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
       const int tn = tap + 1 < 27 ? tap + 1 : tap;
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) a_nxt[mi] = wv[((size_t)mi * kblocks + tn * cblocks + cb) * 64];
+      __builtin_amdgcn_sched_barrier(0);   // pinned in front of this tap's MFMAs: the scheduler sinks the request to its use
       const int toff = ((tap / 9) * 6 + (tap / 3) % 3) * zp + tap % 3;
       const int tnoff = ((tn / 9) * 6 + (tn / 3) % 3) * zp + tn % 3;
 #pragma unroll
