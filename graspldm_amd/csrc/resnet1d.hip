@@ -505,7 +505,7 @@ struct PreA {
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[t][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kblocks + t * kb32) * 3 + pl) * 64);
+        for (int pl = 0; pl < 3; ++pl) a[t][mi][pl] = wv.raw_at(((mt0 + mi) * kblocks + t * kb32) * 3072, pl * 1024);
   }
 };
 
@@ -536,7 +536,7 @@ __device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restric
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        a[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kblocks + t * kb32 + kb) * 3 + pl) * 64);
+        a[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kblocks + t * kb32 + kb) * 3072, pl * 1024);
   };
   auto load_raw = [&](int kb) {
     if constexpr (MT == 1) {
@@ -647,7 +647,7 @@ __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restric
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        a[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kblocks + t * kb32 + kb) * 3 + pl) * 64);
+        a[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kblocks + t * kb32 + kb) * 3072, pl * 1024);
   };
   auto load_b = [&](int buf, int kb) {
     if (kExpNoB && kb > 0) return;
@@ -744,9 +744,11 @@ __device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__
   u32x4 bs[2][3];
   auto load_a = [&](int buf, int kb) {
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+    for (int mi = 0; mi < MT; ++mi) {
+      const int sb = ((mt0 + mi) * KB32 + kb) * 3072;   // one scalar offset per (m-tile, block), the planes by immediates
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * KB32 + kb) * 3 + pl) * 64);
+      for (int pl = 0; pl < 3; ++pl) a[buf][mi][pl] = wv.raw_at(sb, pl * 1024);
+    }
   };
   auto load_b = [&](int buf, int kb, int ni) {
 #pragma unroll
@@ -3315,7 +3317,7 @@ __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *
   const int mt_first = wave * mt_per_wave0, mt_last = mt_first + mt_per_wave0 - 2;
   auto load_a = [&](int mi, int kb, int mt0) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) af[mi][kb][pl] = w0s.raw((((size_t)(mt0 + mi) * KB0 + kb) * 3 + pl) * 64);
+    for (int pl = 0; pl < 3; ++pl) af[mi][kb][pl] = w0s.raw_at(((mt0 + mi) * KB0 + kb) * 3072, pl * 1024);
   };
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -3428,7 +3430,7 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[buf][mi][pl] = wv.raw((((size_t)(mt0 + mi) * kb32 + kb) * 3 + pl) * 64);
+        for (int pl = 0; pl < 3; ++pl) af[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kb32 + kb) * 3072, pl * 1024);
     };
     u32x4 bs[2][2][3];
     auto load_b = [&](int buf, int kb) {

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
       for (int mi = 0; mi < 3; ++mi)
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-          a[buf][mi][k] = wv.raw((((size_t)(3 * mg + mi) * kblocks + cb * kPairs + p) * 3 + k) * 64);
+          a[buf][mi][k] = wv.raw_at((((3 * mg + mi) * kblocks + cb * kPairs + p) * 3) * 1024, k * 1024);
     };
     load_a(0, 0);
     __builtin_amdgcn_s_setprio(0);

@@ -27,6 +27,12 @@ struct WStream {
   __device__ __forceinline__ wstream_u32x4 raw(size_t i) const {
     return __builtin_bit_cast(wstream_u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v, (int)(i * 16), 0));
   }
+  // fragment at byte offset `sbytes` (wave uniform, in an SGPR) + `imm` (compile-time constant < 4096: the instruction's
+  // offset field): three planes of one (m-tile, block) are one scalar offset and immediates 0 / 1024 / 2048, instead of a
+  // scalar offset computed (and, in the big kernels, spilled and reloaded) per load
+  __device__ __forceinline__ wstream_u32x4 raw_at(int sbytes, int imm) const {
+    return __builtin_bit_cast(wstream_u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v + imm, sbytes, 0));
+  }
   __device__ __forceinline__ wstream_f32x4 operator[](size_t i) const {
     const auto q = __builtin_amdgcn_raw_buffer_load_b128(r, v, (int)(i * 16), 0);
     return wstream_f32x4{__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
