@@ -1621,11 +1621,10 @@ __device__ __forceinline__ void out_ln_pm(const Ctx &c, int w_off, int b_off, co
   else out_ln_wave<1, 1, false>(c, wp, bias, 0, w & 3, w < 4, w & 3, src, cin, xres, C, gain);
 }
 
-// PreNorm LayerNorm + to_qkv 1x1 conv of the 4-channel level (resnets.py:104-124,211-222) as one VALU phase: a column's
+// PreNorm LayerNorm + to_qkv 1x1 conv of the 4-channel level (resnets.py:104-124,211-222) as one phase: a column's
 // 4 channels are normalised in its lane (no exchange), then wave w produces rows 48 w .. 48 w + 47 of the 384-row
-// q|k|v block (all four heads, to_qkv's own row order; the LayerNorm gain is folded into the packed weights): 192
-// FMAs per lane against wave-uniform weights, fma chain in the MFMA's k order.  Replaces a 3-barrier LayerNorm pass
-// and padded K = 16 MFMA GEMMs.
+// q|k|v block (all four heads, to_qkv's own row order; the LayerNorm gain is folded into the packed weights) with
+// K = 4 MFMAs (see below).  Replaces a 3-barrier LayerNorm pass and padded K = 16 MFMA GEMMs.
 __device__ __forceinline__ void qkv4_pm(const Ctx &c, int w_off, const float *src, float *dst) {
   const int n = c.lane;
   const lds_f *s3 = (const lds_f *)src;
@@ -1644,25 +1643,32 @@ __device__ __forceinline__ void qkv4_pm(const Ctx &c, int w_off, const float *sr
   float y[4];
 #pragma unroll
   for (int ci = 0; ci < 4; ++ci) y[ci] = (x[ci] - mean) * rstd;
-  // A fragments of [384 x 16 (4 real)]: lane (r % 16) + 16 k of m-tile r / 16 holds W'[r][k] in its first element.
-  // Three fragment loads for the wave's three m-tiles, then every weight is broadcast from its lane (v_readlane: no
-  // memory round trip per weight).
+  // W'[384 x 4] y[4 x 64] is ONE v_mfma_f32_16x16x4_f32 per (m-tile, n-tile): the packed A fragment's first element is the
+  // MFMA's A operand as it stands (lane (r % 16) + 16 k holds W'[r][k]), and the B operand (lane col + 16 k = y[k] of column
+  // 16 j + col) is the normalised column re-read from LDS in that order.  12 MFMAs per wave instead of 192 x (v_readlane,
+  // hazard nop, v_fmac) -- a readlane-fed fma costs ~9 cycles of issue each (tools/micro/salu_rate) -- and the same k-ordered
+  // f32 fma chain from zero.  Every wave normalises all 64 columns itself and writes the same values to the same scratch
+  // rows, then reads its own writes: no barrier.
+  lds_f *ysc = (lds_f *)(c.lds + Geo<64>::kMiscRed1);   // [4][64]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ysc[64 * k + n] = y[k];
   const WStream wv(c.w + w_off, c.lane);
   const int t0 = __builtin_amdgcn_readfirstlane(c.wave * 3);
   f32x4 f[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) f[t] = wv[(size_t)(t0 + t) * 64];
+  const int col = n & 15, kq = n >> 4;
+  float b[4];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int fv = __float_as_int(f[t][0]);
+  for (int j = 0; j < 4; ++j) b[j] = ysc[64 * kq + 16 * j + col];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float acc = 0.f;
+  for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(fv, q + 16 * k)), y[k], acc);
-      d3[pswz(16 * (t0 + t) + q, n)] = acc;
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f[t][0], b[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d3[pswz(16 * (t0 + t) + 4 * kq + r, 16 * j + col)] = acc[r];
     }
-  }
   __syncthreads();
 }
 
