@@ -78,29 +78,69 @@ def event_time(fn, iters, lead=1):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+def count_gpus_without_hip():
+    """GPU nodes of the KFD topology (`simd_count` > 0), read from sysfs: no HIP / torch.cuda call, so the launcher parent
+    really never touches the GPU.  None when the topology is not readable (the ranks then find out for themselves)."""
+    import glob
+    n, seen = 0, False
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split(None, 1) for line in open(path).read().splitlines() if " " in line)
+        except OSError:
+            continue
+        seen = True
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n if seen else None
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without an outside launcher: N child processes of this script, one rank per GPU
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), started BEFORE anything here touches the GPU
-    (this parent never does, and nothing is re-exec'd).  Rank 0's JSON line is relayed; any failing child fails the run."""
+    (this parent never does -- devices are counted from sysfs -- and nothing is re-exec'd).  Rank 0's JSON line is
+    relayed.  All children are polled: the first one to fail ends the run at once (the others are terminated; a rank
+    that died before the rendezvous would otherwise leave rank 0 waiting for the process-group timeout)."""
     import socket
     import subprocess
+    import threading
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     if not args.dry_run:
-        have = torch.cuda.device_count()   # counting devices does not initialise HIP on this image
-        if have < args.gpus:
-            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+        have = count_gpus_without_hip()
+        if have is not None and have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) in the KFD topology")
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):   # the exact children started above
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
     # ONE JSON line on stdout: anything else rank 0's libraries wrote there (gloo / RCCL banners) goes to stderr
-    for line in out0.splitlines():
+    for line in out0:
+        line = line.rstrip("\n")
         print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
     sys.stdout.flush()
     if any(codes):
@@ -113,7 +153,7 @@ def dry_run(args, world, rank):
     from graspldm_amd.distributed import gather_results
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=__import__("datetime").timedelta(seconds=120))
     B, G = args.clouds_per_gpu, args.grasps
     rows = torch.full((B * G, 7), float(rank))
     if world > 1:
@@ -170,7 +210,7 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev, timeout=__import__("datetime").timedelta(seconds=300))
         world = dist.get_world_size()   # n_gpus in the line = the ranks RCCL saw
 
     from graspldm_amd import _lib

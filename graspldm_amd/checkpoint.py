@@ -6,9 +6,11 @@ grasp_ldm/utils/torch_utils.py:4-37) and hardens it for files written elsewhere:
 
   * Lightning `.ckpt` files pickle more than tensors (hyper-parameters holding the reference's
     `Config`, callbacks, optimiser states): none of those classes exist here.  `load_checkpoint` unpickles
-    with an ALLOW-LISTED class resolver (torch tensor / storage rebuild helpers, numpy arrays, plain containers);
-    every other global -- importable or not, `os.system` included -- becomes an inert placeholder, so the tensors are
-    still read and a crafted file cannot execute code through this loader; a bare state dict (no "state_dict" wrapper) is accepted too.
+    with an EXACT (module, name) allow-list (torch's own weights-only set: tensor / storage rebuild helpers, dtypes,
+    OrderedDict; numpy's array reconstruction helpers; plain builtin containers) that never resolves a dotted name
+    (protocol-4 `("torch", "os.system")` walks attributes); every other global -- importable or not -- becomes an inert
+    placeholder, so the tensors are still read and the loader resolves no foreign callable; a bare state dict (no
+    "state_dict" wrapper) is accepted too.
   * weights live under `model.` and, when an EMA copy was kept, `ema_model.online_model.` (the string the
     reference loads for use_ema_model=True, :521; kept verbatim).  Every other key (`ema_model.ema_model.*`,
     `ema_model.initted`, `ema_model.step`, loss buffers) is ignored, exactly like ignore_all_others=True.
@@ -54,43 +56,58 @@ class _Placeholder:
         return (_Placeholder, ())
 
 
-# Globals a Lightning checkpoint legitimately needs to rebuild its TENSORS and plain containers.  Everything else
-# (hyper-parameter objects, callbacks, and anything a crafted file might name: os.system, subprocess.Popen, ...) becomes
-# an inert placeholder, whether or not the class is importable here: the fallback loader never executes foreign code.
-_SAFE_MODULES = ("torch", "collections", "numpy", "_codecs")
-_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
-                  "complex", "slice", "range", "object"}
-_BLOCKED = {("torch", "load"), ("torch", "save"), ("torch.serialization", "load"), ("torch.hub", "load"),
-            ("numpy", "load"), ("numpy", "save"), ("numpy", "fromfile"), ("numpy", "memmap"), ("numpy", "loadtxt")}
+# Globals a Lightning checkpoint legitimately needs to rebuild its TENSORS and plain containers: an EXACT
+# (module, name) allow-list -- torch's own weights-only set (storages, dtypes, the _rebuild_* helpers, OrderedDict,
+# _codecs.encode) plus numpy's array reconstruction helpers and the plain builtin containers.  No module is allowed
+# wholesale and no dotted name is ever resolved: with pickle protocol >= 4 `find_class("torch", "os.system")` walks
+# attributes, so a prefix test on the module string would hand out `os.system` through any module that imports `os`.
+# Everything else (hyper-parameter objects, callbacks, anything a crafted file might name) becomes an inert placeholder,
+# whether or not it is importable here: the fallback loader never executes foreign code.
+_SAFE_BUILTINS = ("dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
+                  "complex", "slice", "range", "object")
+_NUMPY_MODULES = ("numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric",
+                  "numpy.dtypes")
+_NUMPY_NAMES = ("ndarray", "dtype", "_reconstruct", "scalar", "float32", "float64", "int64", "int32", "bool_", "uint8",
+                "int8", "int16", "float16", "Float32DType", "Float64DType", "Int64DType", "Int32DType")
+
+
+def _allowed_globals():
+    """{"module.name": object} -- built once; the objects themselves, so nothing is looked up by attribute walk."""
+    import importlib
+    from torch._weights_only_unpickler import _get_allowed_globals
+    allowed = dict(_get_allowed_globals())
+    import builtins
+    for n in _SAFE_BUILTINS:
+        allowed[f"builtins.{n}"] = getattr(builtins, n)
+    for m in _NUMPY_MODULES:
+        try:
+            mod = importlib.import_module(m)
+        except Exception:
+            continue
+        for n in _NUMPY_NAMES:
+            obj = mod.__dict__.get(n)
+            if obj is not None:
+                allowed[f"{m}.{n}"] = obj
+    return allowed
+
+
+_ALLOWED = None
 
 
 def _is_safe_global(module, name):
-    if (module, name) in _BLOCKED or name.startswith("_") and module == "builtins":
+    global _ALLOWED
+    if "." in name:  # STACK_GLOBAL with a dotted name = an attribute walk: never
         return False
-    if module == "builtins":
-        return name in _SAFE_BUILTINS
-    root = module.split(".", 1)[0]
-    if root not in _SAFE_MODULES:
-        return False
-    if root == "torch":  # storages, dtypes, rebuild helpers, Size, OrderedDict-like containers; no I/O or JIT entry points
-        return module in ("torch", "torch._utils", "torch.storage", "torch._tensor", "torch.nn.parameter",
-                          "torch.serialization") and not name.startswith("load")
-    if root == "numpy":
-        return module in ("numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric",
-                          "numpy._core.numeric", "numpy.dtypes") and name in (
-                              "ndarray", "dtype", "_reconstruct", "scalar", "float32", "float64", "int64", "int32", "bool_",
-                              "uint8", "int8", "int16", "float16", "Float32DType", "Float64DType", "Int64DType", "Int32DType")
-    return True
+    if _ALLOWED is None:
+        _ALLOWED = _allowed_globals()
+    return f"{module}.{name}" in _ALLOWED
 
 
 class _TolerantUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if _is_safe_global(module, name):
-            try:
-                return super().find_class(module, name)
-            except Exception:
-                pass
-        return type(name, (_Placeholder,), {"__module__": module})
+            return _ALLOWED[f"{module}.{name}"]
+        return type(name.rpartition(".")[2] or "Foreign", (_Placeholder,), {"__module__": module})
 
 
 class _TolerantPickle:

@@ -605,7 +605,15 @@ __global__ __launch_bounds__(512) void groupnorm_swish_kernel(float *__restrict_
     float *row = y + ((size_t)b * c + ch) * r3;
     const float ga = gamma[ch] * rstd, be = beta[ch] - mean * rstd * gamma[ch];
     float acc = 0.f;
-    const int n4 = r3 >> 2;
+    const int n4 = (r3 & 3) ? 0 : r3 >> 2;   // rows are 16-byte aligned only when r^3 is a multiple of 4
+    if (r3 & 3) {
+      for (int i = tid; i < r3; i += 512) {
+        const float t = row[i] * ga + be;
+        const float o = t / (1.0f + __expf(-t));
+        acc += o;
+        row[i] = o;
+      }
+    }
     for (int i = tid; i < n4; i += 512) {
       float4 v = reinterpret_cast<float4 *>(row)[i];
       float o[4] = {v.x, v.y, v.z, v.w};
@@ -773,7 +781,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_generic_kernel(const float *__r
                                                                 const float *__restrict__ bias, int cin, int cout, int r,
                                                                 float *__restrict__ y, float *__restrict__ partial) {
   __shared__ float s_red[2][4];
-  const int bpr = r / kBrick, r3 = r * r * r, nvox = 16 * r;
+  const int bpr = (r + kBrick - 1) / kBrick, r3 = r * r * r, nvox = 16 * r;   // any r: the last brick row / column may be partial
   const int bx0 = (blockIdx.x / bpr) * kBrick, by0 = (blockIdx.x % bpr) * kBrick, b = blockIdx.y;
   x += (size_t)b * cin * r3;
   y += (size_t)b * cout * r3;
@@ -782,6 +790,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_generic_kernel(const float *__r
     float s = 0.f, s2 = 0.f;
     for (int v = tid; v < nvox; v += 256) {
       const int iz = v % r, ixy = v / r, gx = bx0 + (ixy >> 2), gy = by0 + (ixy & 3);
+      if (gx >= r || gy >= r) continue;
       float acc = bias[co];
       for (int ci = 0; ci < cin; ++ci) {
         const float *xc = x + (size_t)ci * r3;
@@ -815,8 +824,9 @@ __global__ __launch_bounds__(256) void conv3d_k3_generic_kernel(const float *__r
 }  // namespace
 
 GLDM_API long long gldm_conv3d_partial_floats(int b, int cout, int r) {
-  if (b <= 0 || cout <= 0 || r <= 0 || r % kBrick) return -1;
-  return (long long)b * (r / kBrick) * (r / kBrick) * cout * 2;
+  if (b <= 0 || cout <= 0 || r <= 0) return -1;
+  const long long bpr = (r + kBrick - 1) / kBrick;   // a resolution that is not a multiple of the brick has partial edge bricks
+  return (long long)b * bpr * bpr * cout * 2;
 }
 
 template <int MT, int NTW>
@@ -929,9 +939,9 @@ GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const f
 
 GLDM_API int gldm_groupnorm_swish(float *y, const float *partial, const float *gamma, const float *beta, int b, int c,
                                   int r, int groups, float eps, float *chan_sum, gldm_stream_t stream) {
-  if (!y || !partial || !gamma || !beta || b <= 0 || c <= 0 || r <= 0 || groups <= 0 || c % groups || r % 4)
+  if (!y || !partial || !gamma || !beta || b <= 0 || c <= 0 || r <= 0 || groups <= 0 || c % groups)
     return GLDM_ERR_INVALID_ARG;
-  const int nbricks = (r / kBrick) * (r / kBrick);
+  const int nbricks = ((r + kBrick - 1) / kBrick) * ((r + kBrick - 1) / kBrick);
   hipLaunchKernelGGL(groupnorm_swish_kernel, dim3(groups, b), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), y,
                      partial, gamma, beta, c, r * r * r, nbricks, groups, eps, chan_sum);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
@@ -956,8 +966,7 @@ GLDM_API int gldm_devoxelize_fused(const float *coords, const float *features, c
 GLDM_API int gldm_conv3d_k3_generic(const float *x, const float *w, const float *bias, int b, int cin, int cout, int r,
                                     float *y, float *partial, gldm_stream_t stream) {
   if (!x || !w || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
-  if (r % kBrick) return GLDM_ERR_UNSUPPORTED;
-  const int bpr = r / kBrick;
+  const int bpr = (r + kBrick - 1) / kBrick;
   hipLaunchKernelGGL(conv3d_k3_generic_kernel, dim3(bpr * bpr, b), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w,
                      bias, cin, cout, r, y, partial);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;

@@ -167,15 +167,6 @@ def pointwise_conv_bn_relu(x, conv, bn):
     return _gemm_bias_act(x, w, b, True)
 
 
-def conv3d_gn_swish(x, conv, gn):
-    """Swish(GroupNorm(Conv3d_k3(x)))  (pvconv.py:48-66) for a voxel shape csrc/voxel_conv.hip has no instantiation
-    for: there is no library fallback on this path, the caller gets a GldmError naming the shape."""
-    from ._lib import GldmError
-    raise GldmError(f"voxel conv {conv.in_channels} -> {conv.out_channels} at resolution {x.shape[-1]} is not instantiated "
-                    "in csrc/voxel_conv.hip (channels % 16 == 0, resolution % 4 == 0 and one of the (channels / 16, "
-                    "resolution / 4) pairs of graspldm_amd.voxel.SUPPORTED): add the instantiation")
-
-
 def linear(x, lin):
     """nn.Linear over the last axis of [..., n] (the encoder's out_layer[1] over the POINT axis): hand-written row
     kernel (gldm_linear_rows); n % 4 == 0 and n <= 16384, else the library GEMM."""

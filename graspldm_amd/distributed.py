@@ -22,6 +22,14 @@ def shard_noise(x_T, num_grasps, lo, hi):
     return x_T[lo * num_grasps:hi * num_grasps]
 
 
+def shard_step_noise(step_noise, num_grasps, lo, hi):
+    """Slice the globally drawn DDPM per-step noise [steps, B*G, 1, D] (the draws of gaussian_diffusion.py:258-272, one
+    per step and latent) along the latent axis: rank r sees exactly the rows its latents would see in a single-process
+    run, so a DDPM run is as independent of the world size as a DDIM one.  Contiguous copy: the fused launch indexes it
+    as [step][local latent]."""
+    return step_noise[:, lo * num_grasps:hi * num_grasps].contiguous()
+
+
 def gather_results(local_rows, per_rank_rows, total_rows, group=None):
     """local_rows [n_r, 7] (n_r <= per_rank_rows) -> [total_rows, 7] on every rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -35,15 +43,24 @@ def gather_results(local_rows, per_rank_rows, total_rows, group=None):
 
 
 @torch.no_grad()
-def generate_sharded(generate_fn, pcs, num_grasps, x_T=None, group=None):
-    """generate_fn(pc_shard, x_T_shard) -> (tmrp [n,6], logit [n,1]).  pcs [B,N,3] is the
-    GLOBAL batch (same on every rank); returns the global (tmrp, logit)."""
+def generate_sharded(generate_fn, pcs, num_grasps, x_T=None, group=None, step_noise=None, check=None):
+    """generate_fn(pc_shard, x_T_shard[, step_noise_shard]) -> (tmrp [n,6], logit [n,1]).  pcs [B,N,3] is the
+    GLOBAL batch (same on every rank); returns the global (tmrp, logit).  `step_noise` [steps, B*G, 1, D] (DDPM) is
+    global too and sliced like x_T; it is passed as a third argument only when given.  `check` (e.g. the denoise
+    engine's `check`: raises if a step-segment hand-off of the fused launch was lost) runs before the result rows
+    leave the rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B = pcs.shape[0]
     lo, hi, per = shard_bounds(B, world, rank)
     if hi > lo:
-        tm, lg = generate_fn(pcs[lo:hi], None if x_T is None else shard_noise(x_T, num_grasps, lo, hi))
+        xs = None if x_T is None else shard_noise(x_T, num_grasps, lo, hi)
+        if step_noise is None:
+            tm, lg = generate_fn(pcs[lo:hi], xs)
+        else:
+            tm, lg = generate_fn(pcs[lo:hi], xs, shard_step_noise(step_noise, num_grasps, lo, hi))
+        if check is not None:
+            check()
         rows = torch.cat([tm, lg], dim=1)
     else:
         rows = torch.zeros((0, 7), dtype=torch.float32, device=pcs.device)

@@ -310,20 +310,18 @@ class PVConv(nn.Module):
         se = mods[-1] if isinstance(mods[-1], SE3d) else None
         from . import voxel
         pf = self.point_features(features)
-        if self.resolution % 4 == 0:
-            # hand-written path: implicit-GEMM conv3d on f32 MFMA, GN+Swish, SE gate folded into the
-            # devoxelize pass together with the point-branch add
-            plan = self.__dict__.get("_voxel_plan")
-            from ._cache import params_key, publish
-            key = params_key([c.weight for c in convs], vox.device)
-            if plan is None or plan.key != key:
-                plan = voxel.VoxelBranchPlan(convs, vox.device, self.resolution)
-                plan.key = key
-                self.__dict__["_voxel_plan"] = plan
-                publish(vox.device)
-            return voxel.run(plan, convs, norms, se, vox, norm_coords, pf, self.resolution), coords
-        # resolutions that are not a multiple of the 4 x 4 x r brick: no kernel (raises GldmError naming the shape)
-        return dense.conv3d_gn_swish(vox, convs[0], norms[0]), coords
+        # hand-written path: implicit-GEMM conv3d on MFMA (shapes with an instantiation) or the direct any-shape kernel
+        # (every other width / resolution, partial edge bricks included), GN+Swish, SE gate folded into the devoxelize
+        # pass together with the point-branch add
+        plan = self.__dict__.get("_voxel_plan")
+        from ._cache import params_key, publish
+        key = params_key([c.weight for c in convs], vox.device)
+        if plan is None or plan.key != key:
+            plan = voxel.VoxelBranchPlan(convs, vox.device, self.resolution)
+            plan.key = key
+            self.__dict__["_voxel_plan"] = plan
+            publish(vox.device)
+        return voxel.run(plan, convs, norms, se, vox, norm_coords, pf, self.resolution), coords
 
 
 # --------------------------------------------------------------------- builders

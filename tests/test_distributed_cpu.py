@@ -20,6 +20,30 @@ def _fake_generate(pc, x_T):
     return tm, x_T[:, 0, :1] - feat[:, :1]
 
 
+def _fake_ddpm_generate(pc, x_T, step_noise):
+    """Stand-in for a DDPM run: x_{t-1} = 0.9 x_t + 0.1 f(cloud) + 0.05 noise_t, per latent."""
+    g = x_T.shape[0] // pc.shape[0]
+    feat = pc.mean(dim=1).repeat_interleave(g, 0)
+    x = x_T[:, 0, :3]
+    for t in range(step_noise.shape[0]):
+        x = 0.9 * x + 0.1 * feat + 0.05 * step_noise[t, :, 0, :3]
+    return torch.cat([x, x * feat], dim=1), x[:, :1]
+
+
+def _worker_ddpm(rank, world, port, B, G, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    pcs = torch.randn(B, 32, 3, generator=g)
+    x_T = torch.randn(B * G, 1, 4, generator=g)
+    noise = torch.randn(T, B * G, 1, 4, generator=g)
+    checked = []
+    tm, lg = generate_sharded(_fake_ddpm_generate, pcs, G, x_T, step_noise=noise, check=lambda: checked.append(1))
+    q.put((rank, tm, lg, len(checked)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, B, G, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -64,6 +88,50 @@ def test_two_ranks_match_single_process(B):
     tm_ref, lg_ref = _fake_generate(pcs, x_T)
     for _, tm, lg in outs:
         assert torch.equal(tm, tm_ref) and torch.equal(lg, lg_ref)
+
+
+def _run_two(target, args):
+    ctx = mp.get_context("spawn")
+    for attempt in range(3):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=target, args=(r, 2, port) + args + (q,)) for r in range(2)]
+        [p.start() for p in procs]
+        outs, waited = [], 0
+        while len(outs) < 2 and waited < 240:
+            try:
+                outs.append(q.get(timeout=5))
+            except Exception:
+                waited += 5
+                if not any(p.is_alive() for p in procs) and q.empty():
+                    break
+        [p.join(timeout=60) for p in procs]
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        if len(outs) == 2:
+            return outs
+    return None
+
+
+@pytest.mark.parametrize("B", [5, 2])
+def test_ddpm_step_noise_is_world_size_independent(B):
+    """DDPM draws fresh noise at every step (gaussian_diffusion.py:258-272).  Drawn globally [steps, B*G, 1, D] and
+    sliced per rank (shard_step_noise), a two-rank run equals the single-process run bit for bit; the engine check hook
+    runs once per rank that owns clouds."""
+    from graspldm_amd.distributed import shard_step_noise
+    G, T = 3, 7
+    outs = _run_two(_worker_ddpm, (B, G, T))
+    assert outs is not None, "two-rank gloo run failed three times"
+    g = torch.Generator().manual_seed(0)
+    pcs = torch.randn(B, 32, 3, generator=g)
+    x_T = torch.randn(B * G, 1, 4, generator=g)
+    noise = torch.randn(T, B * G, 1, 4, generator=g)
+    tm_ref, lg_ref = _fake_ddpm_generate(pcs, x_T, noise)
+    for _, tm, lg, nchk in outs:
+        assert torch.equal(tm, tm_ref) and torch.equal(lg, lg_ref) and nchk == 1
+    sl = shard_step_noise(noise, G, 1, 2)
+    assert sl.is_contiguous() and torch.equal(sl, noise[:, G:2 * G])
 
 
 def test_shard_bounds_cover_everything():

@@ -511,9 +511,8 @@ def test_linear_rows_kernel():
 
 def test_voxel_conv_without_mfma_instantiation_runs_the_direct_kernel():
     """A PVConv whose voxel shape has no MFMA instantiation (40 channels: not a multiple of 16) runs the direct kernel
-    (gldm_conv3d_k3_generic), not a library fallback; a resolution that is not a multiple of 4 raises."""
-    import torch.nn.functional as F
-    from graspldm_amd._lib import GldmError
+    (gldm_conv3d_k3_generic), not a library fallback; so does a resolution that is not a multiple of the 4 x 4 x r brick
+    (partial edge bricks; r^3 not a multiple of 4 takes GroupNorm's scalar pass)."""
     from graspldm_amd.pvcnn import PVConv
     from graspldm_amd.synthetic import load_synthetic_weights
     m = load_synthetic_weights(PVConv(8, 40, 3, 8, with_se=True), seed=2).cuda().eval()
@@ -528,6 +527,25 @@ def test_voxel_conv_without_mfma_instantiation_runs_the_direct_kernel():
     exp = R.pvconv(sd, "", feats, coords, 8, True, False)
     exp = exp[0] if isinstance(exp, tuple) else exp
     assert _err(out, exp) < 2e-5, _err(out, exp)
-    bad = load_synthetic_weights(PVConv(8, 16, 3, 6), seed=3).cuda().eval()
-    with pytest.raises(GldmError, match="not instantiated"):
-        bad((feats.cuda(), coords.cuda()))
+    for cout, r, se in ((16, 6, False), (24, 9, True), (48, 18, True)):
+        odd = load_synthetic_weights(PVConv(8, cout, 3, r, with_se=se), seed=3).cuda().eval()
+        with torch.no_grad():
+            out, _ = odd((feats.cuda(), coords.cuda()))
+        sd = {k: v.detach().cpu() for k, v in odd.state_dict().items()}
+        exp = R.pvconv(sd, "", feats, coords, r, True, False)
+        exp = exp[0] if isinstance(exp, tuple) else exp
+        assert out.shape == (2, cout, 256) and _err(out, exp) < 2e-5, (cout, r, _err(out, exp))
+
+
+def test_pvcnn2_encoder_default_constructor_runs():
+    """The registry encoder as it is default-constructed (scale_channels 0.25, scale_voxel_resolution 0.75: PVConv
+    resolutions 24, 12 and 6 -- 6 is not a multiple of the voxel kernels' 4 x 4 x r brick) builds and runs."""
+    from graspldm_amd.pc_encoders import PVCNN2Encoder
+    from graspldm_amd.pvcnn import PVConv
+    from graspldm_amd.synthetic import load_synthetic_weights, synthetic_batch
+    enc = load_synthetic_weights(PVCNN2Encoder(), seed=9).cuda().eval()
+    assert sorted({m.resolution for m in enc.modules() if isinstance(m, PVConv)}) == [6, 12, 24]
+    pcs, _ = synthetic_batch(2, 1024)
+    with torch.no_grad():
+        z = enc(pcs.cuda())
+    assert z.shape == (2, 32) and torch.isfinite(z).all()
