@@ -114,6 +114,14 @@ __device__ __forceinline__ int pswz(int row, int col) { return row * 64 + (col ^
 constexpr int kPlaneH = 128 * 64;                 // H planes: floats [8192, 20480)  (the q|k|v block of the attention
 constexpr int kPlaneX = 128 * 64 + 128 * 96;      // X planes: floats [20480, 32768)  phases overlays both)
 constexpr int kPlaneMaxC = 128;
+// The 256-channel level (only ever the last one: a down conv into it and one ResnetBlock) keeps ONE tensor in LDS, as planes
+// over both regions (kPlaneW = kPlaneH: 8 blocks x 12 KiB = floats [8192, 32768)): the down conv writes the planes of the new
+// residual stream X there and parks X itself (f32) in global scratch (Ctx::park: every lane stores and later re-loads its own
+// accumulator values, 8 x 16 B, coalesced); conv1 reads the planes and, behind its GroupNorm exchange barrier (every wave
+// is past its k-loop), overwrites them with the planes of H; conv2 reads those and forms X = parked + act(GN(conv)) as f32
+// rows for the final 1x1.  Both convs then run on loads + MFMA only; with X and H as f32 rows (64 KiB each, no room for
+// planes) every wave re-read and re-split all 256 x 64 values per conv: 44 k cycles of k-loop for 30.7 k of MFMAs.
+constexpr int kPlaneW = kPlaneH;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 typedef __attribute__((address_space(3))) u32x4 lds_u4;
@@ -193,6 +201,9 @@ struct Ctx {
   // scale / shift rows precomputed per conditioning cloud (pose decoder: ss_table_kernel), for the tile's samples 0 and
   // 1 (16-position engine: a 16-column n-tile is one sample), or null: computed in the epilogue
   const float *ss_row[2] = {nullptr, nullptr};
+  // position-major engine, 256-channel level: this workgroup's 64 KiB of global scratch where the residual stream is
+  // parked (f32) between the level's down conv and the end of its ResnetBlock, while LDS holds the split planes
+  float *park = nullptr;
 };
 
 // ---------------------------------------------------------------- GEMM ----
@@ -509,125 +520,7 @@ struct PreA {
   }
 };
 
-template <int MT, int P0, int NP, class PRE = NoPreA>
-__device__ __forceinline__ void gemm_pm3_bf(const Ctx &c, const float *__restrict__ wp3, int cin, int mt0,
-                                            const float *src, f32x4 (&acc)[MT][NP], const PRE &pre = PRE()) {
-  constexpr int NC = 64;
-  constexpr int PB0 = P0 > 0 ? P0 - 1 : 0, PB1 = P0 + NP < 4 ? P0 + NP : 3, NB = PB1 - PB0 + 1;
-  const int col = c.lane & 15, g = c.lane >> 4;
-  const int kb32 = cin >> 5, kblocks = 3 * kb32;
-  const WStream wv(wp3, c.lane);
-  const lds_f *src3 = (const lds_f *)src;
-  // rows 32 kb + 8 g + j, j = 0..7, of the column (16 (PB0 + q) + col): one lane base per tile (pswz)
-  int b0[NB];
-#pragma unroll
-  for (int q = 0; q < NB; ++q) b0[q] = pswz(8 * g, 16 * (PB0 + q) + col);
-  // A registers.  One m-tile per wave: a set per tap, refilled with the next block's fragments right after the tap's
-  // MFMAs (a whole block to arrive).  Two m-tiles: 72 registers that way, so two sets alternate over the tap steps
-  // instead (the next step's fragments are requested in front of the current step's MFMAs: 36-48 of them, and the
-  // partner wave's, to arrive); the trip covers two blocks so that the alternation is static.
-  constexpr int NA = MT == 1 ? 3 : 2;
-  u32x4 a[NA][MT][3];
-  float raw[MT == 1 ? NB : 2][8];
-  u32x4 bs[NB][3];
-  auto load_a = [&](int buf, int t, int kb) {
-    if (kExpNoA && kb > 0) return;
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        a[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kblocks + t * kb32 + kb) * 3072, pl * 1024);
-  };
-  auto load_raw = [&](int kb) {
-    if constexpr (MT == 1) {
-      const lds_f *s = src3 + kb * 32 * NC;
-#pragma unroll
-      for (int q = 0; q < NB; ++q)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[q][j] = s[b0[q] + j * NC];
-    }
-  };
-  auto split_all = [&]() {
-    if constexpr (MT == 1) {
-#pragma unroll
-      for (int q = 0; q < NB; ++q) split_bf16x3(raw[q], bs[q]);
-    }
-  };
-  auto tap_mfmas = [&](int buf, int t) {
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int sp = P0 + p + t - 1;  // source position of this tap for out tile P0 + p
-        if (sp >= 0 && sp <= 3) {
-          const int qi = sp - PB0 < 0 ? 0 : (sp - PB0 >= NB ? NB - 1 : sp - PB0);
-          acc[mi][p] = mfma_split6(a[buf][mi], bs[qi], acc[mi][p]);
-        }
-      }
-  };
-  const int last = kb32 - 1;
-  auto first_a = [&]() {   // block 0's fragments (three tap sets, or tap 0's with two m-tiles): the caller's, or requested here
-#pragma unroll
-    for (int t = 0; t < (MT == 1 ? 3 : 1); ++t) {
-      if constexpr (PRE::on) {
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) a[t][mi][pl] = pre.a[t][mi][pl];
-      } else {
-        load_a(t, t, 0);
-      }
-    }
-  };
-  if constexpr (MT == 1) {
-    load_raw(0);
-    first_a();
-    for (int kb = 0; kb < kb32; ++kb) {
-      const int nb = kb < last ? kb + 1 : last;  // clamped: every load stays unconditional
-      split_all();
-      load_raw(nb);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        __builtin_amdgcn_sched_barrier(0);
-        tap_mfmas(t, t);
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(t, t, nb);
-      }
-    }
-  } else {
-    first_a();
-    auto step = [&](int st, int kb0) {
-        const int t = st % 3, kb = kb0 + st / 3;
-        const int nt = (st + 1) % 3, nkb = kb0 + (st + 1) / 3;
-        if (t == 0 && !(kExpNoB && kb > 0)) {
-          // this block's B values: read and split tile by tile, two tiles of raw values in flight (the block-ahead
-          // form of the one-m-tile path costs 32 more registers here)
-          const lds_f *sb = src3 + kb * 32 * NC;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) raw[0][j] = sb[b0[0] + j * NC];
-#pragma unroll
-          for (int q = 0; q < NB; ++q) {
-            if (q + 1 < NB) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) raw[(q + 1) & 1][j] = sb[b0[q + 1] + j * NC];
-            }
-            split_bf16x3(raw[q & 1], bs[q]);
-          }
-        }
-        load_a((st + 1) & 1, nt, nkb < last ? nkb : last);
-        __builtin_amdgcn_sched_barrier(0);
-        tap_mfmas(st & 1, t);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // pairs of blocks: the two A sets alternate statically (this path only sees Cin = 256: smaller inputs have planes)
-    for (int kb0 = 0; kb0 < kb32; kb0 += 2) {
-#pragma unroll
-      for (int st = 0; st < 6; ++st) step(st, kb0);
-    }
-  }
-}
-
-// The same conv with the B operand read from pre-split planes (Cin <= 128): ds_read_b128 per (tile, plane), no VALU.
+// The conv with the B operand read from pre-split planes: ds_read_b128 per (tile, plane), no VALU.
 // B planes of the next channel block are requested while the current block's MFMAs run (second register set).
 template <int MT, int P0, int NP, class PRE = NoPreA>
 __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restrict__ wp3, int cin, int mt0,
@@ -637,7 +530,11 @@ __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restric
   const int kb32 = cin >> 5, kblocks = 3 * kb32;
   const WStream wv(wp3, c.lane);
   const lds_u4 *pl3 = (const lds_u4 *)planes + g * 64 + 16 * PB0 + col;   // + (kb * 3 + plane) * 256 + 16 q
-  constexpr int NA = MT == 1 ? 3 : 2;  // see gemm_pm3_bf
+  // A registers.  One m-tile per wave: a set per tap, refilled with the next block's fragments right after the tap's
+  // MFMAs (a whole block to arrive).  Two m-tiles: 72 registers that way, so two sets alternate over the tap steps
+  // instead (the next step's fragments are requested in front of the current step's MFMAs: 36-48 of them, and the
+  // partner wave's, to arrive); the trip covers two blocks so that the alternation is static.
+  constexpr int NA = MT == 1 ? 3 : 2;
   constexpr int NBUF = (MT == 1 && NB <= 3) ? 2 : 1;   // 4 tiles x 2 sets = 96 registers: spills
   u32x4 a[NA][MT][3];
   u32x4 bs[NBUF][NB][3];
@@ -1171,35 +1068,42 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
 #pragma unroll
     for (int p = 0; p < NP; ++p) acc[mi][p] = bv;
   }
-  // B operand: pre-split planes (Cin <= 128; the X planes or the H planes, by which buffer `src` is) or f32 rows split
-  // on the fly (the 256-channel level)
+  // B operand: pre-split planes.  Up to 128 input channels: the X planes or the H planes, by which buffer `src` is; 256
+  // (the last level's ResnetBlock): the level's one plane set (kPlaneW)
   GLDM_WV_STAMP(c, 0, (long long)__builtin_readcyclecounter());
   GLDM_WV_STAMP(c, 3, (long long)(cin * 1000 + cout));
   const bool src_is_x = src == c.lds + GG::kBufX;
-  if constexpr (MT == 1) {  // <= 128 output channels: the input has at most as many
-    gemm_pm3_pl<MT, P0, NP, PRE>(c, wp, cin, mt0, c.lds + (src_is_x ? kPlaneX : kPlaneH), acc, pre);
-  } else {
-    if (cin <= kPlaneMaxC) gemm_pm3_pl<MT, P0, NP, PRE>(c, wp, cin, mt0, c.lds + (src_is_x ? kPlaneX : kPlaneH), acc, pre);
-    else gemm_pm3_bf<MT, P0, NP, PRE>(c, wp, cin, mt0, src, acc, pre);
-  }
+  const float *bplanes = c.lds + (cin > kPlaneMaxC ? kPlaneW : (src_is_x ? kPlaneX : kPlaneH));
+  gemm_pm3_pl<MT, P0, NP, PRE>(c, wp, cin, mt0, bplanes, acc, pre);
   GLDM_WV_STAMP(c, 1, (long long)__builtin_readcyclecounter());
   if (FIN != 0) load_params();
+  // 256-channel level (two m-tiles per wave): this lane's slice of the parked residual stream, one f32x4 per (m-tile, position)
+  constexpr bool kWide = MT == 2;
+  f32x4 *pk = reinterpret_cast<f32x4 *>(c.park) + (size_t)(c.wave * MT * NP) * 64 + c.lane;
+  f32x4 parked[FIN == 2 && kWide ? MT : 1][FIN == 2 && kWide ? NP : 1];
+  if constexpr (FIN == 2 && kWide) {   // requested here, in flight under the statistics and the exchange barrier
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) parked[mi][p] = pk[(mi * NP + p) * 64];
+  }
   hook();   // the fused ResnetBlock's request for its second conv's first fragments: in flight under this epilogue
-  // outputs of up to 128 channels are also (or only) written as planes: exactly the one-m-tile instantiations (cout = 16 x
-  // 8, 4 or 2 m-tiles of the workgroup; two m-tiles per wave = 256 channels)
-  constexpr bool out_planes = MT == 1;
-  if constexpr (FIN == 0) {  // the level's down conv: the new residual stream X (f32) and, up to 128 channels, its planes
+  if constexpr (FIN == 0) {  // the level's down conv: the new residual stream X as planes, and as f32 rows (up to 128
+                             // channels: in LDS) or parked in global scratch (256: see kPlaneW)
     if (alias) __syncthreads();
     lds_f *d3 = (lds_f *)dst;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
+        if constexpr (kWide) {
+          pk[(mi * NP + p) * 64] = acc[mi][p];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d3[pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm)] = acc[mi][p][r];
-        if (out_planes)
-          store_planes4(c.lds + kPlaneX, 16 * (mt0 + mi) + 4 * kq, 16 * (P0 + p) + sm, acc[mi][p][0], acc[mi][p][1],
-                        acc[mi][p][2], acc[mi][p][3]);
+          for (int r = 0; r < 4; ++r) d3[pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm)] = acc[mi][p][r];
+        }
+        store_planes4(c.lds + (kWide ? kPlaneW : kPlaneX), 16 * (mt0 + mi) + 4 * kq, 16 * (P0 + p) + sm, acc[mi][p][0],
+                      acc[mi][p][1], acc[mi][p][2], acc[mi][p][3]);
       }
     GLDM_WV_STAMP(c, 2, (long long)__builtin_readcyclecounter());
     GLDM_WV_NEXT(c);
@@ -1280,8 +1184,9 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
     m2 += ps2[q] + (float)kNloc * dm * dm;
   }
   const float rstd = __builtin_amdgcn_rsqf(m2 * (1.0f / (float)(kNloc * kParts)) + 1e-5f);
-  // mode 1 (block1): H = y, as planes only up to 128 channels (H is only ever a conv input), f32 rows above;
-  // mode 2 (block2): X += y in f32 (the residual stream), plus the planes of the new X up to 128 channels.
+  // mode 1 (block1): H = y, as planes only (H is only ever a conv input);
+  // mode 2 (block2): X += y in f32 (the residual stream), plus the planes of the new X up to 128 channels; at 256
+  // channels X = parked + y as f32 rows only (what follows is the final 1x1 conv).
   // One straight-line instance per (mode, scale/shift): with the two tested per VALUE (wave-uniform branches inside
   // the unrolled loops) every value was its own chain of basic blocks -- 61 branches and no overlap between the 16-32
   // exp / rcp chains of a lane: 3.8-4.9 k cycles for the 16 values of a one-m-tile conv, alone on the SIMD or not.
@@ -1300,17 +1205,16 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
           if (kSS) t = t * sc[mi][r] + sh[mi][r];
           t = silu(t);
           const int a = pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm);
-          if (kMode == 2) {
-            t = d3[a] + t;
-            d3[a] = t;
-          } else if (!out_planes) {
+          if constexpr (kMode == 2) {
+            if constexpr (kWide) t = parked[mi][p][r] + t;
+            else t = d3[a] + t;
             d3[a] = t;
           }
           y[r] = t;
         }
-        if (out_planes)
-          store_planes4(c.lds + (kMode == 2 ? kPlaneX : kPlaneH), 16 * (mt0 + mi) + 4 * kq, 16 * (P0 + p) + sm, y[0], y[1],
-                        y[2], y[3]);
+        if constexpr (!(kMode == 2 && kWide))
+          store_planes4(c.lds + (kMode == 2 ? kPlaneX : (kWide ? kPlaneW : kPlaneH)), 16 * (mt0 + mi) + 4 * kq,
+                        16 * (P0 + p) + sm, y[0], y[1], y[2], y[3]);
       }
   };
   using std::integral_constant;
@@ -2254,6 +2158,7 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
 // unique per launch and step; the zero-initialised workspace holds tag 0, which no hand-off uses.
 struct ChainHdr { unsigned ticket, done, epoch, error; };
 constexpr int kChainHdrBytes = 256;
+constexpr int kParkBytes = 256 * 64 * 4;   // one [256][64] f32 tile per workgroup (Ctx::park)
 __device__ __forceinline__ unsigned chain_tag(unsigned epoch, int step) { return (epoch << 12) | (unsigned)step; }
 __device__ __forceinline__ void chain_give(unsigned long long *g, float v, unsigned tag) {
   __hip_atomic_store(g, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2289,6 +2194,7 @@ struct RunArgs {
   float *out0;            // denoise: x_out [n][L]; decode: tmrp [n][6]
   float *out1;            // decode: logit [n]
   float *ws;              // workspace: chain header + hand-off granules (+ the decoder's scale/shift table)
+  float *park;            // position-major engine with a 256-channel last level: 64 KiB of scratch per workgroup (Ctx::park)
   const float *ss_tab;    // [n_cond][ss_stride] scale/shift rows of every ResnetBlock per conditioning cloud, or null
   int ss_stride;
   int skip;               // diagnostic phase-skip mask (GLDM_R1D_SKIP env; 0 in production)
@@ -2620,6 +2526,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   auto col_of = [](int sm, int l) { return PM ? 16 * l + sm : sm * L + l; };
   Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
         a.skip, GG::kNT};
+  if constexpr (PM) c.park = a.park + (size_t)blockIdx.x * (kParkBytes / 4);
   const int E = d.emb_dim, R = d.cond_rows;
   float *lat = lds + GG::kMiscLat, *epsr = lds + GG::kMiscEps, *G = lds + GG::kMiscG;
   float *X = lds + GG::kBufX;
@@ -3026,6 +2933,16 @@ bool pm_supported(const gldm_r1d_desc *d) {
 
 using gldm_dev::cu_count;
 
+// Scratch behind the hand-off granules where the position-major engine parks the residual stream of a 256-channel last
+// level (kPlaneW): 64 KiB per workgroup of the launch (at most one per CU), 256-byte aligned.  *base is rounded up to the
+// alignment; returns the bytes to add behind it (0: this descriptor never parks).
+long long park_bytes(const gldm_r1d_desc *d, long long tiles, long long *base) {
+  if (!pm_supported(d) || d->dims[d->n_levels] != 256) return 0;
+  *base = (*base + 255) & ~255LL;
+  const long long wgs = tiles < cu_count() ? tiles : cu_count();
+  return wgs * kParkBytes;
+}
+
 // Work plan of one launch.  `slots` = workgroups resident at once (two 32-column tiles per CU).  A batch of
 // up to `slots` tiles is one workgroup per tile.  A larger one runs `slots` persistent workgroups: each owns
 // `rounds` whole tiles, and the `left` tiles beyond the whole rounds are NOT run as a last, partly empty
@@ -3076,6 +2993,12 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   if (tiles <= 0) return GLDM_ERR_UNSUPPORTED;  // > ~250 k samples in one launch: split the batch
   RunArgs a = a_in;
   a.slots = pl.slots; a.rounds = pl.rounds; a.left_tiles = pl.left; a.chain = pl.chain; a.seglen = pl.seglen;
+  a.park = nullptr;
+  if (pm) {
+    const long long all_tiles = (a_in.n_samples + 16 - 1) / 16;
+    long long off = kChainHdrBytes + all_tiles * 64 * 8;
+    if (park_bytes(&a_in.d, all_tiles, &off) > 0) a.park = reinterpret_cast<float *>(reinterpret_cast<char *>(a_in.ws) + off);
+  }
   a.n_cus = cu_count();
 #ifdef GLDM_DEBUG_KNOBS
   // diagnostic builds only (make EXTRA=-DGLDM_DEBUG_KNOBS): phase skipping, a start offset for the
@@ -3784,6 +3707,7 @@ GLDM_API long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_sam
   const long long tiles = (n_samples + S - 1) / S;
   long long bytes = kChainHdrBytes + tiles * nc * 8;
   if (ss_table_rows(desc) > 0) bytes = ((bytes + 255) & ~255LL) + (long long)n_samples * ss_table_rows(desc) * 4;
+  bytes += park_bytes(desc, tiles, &bytes);
   return bytes;
 }
 

@@ -223,7 +223,10 @@ int gldm_r1d_cond_embed(const float *z_cond /*[n_cond,R,Dc]*/, const float *w /*
  * left-over tiles are split along the step axis over several workgroups.  For a pose-decoder descriptor
  * (seq_len 16, latent_dim > 0, emb_dim >= 32) it also holds, behind those, the ResnetBlocks' scale/shift
  * rows per conditioning cloud (4 bytes x n_samples x sum of 2 C over the blocks: sized for one grasp per
- * cloud), written by gldm_decode itself before the fused launch.
+ * cloud), written by gldm_decode itself before the fused launch.  For a latent-denoiser descriptor of the
+ * position-major engine whose last level has 256 channels it holds, behind the granules (256-byte aligned),
+ * 64 KiB of scratch per workgroup of the launch (min(tiles, compute units)): the level's residual stream is
+ * parked there, by the lanes that re-load it, while LDS holds its split-bf16 planes.
  * Contract: the caller ZEROES the workspace once, when it allocates it; a workspace is used by one
  * launch at a time (launches on the same stream may share it, concurrent streams may not); the
  * library re-arms it at the end of every launch.  The 32-bit word at byte GLDM_R1D_WS_ERROR is set
