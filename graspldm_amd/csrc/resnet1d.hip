@@ -631,7 +631,8 @@ __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restric
 }
 
 // 1x1 conv with the B operand from pre-split planes (the folded-LayerNorm qkv conv reads the X planes).
-template <int KB32, int MT, int NT, class PRE = NoPre>
+// MS: stride between the wave's m-tiles (the fused qkv + attention phase takes a head's q, k and v rows: 8 m-tiles apart).
+template <int KB32, int MT, int NT, class PRE = NoPre, int MS = 1>
 __device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__ wp3, int mt0, int nt0, const float *planes,
                                          f32x4 (&acc)[MT][NT], const PRE &pre = PRE()) {
   const int col = c.lane & 15, g = c.lane >> 4;
@@ -642,7 +643,7 @@ __device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__
   auto load_a = [&](int buf, int kb) {
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
-      const int sb = ((mt0 + mi) * KB32 + kb) * 3072;   // one scalar offset per (m-tile, block), the planes by immediates
+      const int sb = ((mt0 + mi * MS) * KB32 + kb) * 3072;   // one scalar offset per (m-tile, block), the planes by immediates
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) a[buf][mi][pl] = wv.raw_at(sb, pl * 1024);
     }
@@ -1525,64 +1526,9 @@ __device__ __forceinline__ void out_ln_pm(const Ctx &c, int w_off, int b_off, co
   else out_ln_wave<1, 1, false>(c, wp, bias, 0, w & 3, w < 4, w & 3, src, cin, xres, C, gain);
 }
 
-// PreNorm LayerNorm + to_qkv 1x1 conv of the 4-channel level (resnets.py:104-124,211-222) as one phase: a column's
-// 4 channels are normalised in its lane (no exchange), then wave w produces rows 48 w .. 48 w + 47 of the 384-row
-// q|k|v block (all four heads, to_qkv's own row order; the LayerNorm gain is folded into the packed weights) with
-// K = 4 MFMAs (see below).  Replaces a 3-barrier LayerNorm pass and padded K = 16 MFMA GEMMs.
-__device__ __forceinline__ void qkv4_pm(const Ctx &c, int w_off, const float *src, float *dst) {
-  const int n = c.lane;
-  const lds_f *s3 = (const lds_f *)src;
-  lds_f *d3 = (lds_f *)dst;
-  float x[4];
-#pragma unroll
-  for (int ci = 0; ci < 4; ++ci) x[ci] = s3[pswz(ci, n)];
-  const float mean = (x[0] + x[1] + x[2] + x[3]) * 0.25f;
-  float vt = 0.f;
-#pragma unroll
-  for (int ci = 0; ci < 4; ++ci) {
-    const float d = x[ci] - mean;
-    vt += d * d;
-  }
-  const float rstd = __builtin_amdgcn_rsqf(vt * 0.25f + 1e-5f);
-  float y[4];
-#pragma unroll
-  for (int ci = 0; ci < 4; ++ci) y[ci] = (x[ci] - mean) * rstd;
-  // W'[384 x 4] y[4 x 64] is ONE v_mfma_f32_16x16x4_f32 per (m-tile, n-tile): the packed A fragment's first element is the
-  // MFMA's A operand as it stands (lane (r % 16) + 16 k holds W'[r][k]), and the B operand (lane col + 16 k = y[k] of column
-  // 16 j + col) is the normalised column re-read from LDS in that order.  12 MFMAs per wave instead of 192 x (v_readlane,
-  // hazard nop, v_fmac) -- a readlane-fed fma costs ~9 cycles of issue each (tools/micro/salu_rate) -- and the same k-ordered
-  // f32 fma chain from zero.  Every wave normalises all 64 columns itself and writes the same values to the same scratch
-  // rows, then reads its own writes: no barrier.
-  lds_f *ysc = (lds_f *)(c.lds + Geo<64>::kMiscRed1);   // [4][64]
-#pragma unroll
-  for (int k = 0; k < 4; ++k) ysc[64 * k + n] = y[k];
-  const WStream wv(c.w + w_off, c.lane);
-  const int t0 = __builtin_amdgcn_readfirstlane(c.wave * 3);
-  f32x4 f[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) f[t] = wv[(size_t)(t0 + t) * 64];
-  const int col = n & 15, kq = n >> 4;
-  float b[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) b[j] = ysc[64 * kq + 16 * j + col];
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f[t][0], b[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d3[pswz(16 * (t0 + t) + 4 * kq + r, 16 * j + col)] = acc[r];
-    }
-  __syncthreads();
-}
-
-// PreNorm LayerNorm folded into the to_qkv 1x1 conv (resnets.py:104-124,211-222) for the 16 | C levels of the
-// position-major engine:  W (g * (x - mean) * rstd) = rstd * (W' x - mean * s),  W' = W diag(g), s = W' 1  (both
-// prepared on the host).  All 384 q|k|v rows (to_qkv's own order) in one sweep: 3 m-tiles x 4 n-tiles a wave.
-// The column statistics are taken while the first weight fragments are on their way: wave w owns columns 8 w .. 8 w + 7,
-// lane = (row part, column), two passes over the C / 8 values in its registers (the reference's mean, then
-// sum (x - mean)^2), the parts meet through DPP / permlane swaps, (mean, rstd) go to LDS and are picked up by every
-// wave's epilogue after the barrier that follows the GEMM: no LayerNorm phase, no normalised copy of x.
+// Rows of the per-column LayerNorm statistics the fused qkv + attention phase needs (see qkv_att_pm): wave w owns columns
+// 8 w .. 8 w + 7, lane = (row part, column), two passes over the C / 8 values in its registers (the reference's mean,
+// then sum (x - mean)^2), the parts meet through DPP / permlane swaps, (mean, rstd) go to LDS.
 template <int RP>  // rows per lane: C / 8
 __device__ __forceinline__ void column_stats8(const Ctx &c, const float *src, float inv_c) {
   constexpr int NC = 64;
@@ -1613,152 +1559,163 @@ __device__ __forceinline__ void column_stats8(const Ctx &c, const float *src, fl
   }
 }
 
-__device__ __forceinline__ void qkv_ln_pm(const Ctx &c, int w_off, int s_off, const float *src, int C, float *dst) {
-  constexpr int NC = 64, MT = 3, NT = 4;
+// Residual(PreNorm(LinearAttention)) up to its to_out conv (resnets.py:104-124, 211-235) as ONE phase of the position-major
+// engine: PreNorm LayerNorm, to_qkv 1x1 conv and the attention core of all four heads, with q, k and v never leaving the
+// accumulators (they used to be stored as a [384][64] f32 block -- 96 KiB through ds_write_b32 -- and read back by a
+// separate three-barrier attention phase).
+//   * Wave = (head h, channel half): its three m-tiles are rows 32 h + 16 half .. + 15 of q, of k and of v (to_qkv's own
+//     row order: m-tiles 2 h + half, + 8, + 16).  In the C layout of the MFMA a lane then holds, for ONE sample (lane & 15),
+//     four channels (4 (lane >> 4) + r) at all four positions (the n-tiles), of q, k and v alike.
+//   * LayerNorm is folded into the conv for the 16 | C levels:  W (g (x - mean) rstd) = rstd (W' x - mean s),  W' = W diag(g),
+//     s = W' 1  (both prepared on the host); the column statistics are taken while the first weight fragments are on their
+//     way (column_stats8) and applied to the accumulators after the one barrier that publishes them.  The 4-channel level
+//     normalises its columns in the lanes and multiplies with K = 4 f32 MFMAs (the packed A fragment's first element is
+//     the operand as it stands).
+//   * Attention, reassociated at n = L = 4:  out[e][n] = sum_m v[e][m] A[m][n],  A[m][n] = scale / sum_d exp(q[d][n] - max_n)
+//     * sum_d softmax_m(k[d])[m] exp(q[d][n] - max_n).  The key softmax over a sample's 4 positions and the products with v
+//     are in-lane; the sums over d (32 channels of the head) are in-lane over the lane's 4 channels, permlane swaps over
+//     the four row quarters, and ONE exchange through LDS between the two waves of the head: each publishes
+//     (max, sum, A) taken over its own 16 channels and merges the partner's like two blocks of an online softmax.
+//   * The output leaves as split-bf16 planes (it is only ever the B operand of to_out), into the H-plane region.
+// Barriers: statistics, exchange, end (the two phases this replaces had five).
+constexpr int kAttExch = 512 * 64;   // floats [32768, 35840): 8 waves x 24 rows x 16 samples, behind the X planes
+static_assert(kAttExch + 8 * 24 * 16 <= Geo<64>::kArena, "attention exchange slots");
+template <int KB32>   // C / 32 (0: the 4-channel level)
+__device__ __forceinline__ void qkv_att_pm(const Ctx &c, int w_off, int s_off, const float *src, int C) {
+  constexpr int NC = 64;
   using GG = Geo<NC>;
   if (GLDM_SKIP(c, 8)) return;
-  const float *wp = c.w + w_off, *srow = c.w + s_off;
-  const int mt0 = 3 * c.wave;
-  const int col = c.lane & 15, kq = c.lane >> 4;
-  f32x4 sv[MT];
+  const int head = c.wave >> 1, half = c.wave & 1;
+  const int mt0 = 2 * head + half;   // q rows; k: m-tile + 8, v: + 16
+  const int sm = c.lane & 15, kq = c.lane >> 4;
+  f32x4 acc[3][4];
+  if constexpr (KB32 == 0) {
+    const int n = c.lane;
+    const lds_f *s3 = (const lds_f *)src;
+    float x[4];
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi) sv[mi] = *reinterpret_cast<const f32x4 *>(srow + 16 * (mt0 + mi) + 4 * kq);
-  f32x4 acc[MT][NT];
+    for (int ci = 0; ci < 4; ++ci) x[ci] = s3[pswz(ci, n)];
+    const float mean = (x[0] + x[1] + x[2] + x[3]) * 0.25f;
+    float vt = 0.f;
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi)
+    for (int ci = 0; ci < 4; ++ci) {
+      const float d = x[ci] - mean;
+      vt += d * d;
+    }
+    const float rstd = __builtin_amdgcn_rsqf(vt * 0.25f + 1e-5f);
+    // every wave normalises all 64 columns itself and writes the same values to the same scratch rows, then reads its
+    // own writes in B-operand order (lane col + 16 k = y[k] of column 16 j + col): no barrier
+    lds_f *ysc = (lds_f *)(c.lds + GG::kMiscRed1);   // [4][64]
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int cblocks = C >> 4;
-  const float inv_c = __builtin_amdgcn_rcpf((float)C);  // C: a power of two -> exact
-  const float *xp = c.lds + kPlaneX;  // the conv runs on the X planes, the column statistics on the f32 rows
-  if (cblocks == 8) {
-    gemm1_pl<4, MT, NT>(c, wp, mt0, 0, xp, acc, [&]() { column_stats8<16>(c, src, inv_c); });
-  } else if (cblocks == 4) {
-    gemm1_pl<2, MT, NT>(c, wp, mt0, 0, xp, acc, [&]() { column_stats8<8>(c, src, inv_c); });
+    for (int k = 0; k < 4; ++k) ysc[64 * k + n] = (x[k] - mean) * rstd;
+    const WStream wv(c.w + w_off, c.lane);
+    f32x4 f[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) f[t] = wv[(size_t)(mt0 + 8 * t) * 64];
+    float b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = ysc[64 * kq + 16 * j + sm];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[t][0], b[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
   } else {
-    gemm1_pl<1, MT, NT>(c, wp, mt0, 0, xp, acc, [&]() { column_stats8<4>(c, src, inv_c); });
+    const float *wp = c.w + w_off, *srow = c.w + s_off;
+    f32x4 sv[3];
+#pragma unroll
+    for (int mi = 0; mi < 3; ++mi) sv[mi] = *reinterpret_cast<const f32x4 *>(srow + 16 * (mt0 + 8 * mi) + 4 * kq);
+#pragma unroll
+    for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float inv_c = __builtin_amdgcn_rcpf((float)C);  // C: a power of two -> exact
+    auto stats = [&]() { column_stats8<4 * KB32>(c, src, inv_c); };
+    gemm1_pl<KB32, 3, 4, decltype(stats), 8>(c, wp, mt0, 0, c.lds + kPlaneX, acc, stats);
+    __syncthreads();  // every column's (mean, rstd) is in LDS
+    const lds_f *mean3 = (const lds_f *)(c.lds + GG::kMiscRed1), *rstd3 = (const lds_f *)(c.lds + GG::kMiscRed2);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const float rstd = rstd3[16 * ni + sm];
+      const float mr = mean3[16 * ni + sm] * rstd;
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][ni][r] = acc[mi][ni][r] * rstd - mr * sv[mi][r];
+    }
   }
-  __syncthreads();  // every column's (mean, rstd) is in LDS
-  const lds_f *mean3 = (const lds_f *)(c.lds + GG::kMiscRed1), *rstd3 = (const lds_f *)(c.lds + GG::kMiscRed2);
-  lds_f *d3 = (lds_f *)dst;
+  // ---- keys: softmax over the sample's 4 positions, per channel (in lane)
+  float kn[4][4];   // [position][channel r]
 #pragma unroll
-  for (int ni = 0; ni < NT; ++ni) {
-    const float rstd = rstd3[16 * ni + col];
-    const float mr = mean3[16 * ni + col] * rstd;
+  for (int r = 0; r < 4; ++r) {
+    const float km = fmaxf(fmaxf(acc[1][0][r], acc[1][1][r]), fmaxf(acc[1][2][r], acc[1][3][r]));
+    float ks = 0.f;
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const int row0 = 16 * (mt0 + mi) + 4 * kq, cf = 16 * ni + col;
+    for (int p = 0; p < 4; ++p) {
+      kn[p][r] = fast_exp(acc[1][p][r] - km);
+      ks += kn[p][r];
+    }
+    const float inv = __builtin_amdgcn_rcpf(ks);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) d3[pswz(row0 + r, cf)] = acc[mi][ni][r] * rstd - mr * sv[mi][r];
+    for (int p = 0; p < 4; ++p) kn[p][r] *= inv;
+  }
+  // ---- queries: exp(q - max) and their sum over this wave's 16 channels of the head, per position
+  float qe[4][4], qm[4], qs[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float m = fmaxf(fmaxf(acc[0][p][0], acc[0][p][1]), fmaxf(acc[0][p][2], acc[0][p][3]));
+    m = half_max(row_pair_max(m));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      qe[p][r] = fast_exp(acc[0][p][r] - m);
+      sum += qe[p][r];
+    }
+    qm[p] = m;
+    qs[p] = half_sum(row_pair_sum(sum));
+  }
+  // ---- A[m][n] over this wave's channels
+  float A[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float a = kn[m][0] * qe[n][0];
+#pragma unroll
+      for (int r = 1; r < 4; ++r) a = fmaf(kn[m][r], qe[n][r], a);
+      A[m][n] = half_sum(row_pair_sum(a));
+    }
+  // ---- exchange with the other half of the head (wave ^ 1): rows [max 4 | sum 4 | A 16] x 16 samples
+  lds_f *ex = (lds_f *)(c.lds + kAttExch);
+  if (kq == 0) {
+    lds_f *mine = ex + c.wave * 384 + sm;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      mine[16 * n] = qm[n];
+      mine[16 * (4 + n)] = qs[n];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) mine[16 * (8 + 4 * m + n)] = A[m][n];
     }
   }
   __syncthreads();
-}
-
-// LinearAttention core (resnets.py:223-235) of all four heads, position-major: qkv [384][64] in to_qkv's row order
-// (q | k | v, head h at rows 32 h of each third); the output o [128][64] leaves as split-bf16 planes (see the end).
-//   out[e][n] = sum_m v[e][m] A[m][n],   A[m][n] = scale / sum_d exp(q[d][n] - max) * sum_d softmax_m(k[d])[m] exp(q[d][n] - max)
-// Phase 1: softmax of k over the sample's 4 positions, once per (head, channel, sample), written back in place (wave =
-// (head, 16 channels), lane = (sample, 4 channels)).  Phase 2: wave = (head, position pair), lane = (sample, part):
-// 8 of the head's 32 channels at the two columns 16 * position + sample; the sample's four key / value columns are
-// the same lane's columns in the four position tiles, read once for both positions; every reduction over the parts
-// is a permlane swap inside the wave.  A lane overwrites exactly the q elements it alone has read: no o buffer.
-// Banks: lanes l and l + 16 (neighbouring parts) sit 8 (phase 1: 4) rows apart in the same columns, the same bank of
-// a ds_read_b32 / ds_write_b32.  Phase 1's odd parts walk the positions in the order 1, 0, 3, 2 and phase 2's odd
-// parts walk their channels in that order: opposite row parity or column half, hence the other half of the banks.
-__device__ __forceinline__ void attention_quad_pm(const Ctx &c, float *qkv) {
-  if (GLDM_SKIP(c, 4)) return;
-  lds_f *q3 = (lds_f *)qkv;
-  const int sm = c.lane & 15, pt = c.lane >> 4, odd = pt & 1;
-  const int head = c.wave >> 1, half = c.wave & 1;
-  {
-    const int row0 = kHidden + kDimHead * head + 16 * half + 4 * pt, cx = odd << 4;
-    float k[4][4];
+  const lds_f *oth = ex + (c.wave ^ 1) * 384 + sm;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+  for (int n = 0; n < 4; ++n) {
+    const float mo = oth[16 * n], so = oth[16 * (4 + n)];
+    const float m = fmaxf(qm[n], mo);
+    const float fs = fast_exp(qm[n] - m), fo = fast_exp(mo - m);
+    const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(qs[n] * fs + so * fo);   // dim_head ** -0.5 / sum
 #pragma unroll
-      for (int j = 0; j < 4; ++j) k[u][j] = q3[pswz(row0 + u, (16 * j + sm) ^ cx)];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float km = fmaxf(fmaxf(k[u][0], k[u][1]), fmaxf(k[u][2], k[u][3]));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) k[u][j] = fast_exp(k[u][j] - km);
-      const float inv = __builtin_amdgcn_rcpf(k[u][0] + k[u][1] + k[u][2] + k[u][3]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) q3[pswz(row0 + u, (16 * j + sm) ^ cx)] = k[u][j] * inv;
-    }
+    for (int mm = 0; mm < 4; ++mm) A[mm][n] = (A[mm][n] * fs + oth[16 * (8 + 4 * mm + n)] * fo) * sc;
   }
-  const int d0 = kDimHead * head + 8 * pt;
-  const int qr = d0, kr = kHidden + d0, vr = 2 * kHidden + d0;
-  const int n0 = 32 * half + sm;  // columns of the wave's two positions: n0, n0 + 16
-  float qe[2][8], qsum[2];
-  float vv[8][4];
-  {
-    float q[2][8], qmax[2] = {-3.0e38f, -3.0e38f};
+  // ---- out[e][n] = sum_m v[e][m] A[m][n] for the lane's 4 channels e, as planes (32-channel block = head)
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+  for (int n = 0; n < 4; ++n) {
+    float o[4];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        q[e][i] = q3[pswz(qr + (i ^ odd), n0 + 16 * e)];
-        qmax[e] = fmaxf(qmax[e], q[e][i]);
-      }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) vv[i][j] = q3[pswz(vr + (i ^ odd), 16 * j + sm)];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      qmax[e] = half_max(row_pair_max(qmax[e]));
-      qsum[e] = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        qe[e][i] = fast_exp(q[e][i] - qmax[e]);
-        qsum[e] += qe[e][i];
-      }
-    }
-  }
-  __syncthreads();  // phase 1's normalised keys are in place
-  float a[2][4];
-#pragma unroll
-  for (int e = 0; e < 2; ++e)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[e][j] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float kk = q3[pswz(kr + (i ^ odd), 16 * j + sm)];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) a[e][j] = fmaf(kk, qe[e][i], a[e][j]);
-    }
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(half_sum(row_pair_sum(qsum[e])));  // dim_head ** -0.5 / sum
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[e][j] = half_sum(row_pair_sum(a[e][j])) * sc;
-  }
-  // The output is only ever the B operand of to_out: it leaves as split-bf16 planes (over the q rows and the first
-  // key rows, the H-plane region: dead once every wave is past its reads), not as f32 rows.  A lane's 8 channels are one
-  // 8-group of the fragment layout (32-channel block = head, g = part), in the order i ^ odd.
-  float ov[2][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int e = 0; e < 2; ++e) ov[e][i] = vv[i][0] * a[e][0] + vv[i][1] * a[e][1] + vv[i][2] * a[e][2] + vv[i][3] * a[e][3];
-  __syncthreads();  // all reads of q, k, v are done
-  lds_u4 *op = (lds_u4 *)(c.lds + kPlaneH) + ((head * 3) * 4 + pt) * 64;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    float oj[8];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      oj[2 * m] = odd ? ov[e][2 * m + 1] : ov[e][2 * m];
-      oj[2 * m + 1] = odd ? ov[e][2 * m] : ov[e][2 * m + 1];
-    }
-    u32x4 pl[3];
-    split_bf16x3(oj, pl);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) op[k * 256 + n0 + 16 * e] = pl[k];
+    for (int r = 0; r < 4; ++r)
+      o[r] = acc[2][0][r] * A[0][n] + acc[2][1][r] * A[1][n] + acc[2][2][r] * A[2][n] + acc[2][3][r] * A[3][n];
+    store_planes4(c.lds + kPlaneH, kDimHead * head + 16 * half + 4 * kq, 16 * n + sm, o[0], o[1], o[2], o[3]);
   }
   __syncthreads();
 }
@@ -2211,7 +2168,7 @@ struct RunArgs {
 // down conv).  It is written once per workgroup into LDS (12 ints per op) and interpreted by a switch
 // inside the step loop, so every phase body exists once, inlined, with registers allocated across the
 // whole kernel: no calls, no callee-save traffic and no spilled kernel state between phases.
-enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKV4 = 5, OP_OUTLN = 6, OP_QKVLN = 7 };
+enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_OUTLN = 6, OP_QKVATT = 7 };
 // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9 | (scale/shift table offset / 4) << 12
 constexpr int kFlagAlias = 1 << 8;
 constexpr int kFlagFused = 1 << 11;   // position-major engine: this conv and the next tape entry are one ResnetBlock op
@@ -2367,14 +2324,10 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
       const gldm_r1d_level &v = d.lv[lv];
       // position-major engine (C <= 128 at attention levels): X rows [0, 128) | q,k,v of the four heads: 384 rows, o in
       // place of q.  The PreNorm LayerNorm is folded into the qkv conv (C = 4: computed in the lanes of the qkv phase).
-      constexpr int QKV4H = 128 * NC;
-      static_assert(NC != 64 || QKV4H + 3 * kHidden * NC <= GG::kArena, "four-head attention layout");
       int Oa = O;
-      if (NC == 64) {
-        if (C == 4) emit(OP_QKV4, v.qkvn_w, X, QKV4H);
-        else emit(OP_QKVLN, v.qkvn_w3, v.qkvn_s, X, QKV4H, C);
-        emit(OP_ATT, QKV4H);
-        Oa = QKV4H;
+      if (NC == 64) {   // PreNorm + to_qkv + attention core of the four heads: one op, the output as planes (kPlaneH)
+        emit(OP_QKVATT, C == 4 ? v.qkvn_w : v.qkvn_w3, v.qkvn_s, X, C);
+        Oa = kPlaneH;
       } else {
         emit(OP_LN, X, Y, -1, C, v.ln_g);
         emit(OP_CONV, v.qkv_w[0], -1, Y, QKV, C, 192, 1);
@@ -2449,11 +2402,13 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
         }
         if (o[11]) __syncthreads();
         break;
-      case OP_QKV4:
-        if constexpr (NC == 64) qkv4_pm(c, o[1], c.lds + o[2], c.lds + o[3]);
-        break;
-      case OP_QKVLN:
-        if constexpr (NC == 64) qkv_ln_pm(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4]);
+      case OP_QKVATT:
+        if constexpr (NC == 64) {
+          if (o[4] == 128) qkv_att_pm<4>(c, o[1], o[2], c.lds + o[3], o[4]);
+          else if (o[4] == 64) qkv_att_pm<2>(c, o[1], o[2], c.lds + o[3], o[4]);
+          else if (o[4] == 32) qkv_att_pm<1>(c, o[1], o[2], c.lds + o[3], o[4]);
+          else qkv_att_pm<0>(c, o[1], o[2], c.lds + o[3], o[4]);
+        }
         break;
       case OP_OUTLN:
         if constexpr (NC == 64) out_ln_pm(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4], o[6], o[7]);
@@ -2463,8 +2418,7 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
                             o[4], o[5]);
         break;
       default:
-        if constexpr (NC == 64) attention_quad_pm(c, c.lds + o[1]);
-        else attention_pair<NC, L>(c, c.lds + o[1], c.lds + o[2]);
+        if constexpr (NC != 64) attention_pair<NC, L>(c, c.lds + o[1], c.lds + o[2]);
         break;
     }
   }
@@ -3020,7 +2974,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
                     : (L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s));
   if (stamp) {
     static long long host[kMaxOps + 2];
-    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "QKV4", "OUTLN", "QKVLN"};
+    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "", "OUTLN", "QKVAT"};
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(host, dstamps, sizeof(host), hipMemcpyDeviceToHost);
     // the tape is rebuilt on the host only to label the stamps
@@ -3038,7 +2992,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
     for (int lv = 0; lv < a.d.n_levels; ++lv) {
       const int C = dims[lv];
       resblock(C); resblock(C);
-      if (pm) { line(C == 4 ? 5 : 7, C, 384, 1); line(4, C, 128, 0); }
+      if (pm) line(7, C, 384, 1);
       else { line(3, C, C, 0); line(1, C, 192, 1); line(4, C, 64, 0); line(1, C, 192, 1); line(4, C, 64, 0); }
       if (pm && (C == 4 || C == 32 || C == 64 || C == 128)) line(6, 128, C, 1);
       else { line(1, 128, C, 1); line(3, C, C, 0); }
