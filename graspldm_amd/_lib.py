@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # GLDM_LIB: another build of the same library (diagnostic builds: make -C graspldm_amd/csrc EXTRA=... OUT=...)
 LIB_PATH = os.environ.get("GLDM_LIB") or os.path.join(_PKG, "libgldm_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class GldmError(RuntimeError):
@@ -94,6 +94,8 @@ def lib():
         fn.restype = _i
     h.gldm_r1d_workspace_bytes.argtypes = [_vp, _i]
     h.gldm_r1d_workspace_bytes.restype = ctypes.c_longlong
+    h.gldm_r1d_tile_columns.argtypes = [_vp]
+    h.gldm_r1d_tile_columns.restype = _i
     h.gldm_conv3d_partial_floats.argtypes = [_i, _i, _i]
     h.gldm_conv3d_partial_floats.restype = ctypes.c_longlong
     _lib = h

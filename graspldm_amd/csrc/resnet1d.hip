@@ -1012,6 +1012,7 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
 #undef GLDM_LOAD_GN_PARAMS
 
 constexpr int kOpInts = 12, kMaxOps = 84;  // op tape: 84 * 12 = 1008 ints; the op count lives in int 1023
+constexpr int kPmMaxOps = 7 * GLDM_R1D_MAX_LEVELS + 2;   // position-major engine: 7 entries per level + the last ResnetBlock's 2
 
 // =========================================================================================================
 // Position-major engine pieces (L = 4, 64-column tiles = 16 samples x 4 positions, column = 16 * pos + sample,
@@ -2161,6 +2162,11 @@ struct RunArgs {
   int slots, rounds, left_tiles, chain, seglen;
   int stagger_ticks, n_cus;  // start offset (100 MHz ticks) of the second workgroup of a CU
   long long *stamps;         // diagnostic (GLDM_R1D_STAMP): cycle counter at every op of the last step, block 0
+  // Position-major engine: the step program, built on the host (launch_r1d), travels in the kernel arguments: an op's
+  // 12 ints are three scalar loads from the kernarg segment, straight into SGPRs.  (From the LDS copy the interpreter
+  // paid three ds_read_b128, their latency and 12 v_readfirstlane per op -- ~0.7 k cycles on every wave, 28 ops a step.)
+  int pm_nops;
+  int pm_tape[kPmMaxOps * kOpInts];
 };
 
 // One denoiser / decoder step is a fixed program of barrier-separated ops (45 for the shipped
@@ -2290,7 +2296,7 @@ __host__ __device__ __forceinline__ bool gn_fusable(int C, int groups) {
 }
 
 template <int NC>
-__device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
+__host__ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
   using GG = Geo<NC>;
   int n = 0;
   auto emit = [&](int type, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0, int a6 = 0, int a7 = 0,
@@ -2350,8 +2356,35 @@ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
   return n;
 }
 
+// One tape entry -> 12 wave-uniform ints.  LDS tape (sample-major engines): three 16-byte reads + v_readfirstlane;
+// kernarg tape (position-major engine): scalar loads from the constant address space, no vector instruction at all.
+typedef __attribute__((address_space(4))) const int kernarg_int;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+template <bool KARG>
+__device__ __forceinline__ void read_op(const int *tape, kernarg_int *ktape, int op, int (&o)[kOpInts]) {
+  if constexpr (KARG) {
+    typedef __attribute__((address_space(4))) const i32x4 kernarg_i4;
+    kernarg_i4 *t4 = reinterpret_cast<kernarg_i4 *>(ktape + kOpInts * op);
+    const i32x4 q0 = t4[0], q1 = t4[1], q2 = t4[2];
+    o[0] = q0.x; o[1] = q0.y; o[2] = q0.z; o[3] = q0.w; o[4] = q1.x; o[5] = q1.y; o[6] = q1.z; o[7] = q1.w;
+    o[8] = q2.x; o[9] = q2.y; o[10] = q2.z; o[11] = q2.w;
+  } else {
+    const int4 *t4 = reinterpret_cast<const int4 *>(tape + kOpInts * op);
+    const int4 q0 = t4[0], q1 = t4[1], q2 = t4[2];
+    o[0] = q0.x; o[1] = q0.y; o[2] = q0.z; o[3] = q0.w; o[4] = q1.x; o[5] = q1.y; o[6] = q1.z; o[7] = q1.w;
+    o[8] = q2.x; o[9] = q2.y; o[10] = q2.z; o[11] = q2.w;
+#pragma unroll
+    for (int i = 0; i < kOpInts; ++i) o[i] = __builtin_amdgcn_readfirstlane(o[i]);
+  }
+}
+
 template <int NC, int L>
-__device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_ops, int E, long long *stamps) {
+__device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, kernarg_int *ktape, int n_ops, int E, long long *stamps) {
+#if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_EXP_LDS_TAPE)   // A/B experiment: the tape from LDS as before
+  constexpr bool KARG = false;
+#else
+  constexpr bool KARG = NC == 64;
+#endif
   for (int op = 0; op < n_ops; ++op) {
     if (stamps && c0.tid == 0) stamps[op] = (long long)__builtin_readcyclecounter();
     // the lane ids are laundered per op: otherwise every variant's lane-derived LDS offsets are
@@ -2359,14 +2392,7 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
     Ctx c = c0;
     asm volatile("" : "+v"(c.tid), "+v"(c.lane));
     int o[kOpInts];
-    {
-      const int4 *t4 = reinterpret_cast<const int4 *>(tape + kOpInts * op);
-      const int4 q0 = t4[0], q1 = t4[1], q2 = t4[2];
-      o[0] = q0.x; o[1] = q0.y; o[2] = q0.z; o[3] = q0.w; o[4] = q1.x; o[5] = q1.y; o[6] = q1.z; o[7] = q1.w;
-      o[8] = q2.x; o[9] = q2.y; o[10] = q2.z; o[11] = q2.w;
-#pragma unroll
-      for (int i = 0; i < kOpInts; ++i) o[i] = __builtin_amdgcn_readfirstlane(o[i]);
-    }
+    read_op<KARG>(tape, ktape, op, o);
     // the short latency-bound phases get issue priority over the co-resident workgroup's long MFMA
     // streams (which need one issue slot per 32 cycles and lose nothing)
     if (o[0] == OP_CONV && o[5] * o[6] >= 128 * 128) __builtin_amdgcn_s_setprio(0);
@@ -2376,12 +2402,7 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, int n_o
         if constexpr (NC == 64) {
           if (o[7] & kFlagFused) {   // ResnetBlock: this entry is conv1, the next one conv2 (same width, H -> X)
             int q[kOpInts];
-            const int4 *t4 = reinterpret_cast<const int4 *>(tape + kOpInts * (op + 1));
-            const int4 q0 = t4[0], q1 = t4[1], q2 = t4[2];
-            q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w; q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
-            q[8] = q2.x; q[9] = q2.y; q[10] = q2.z; q[11] = q2.w;
-#pragma unroll
-            for (int i = 0; i < kOpInts; ++i) q[i] = __builtin_amdgcn_readfirstlane(q[i]);
+            read_op<KARG>(tape, ktape, op + 1, q);
             const GnEpilogue g1{1, o[8], o[9], o[10], o[11], E, o[6], o[6] / 4, c.lds + o[4], (o[7] >> kFlagTabShift) << 2};
             const GnEpilogue g2{2, q[8], q[9], -1, 0, E, q[6], q[6] / 4, c.lds + q[4], 0};
             resblock_pm(c, o[1], o[2], q[1], q[2], c.lds + o[3], c.lds + o[4], o[6], g1, g2, stamps ? stamps + op + 1 : nullptr);
@@ -2496,7 +2517,11 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   unsigned long long *state = reinterpret_cast<unsigned long long *>(a.ws) + kChainHdrBytes / 8;
   const bool chained = a.left_tiles > 0 && a.chain > 1;
   if (c.tid == 0) {
+#if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_EXP_LDS_TAPE)
     tape[1023] = build_tape<NC>(d, tape);
+#else
+    tape[1023] = PM ? a.pm_nops : build_tape<NC>(d, tape);
+#endif
     // Slot = order of arrival, not blockIdx: a slot only ever waits for the slot before it, which has
     // then already started, so the hand-offs cannot deadlock whatever the dispatch order or residency.
     tape[1022] = chained ? (int)__hip_atomic_fetch_add(&hdr->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -2505,6 +2530,9 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   }
   __syncthreads();
   const int n_ops = __builtin_amdgcn_readfirstlane(tape[1023]);
+  // the kernel's one argument (RunArgs, by value) sits at offset 0 of the kernarg segment
+  kernarg_int *ktape = (kernarg_int *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() +
+                                       offsetof(RunArgs, pm_tape));
   const int slot = __builtin_amdgcn_readfirstlane(tape[1022]);
   const unsigned epoch = (unsigned)__builtin_amdgcn_readfirstlane(tape[1021]);
 #ifdef GLDM_DEBUG_KNOBS
@@ -2637,7 +2665,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     }
     __syncthreads();
 
-    run_tape<NC, L>(c, tape, n_ops, E, blockIdx.x == 0 ? GLDM_STAMPS(a.stamps) : nullptr);
+    run_tape<NC, L>(c, tape, ktape, n_ops, E, blockIdx.x == 0 ? GLDM_STAMPS(a.stamps) : nullptr);
     if (GLDM_STAMPS(a.stamps) && blockIdx.x == 0 && c.tid == 0) a.stamps[n_ops] = (long long)__builtin_readcyclecounter();
 
     // ---- final 1x1 conv to one channel: eps[n] = b + sum_c w[c] X[c][n]
@@ -2948,7 +2976,10 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   RunArgs a = a_in;
   a.slots = pl.slots; a.rounds = pl.rounds; a.left_tiles = pl.left; a.chain = pl.chain; a.seglen = pl.seglen;
   a.park = nullptr;
+  a.pm_nops = 0;
   if (pm) {
+    static_assert(7 * GLDM_R1D_MAX_LEVELS + 2 <= kPmMaxOps, "position-major tape");
+    a.pm_nops = build_tape<64>(a_in.d, a.pm_tape);
     const long long all_tiles = (a_in.n_samples + 16 - 1) / 16;
     long long off = kChainHdrBytes + all_tiles * 64 * 8;
     if (park_bytes(&a_in.d, all_tiles, &off) > 0) a.park = reinterpret_cast<float *>(reinterpret_cast<char *>(a_in.ws) + off);
@@ -3663,6 +3694,12 @@ GLDM_API long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_sam
   if (ss_table_rows(desc) > 0) bytes = ((bytes + 255) & ~255LL) + (long long)n_samples * ss_table_rows(desc) * 4;
   bytes += park_bytes(desc, tiles, &bytes);
   return bytes;
+}
+
+GLDM_API int gldm_r1d_tile_columns(const gldm_r1d_desc *desc) {
+  const int st = validate(desc);
+  if (st != GLDM_OK) return st;
+  return pm_supported(desc) ? 64 : engine_nc();
 }
 
 GLDM_API int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,

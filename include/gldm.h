@@ -234,6 +234,13 @@ int gldm_r1d_cond_embed(const float *z_cond /*[n_cond,R,Dc]*/, const float *w /*
 #define GLDM_R1D_WS_ERROR 12
 long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples);
 
+/* Which engine gldm_denoise / gldm_decode run this descriptor on: 64 = the position-major engine (64-column tiles = 16
+ * samples x 4 positions, GEMMs as split-bf16 products on the bf16 matrix pipe: 4-position latent denoisers packed with
+ * the ABI >= 5 fields), 32 = the sample-major engine (32-column tiles, f32 matrix pipe: the 16-position pose decoder and
+ * every other supported shape), or a negative GLDM_ERR_* status for a descriptor no engine takes.  No reference
+ * counterpart: reporting only (bench.py labels its roofline record with it). */
+int gldm_r1d_tile_columns(const gldm_r1d_desc *desc);
+
 /* ref: grasp_ldm/models/diffusion/gaussian_diffusion.py:232-277 (sample loop:
  * eps = model(x, t, z_cond); x = scheduler.step(eps, t, x)) and
  * resnets.py:558-616 (TimeConditionedResNet1D.forward), fused: ONE launch runs

@@ -45,6 +45,28 @@ def main():
     with open(os.path.join(ROOT, "tests", "golden", "encoder_flops.json"), "w") as f:
         json.dump(dict(points=1024, note="torch FlopCounterMode over the reference's modules (oracle/count_flops.py)",
                        models=out), f, indent=1)
+    # ---- the 1-D ResNets of both shipped experiments: one denoiser forward per latent, one decoder forward per grasp
+    from grasp_ldm.models.modules.resnets import ResNet1D, TimeConditionedResNet1D
+    r1d = {}
+    for tag, latent, pc_latent in (("fpc", 4, 64), ("ppc", 16, 256)):
+        rn = dict(block_channels=(32, 64, 128, 256), input_conditioning_dims=pc_latent, resnet_block_groups=4, dropout=0.1)
+        den = TimeConditionedResNet1D(dim=latent, channels=1, is_time_conditioned=True, learned_variance=False,
+                                      learned_sinusoidal_cond=False, random_fourier_features=True, **rn).eval()
+        xb = torch.randn(1, 1, latent, generator=g)
+        zc = torch.randn(1, 3, pc_latent, generator=g)
+        with FlopCounterMode(display=False) as fc:
+            den(xb, time=torch.tensor([500]), z_cond=zc)
+        r1d[f"denoiser({tag})"] = dict(flop_per_latent_step=int(fc.get_total_flops()), seq_len=latent, cond_dims=pc_latent)
+        dec = ResNet1D(dim=16, channels=1, **rn).eval()   # the pose decoder's trunk at feature resolution 16 (grasp_vae.py:401-436)
+        with FlopCounterMode(display=False) as fc:
+            dec(torch.randn(1, 1, 16, generator=g), z_cond=zc)
+        r1d[f"decoder_trunk({tag})"] = dict(flop_per_grasp=int(fc.get_total_flops()), seq_len=16, cond_dims=pc_latent)
+    for k, v in r1d.items():
+        print(k, v)
+    with open(os.path.join(ROOT, "tests", "golden", "r1d_flops.json"), "w") as f:
+        json.dump(dict(note="torch FlopCounterMode over the reference's TimeConditionedResNet1D / ResNet1D (oracle/count_flops.py); "
+                            "includes the conditioning Linear + time MLP of every call, which the HIP path hoists out of the step loop",
+                       models=r1d), f, indent=1)
 
 
 if __name__ == "__main__":
