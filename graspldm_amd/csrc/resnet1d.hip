@@ -126,7 +126,26 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 typedef __attribute__((address_space(3))) u32x4 lds_u4;
 typedef __attribute__((address_space(3))) u32x2_t lds_u2;
+// Geometry of the plane rows.  LL = 4 (position-major tiles of the 4-position denoiser): 64 columns per (block, plane, g)
+// row.  LL = 16 (the 16-position nets: pose decoder, ppc denoiser; column = 4 * position + sample, 4 samples per tile):
+// 72 entries per row, the 64 columns at entries 4 .. 67 between four ZERO entries on each side, so that the taps of a
+// k = 3 conv are the same reads shifted by one position = 4 entries (entry 4 t + column for tap t), with no masks.
+template <int LL>
+struct PG {
+  static constexpr int kCols = LL == 16 ? 72 : 64;   // 16-byte entries per row
+  static constexpr int kOff = LL == 16 ? 4 : 0;      // entry of column 0
+  static constexpr int kPlaneU4 = 4 * kCols;         // entries per plane of a 32-channel block
+  static constexpr int kBlockU4 = 3 * kPlaneU4;      // per block
+  static constexpr int kBlockFloats = 4 * kBlockU4;
+  static constexpr int kH = 128 * 64;                // H planes (floats), 4 blocks
+  static constexpr int kX = kH + 4 * kBlockFloats;   // X planes
+  static constexpr int kW = kH;                      // the 256-channel level's one set, 8 blocks
+  static constexpr int kEnd = kH + 8 * kBlockFloats;
+};
+static_assert(PG<4>::kH == kPlaneH && PG<4>::kX == kPlaneX, "plane regions");
+static_assert(PG<16>::kEnd <= Geo<64>::kArena, "padded planes fit the arena");
 // rows c0 .. c0 + 3 (c0 % 4 == 0) of column n -> the three planes
+template <int LL = 4>
 __device__ __forceinline__ void store_planes4(float *planes, int c0, int n, float v0, float v1, float v2, float v3) {
   const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){v0, v1}, __attribute__((ext_vector_type(2))) __bf16));
   const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){v2, v3}, __attribute__((ext_vector_type(2))) __bf16));
@@ -138,12 +157,13 @@ __device__ __forceinline__ void store_planes4(float *planes, int c0, int n, floa
   const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xffff0000u);
   const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){s0, s1}, __attribute__((ext_vector_type(2))) __bf16));
   const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){s2, s3}, __attribute__((ext_vector_type(2))) __bf16));
-  // dword address: (((kb * 3 + plane) * 4 + g) * 64 + n) * 4 + 2 * (half of the 8-group)
-  const int a = ((((c0 >> 5) * 3) * 4 + ((c0 >> 3) & 3)) * 64 + n) * 4 + ((c0 >> 2) & 1) * 2;
+  // dword address: (((kb * 3 + plane) * 4 + g) * kCols + kOff + n) * 4 + 2 * (half of the 8-group)
+  using G = PG<LL>;
+  const int a = ((((c0 >> 5) * 3) * 4 + ((c0 >> 3) & 3)) * G::kCols + G::kOff + n) * 4 + ((c0 >> 2) & 1) * 2;
   lds_u2 *d = (lds_u2 *)(planes + a);
   d[0] = u32x2_t{h0, h1};
-  d[512] = u32x2_t{m0, m1};    // next plane: 4 * 64 * 4 dwords = 1024 dwords = 512 u2
-  d[1024] = u32x2_t{l0, l1};
+  d[2 * G::kPlaneU4] = u32x2_t{m0, m1};    // next plane: kPlaneU4 entries of 16 bytes = 2 kPlaneU4 u2
+  d[4 * G::kPlaneU4] = u32x2_t{l0, l1};
 }
 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
@@ -201,6 +221,7 @@ struct Ctx {
   // scale / shift rows precomputed per conditioning cloud (pose decoder: ss_table_kernel), for the tile's samples 0 and
   // 1 (16-position engine: a 16-column n-tile is one sample), or null: computed in the epilogue
   const float *ss_row[2] = {nullptr, nullptr};
+  const float *ss_lane = nullptr;   // 16-position 64-column engine: the same rows for THIS LANE's sample (lane & 3), or null
   // position-major engine, 256-channel level: this workgroup's 64 KiB of global scratch where the residual stream is
   // parked (f32) between the level's down conv and the end of its ResnetBlock, while LDS holds the split planes
   float *park = nullptr;
@@ -630,14 +651,113 @@ __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restric
   }
 }
 
+// k = 3 conv of the 16-position engine (LL = 16: column = 4 * position + sample).  A tap is the same B read shifted by
+// one position = 4 entries of the zero-padded plane rows (PG<16>): no masks, and no (tap, position) product is padding
+// except at a sample's two end positions (46 of 48 are real).  Every (tap, tile) has its own B fragments, read from LDS
+// in front of the MFMAs they feed: one m-tile per wave -> the next tap step's set while the current one multiplies (two
+// register sets; the trip covers two channel blocks so that the alternation is static); two m-tiles (256 channels) -> tile
+// by tile, the next tile's planes under the current tile's 12 MFMAs.  A fragments exactly as in gemm_pm3_pl.
+// T0, NT: the wave's n-tiles (tile = 4 consecutive positions x 4 samples).  Cin = 16 runs as one 32-channel block whose
+// upper half has zero weights (r1d_pack.pad_cin32).
+template <int MT, int T0, int NT, class PRE = NoPreA>
+__device__ __forceinline__ void gemm_sm3_pl(const Ctx &c, const float *__restrict__ wp3, int cin, int mt0,
+                                            const float *planes, f32x4 (&acc)[MT][NT], const PRE &pre = PRE()) {
+  using G = PG<16>;
+  const int col = c.lane & 15, g = c.lane >> 4;
+  const int kb32 = (cin + 31) >> 5, kblocks = 3 * kb32;
+  const WStream wv(wp3, c.lane);
+  const lds_u4 *pl3 = (const lds_u4 *)planes + g * G::kCols + 16 * T0 + col;   // + (kb * 3 + plane) * kPlaneU4 + 16 q + 4 t
+  constexpr int NA = MT == 1 ? 3 : 2;
+  u32x4 a[NA][MT][3];
+  auto load_a = [&](int buf, int t, int kb) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kblocks + t * kb32 + kb) * 3072, pl * 1024);
+  };
+  auto first_a = [&]() {   // block 0's fragments (three tap sets, or tap 0's with two m-tiles): the caller's, or requested here
+#pragma unroll
+    for (int t = 0; t < (MT == 1 ? 3 : 1); ++t) {
+      if constexpr (PRE::on) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) a[t][mi][pl] = pre.a[t][mi][pl];
+      } else {
+        load_a(t, t, 0);
+      }
+    }
+  };
+  const int last = kb32 - 1;
+  if constexpr (MT == 1) {
+    u32x4 bs[2][NT][3];
+    auto load_b = [&](int buf, int kb, int t) {
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bs[buf][q][pl] = pl3[(kb * 3 + pl) * G::kPlaneU4 + 16 * q + 4 * t];
+    };
+    load_b(0, 0, 0);
+    first_a();
+    // st: tap step inside a trip of two blocks (0..5); B set st & 1, A set = tap
+    auto step = [&](int st, int kb0) {
+      const int t = st % 3, kb = kb0 + st / 3;
+      const int nt = (st + 1) % 3, nkb = kb0 + (st + 1) / 3;
+      load_b((st + 1) & 1, nkb < last ? nkb : last, nt);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < NT; ++q) acc[0][q] = mfma_split6(a[t][0], bs[st & 1][q], acc[0][q]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(t, t, kb < last ? kb + 1 : last);
+    };
+    if (kb32 == 1) {
+      step(0, 0); step(1, 0); step(2, 0);
+    } else {
+      for (int kb0 = 0; kb0 < kb32; kb0 += 2) {
+#pragma unroll
+        for (int st = 0; st < 6; ++st) step(st, kb0);
+      }
+    }
+  } else {
+    static_assert(MT == 1 || NT == 4, "two m-tiles per wave: all four tiles");
+    u32x4 bs[2][3];
+    auto load_b1 = [&](int buf, int kb, int t, int q) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bs[buf][pl] = pl3[(kb * 3 + pl) * G::kPlaneU4 + 16 * q + 4 * t];
+    };
+    first_a();
+    load_b1(0, 0, 0, 0);
+    auto step = [&](int st, int kb0) {
+      const int t = st % 3, kb = kb0 + st / 3;
+      const int nt = (st + 1) % 3, nkb0 = kb0 + (st + 1) / 3, nkb = nkb0 < last ? nkb0 : last;
+      load_a((st + 1) & 1, nt, nkb);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) load_b1((q + 1) & 1, kb, t, q + 1);
+        else load_b1(0, nkb, nt, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) acc[mi][q] = mfma_split6(a[st & 1][mi], bs[q & 1], acc[mi][q]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    for (int kb0 = 0; kb0 < kb32; kb0 += 2) {   // 4 or 8 blocks here
+#pragma unroll
+      for (int st = 0; st < 6; ++st) step(st, kb0);
+    }
+  }
+}
+
 // 1x1 conv with the B operand from pre-split planes (the folded-LayerNorm qkv conv reads the X planes).
 // MS: stride between the wave's m-tiles (the fused qkv + attention phase takes a head's q, k and v rows: 8 m-tiles apart).
-template <int KB32, int MT, int NT, class PRE = NoPre, int MS = 1>
+template <int KB32, int MT, int NT, class PRE = NoPre, int MS = 1, int LL = 4>
 __device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__ wp3, int mt0, int nt0, const float *planes,
                                          f32x4 (&acc)[MT][NT], const PRE &pre = PRE()) {
   const int col = c.lane & 15, g = c.lane >> 4;
   const WStream wv(wp3, c.lane);
-  const lds_u4 *pl3 = (const lds_u4 *)planes + g * 64 + 16 * nt0 + col;
+  using PGx = PG<LL>;
+  const lds_u4 *pl3 = (const lds_u4 *)planes + g * PGx::kCols + PGx::kOff + 16 * nt0 + col;
   u32x4 a[2][MT][3];
   u32x4 bs[2][3];
   auto load_a = [&](int buf, int kb) {
@@ -650,7 +770,7 @@ __device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__
   };
   auto load_b = [&](int buf, int kb, int ni) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) bs[buf][pl] = pl3[(kb * 3 + pl) * 256 + 16 * ni];
+    for (int pl = 0; pl < 3; ++pl) bs[buf][pl] = pl3[(kb * 3 + pl) * PGx::kPlaneU4 + 16 * ni];
   };
   load_a(0, 0);
   load_b(0, 0, 0);
@@ -1012,7 +1132,7 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
 #undef GLDM_LOAD_GN_PARAMS
 
 constexpr int kOpInts = 12, kMaxOps = 84;  // op tape: 84 * 12 = 1008 ints; the op count lives in int 1023
-constexpr int kPmMaxOps = 7 * GLDM_R1D_MAX_LEVELS + 2;   // position-major engine: 7 entries per level + the last ResnetBlock's 2
+constexpr int kPmMaxOps = 8 * GLDM_R1D_MAX_LEVELS + 2;   // 64-column engines: at most 8 entries per level + the last ResnetBlock's 2
 
 // =========================================================================================================
 // Position-major engine pieces (L = 4, 64-column tiles = 16 samples x 4 positions, column = 16 * pos + sample,
@@ -1033,14 +1153,22 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // FIN: which epilogues this instance carries (code size: the kernel's straight-line phases must stay inside the instruction
 // cache): 0 = none (the level's down conv, mode 0), 1 = block1 (H = act(GN(conv)), scale/shift at run time), 2 = block2
 // (X += act(GN(conv)), no scale/shift).  Modes 1 and 2 only ever run inside the fused ResnetBlock op.
-template <int MT, int P0, int NP, int GK, int FIN = 0, class PRE = NoPreA, class HOOK = NoHook>
+// LL: 4 = position-major tiles of the 4-position denoiser (P0 / NP: positions); 16 = the 16-position engine (P0 / NP: the
+// wave's n-tiles of 4 positions x 4 samples; sample = lane & 3; GK 3: C = 16, one m-tile whose four row quarters are the
+// four groups, waves 0-3 one tile each -- waves 4-7 repeat their work with `live` false so that every wave meets the
+// barriers).  The statistics of a sample then also sum over the four positions inside a tile (DPP row rotations).
+template <int MT, int P0, int NP, int GK, int FIN = 0, class PRE = NoPreA, class HOOK = NoHook, int LL = 4>
 __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, const float *bias, int mt0,
                                               const float *src, int cin, float *dst, int cout, bool alias,
-                                              const GnEpilogue &g, const PRE &pre = PRE(), const HOOK &hook = HOOK()) {
+                                              const GnEpilogue &g, const PRE &pre = PRE(), const HOOK &hook = HOOK(),
+                                              bool live = true) {
   using GG = Geo<64>;
-  const int kq = c.lane >> 4, sm = c.lane & 15;
+  using PGx = PG<LL>;
+  const int kq = c.lane >> 4, cl = c.lane & 15;
+  const int sm = LL == 16 ? (c.lane & 3) : cl;   // the lane's sample
   f32x4 acc[MT][NP];
   const bool has_ss = FIN == 1 && g.ss_w >= 0;
+  const bool ss_tab = LL == 16 && has_ss && c.ss_lane != nullptr;   // rows precomputed per cloud (pose decoder)
   const int ekb = g.E >> 4;
   const WStream wss(c.w + (has_ss ? g.ss_w : 0), c.lane);
   f32x4 ga[MT], be[MT], sc[MT], sh[MT], a_sc[MT], a_sh[MT];
@@ -1054,7 +1182,10 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
       be[mi] = *reinterpret_cast<const f32x4 *>(c.w + g.beta_off + row0);
       sc[mi] = f32x4{1.f, 1.f, 1.f, 1.f};
       sh[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (has_ss) {
+      if (ss_tab) {
+        sc[mi] = *reinterpret_cast<const f32x4 *>(c.ss_lane + g.tab_off + row0);
+        sh[mi] = *reinterpret_cast<const f32x4 *>(c.ss_lane + g.tab_off + g.C + row0);
+      } else if (has_ss) {
         const float *sb = c.w + g.ss_b;
         sc[mi] = *reinterpret_cast<const f32x4 *>(sb + row0);
         sh[mi] = *reinterpret_cast<const f32x4 *>(sb + g.C + row0);
@@ -1071,12 +1202,13 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
     for (int p = 0; p < NP; ++p) acc[mi][p] = bv;
   }
   // B operand: pre-split planes.  Up to 128 input channels: the X planes or the H planes, by which buffer `src` is; 256
-  // (the last level's ResnetBlock): the level's one plane set (kPlaneW)
+  // (the last level's ResnetBlock): the level's one plane set (kW)
   GLDM_WV_STAMP(c, 0, (long long)__builtin_readcyclecounter());
   GLDM_WV_STAMP(c, 3, (long long)(cin * 1000 + cout));
   const bool src_is_x = src == c.lds + GG::kBufX;
-  const float *bplanes = c.lds + (cin > kPlaneMaxC ? kPlaneW : (src_is_x ? kPlaneX : kPlaneH));
-  gemm_pm3_pl<MT, P0, NP, PRE>(c, wp, cin, mt0, bplanes, acc, pre);
+  const float *bplanes = c.lds + (cin > kPlaneMaxC ? PGx::kW : (src_is_x ? PGx::kX : PGx::kH));
+  if constexpr (LL == 16) gemm_sm3_pl<MT, P0, NP, PRE>(c, wp, cin, mt0, bplanes, acc, pre);
+  else gemm_pm3_pl<MT, P0, NP, PRE>(c, wp, cin, mt0, bplanes, acc, pre);
   GLDM_WV_STAMP(c, 1, (long long)__builtin_readcyclecounter());
   if (FIN != 0) load_params();
   // 256-channel level (two m-tiles per wave): this lane's slice of the parked residual stream, one f32x4 per (m-tile, position)
@@ -1093,28 +1225,40 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
   if constexpr (FIN == 0) {  // the level's down conv: the new residual stream X as planes, and as f32 rows (up to 128
                              // channels: in LDS) or parked in global scratch (256: see kPlaneW)
     if (alias) __syncthreads();
-    lds_f *d3 = (lds_f *)dst;
+    if (live) {
+      lds_f *d3 = (lds_f *)dst;
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+      for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        if constexpr (kWide) {
-          pk[(mi * NP + p) * 64] = acc[mi][p];
-        } else {
+        for (int p = 0; p < NP; ++p) {
+          if constexpr (kWide) {
+            pk[(mi * NP + p) * 64] = acc[mi][p];
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) d3[pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm)] = acc[mi][p][r];
+            for (int r = 0; r < 4; ++r) d3[pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + cl)] = acc[mi][p][r];
+          }
+          store_planes4<LL>(c.lds + (kWide ? PGx::kW : PGx::kX), 16 * (mt0 + mi) + 4 * kq, 16 * (P0 + p) + cl, acc[mi][p][0],
+                            acc[mi][p][1], acc[mi][p][2], acc[mi][p][3]);
         }
-        store_planes4(c.lds + (kWide ? kPlaneW : kPlaneX), 16 * (mt0 + mi) + 4 * kq, 16 * (P0 + p) + sm, acc[mi][p][0],
-                      acc[mi][p][1], acc[mi][p][2], acc[mi][p][3]);
-      }
+    }
     GLDM_WV_STAMP(c, 2, (long long)__builtin_readcyclecounter());
     GLDM_WV_NEXT(c);
     return;
   }
   if constexpr (FIN != 0) {
-  // ---- this wave's share of the statistics, per sample (= lane & 15)
-  constexpr int kNloc = GK == 2 ? 8 * NP : 16 * MT * NP;  // values behind one published pair
-  constexpr int kParts = GK == 2 ? 4 : 2;
+  // ---- this wave's share of the statistics, per sample
+  constexpr int kRows = GK == 3 ? 4 : (GK == 2 ? 8 : 16 * MT);   // rows behind one published pair
+  constexpr int kNloc = kRows * NP * (LL == 16 ? 4 : 1);         // values behind it
+  constexpr int kParts = (GK == 2 || GK == 3) ? 4 : 2;
+  auto over_sample = [&](float v) {   // the lanes that hold this sample's other positions / row quarters of the group
+    if constexpr (LL == 16) {
+      v += dpp_mov<0x124>(v);   // row_ror:4
+      v += dpp_mov<0x128>(v);   // row_ror:8: the four positions inside the tile
+    }
+    if constexpr (GK != 3) v = row_pair_sum(v);
+    if constexpr (GK == 0 || GK == 1) v = half_sum(v);
+    return v;
+  };
   float s1 = 0.f;
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi)
@@ -1122,8 +1266,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
     for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int r = 0; r < 4; ++r) s1 += acc[mi][p][r];
-  s1 = row_pair_sum(s1);
-  if (GK != 2) s1 = half_sum(s1);
+  s1 = over_sample(s1);
   const float mloc = s1 * (1.0f / (float)kNloc);
   float s2 = 0.f;
 #pragma unroll
@@ -1135,17 +1278,17 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
         const float dx = acc[mi][p][r] - mloc;
         s2 += dx * dx;
       }
-  s2 = row_pair_sum(s2);
-  if (GK != 2) s2 = half_sum(s2);
+  s2 = over_sample(s2);
   lds_f *red1 = (lds_f *)(c.lds + GG::kMiscRed1), *red2 = (lds_f *)(c.lds + GG::kMiscRed2);
-  const int slot = GK == 2 ? (kq >> 1) : 0;
-  if ((kq & (GK == 2 ? 1 : 3)) == 0) {
-    red1[(c.wave * 2 + slot) * 16 + sm] = s1;
-    red2[(c.wave * 2 + slot) * 16 + sm] = s2;
+  const int slot = GK == 3 ? kq : (GK == 2 ? (kq >> 1) : 0);
+  const bool pub = (GK == 3 || (kq & (GK == 2 ? 1 : 3)) == 0) && (LL != 16 || (cl >> 2) == 0);
+  if (pub && live) {
+    red1[(c.wave * 4 + slot) * 16 + sm] = s1;
+    red2[(c.wave * 4 + slot) * 16 + sm] = s2;
   }
   // ---- scale / shift rows of this lane's sample (the same for all positions: once per m-tile).  They do not depend
   // on the statistics, so they are issued in front of the exchange barrier: the MFMA chain runs while the wave waits
-  if (has_ss) {
+  if (has_ss && !ss_tab) {
     const lds_f *Gs = (const lds_f *)(c.lds + GG::kMiscG) + sm * g.E;
     float gb[4];
 #pragma unroll
@@ -1173,9 +1316,11 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
   float tot = 0.f, ps1[kParts], ps2[kParts];
 #pragma unroll
   for (int q = 0; q < kParts; ++q) {
-    const int pw = GK == 0 ? ((c.wave & ~1) + q) : (GK == 1 ? ((c.wave & 3) + 4 * q) : ((c.wave & 1) + 2 * q));
-    ps1[q] = red1[(pw * 2 + slot) * 16 + sm];
-    ps2[q] = red2[(pw * 2 + slot) * 16 + sm];
+    // partners: GK 0 the adjacent wave; GK 1 wave ^ 4 (the other half of the positions / tiles); GK 2 the four waves of the
+    // m-tile (one per position / tile); GK 3 waves 0-3 (one tile each)
+    const int pw = GK == 0 ? ((c.wave & ~1) + q) : (GK == 1 ? ((c.wave & 3) + 4 * q) : (GK == 2 ? ((c.wave & 1) + 2 * q) : q));
+    ps1[q] = red1[(pw * 4 + slot) * 16 + sm];
+    ps2[q] = red2[(pw * 4 + slot) * 16 + sm];
     tot += ps1[q];
   }
   const float mean = tot * (1.0f / (float)(kNloc * kParts));
@@ -1206,7 +1351,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
           float t = (acc[mi][p][r] - mean) * (rstd * ga[mi][r]) + be[mi][r];
           if (kSS) t = t * sc[mi][r] + sh[mi][r];
           t = silu(t);
-          const int a = pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + sm);
+          const int a = pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + cl);
           if constexpr (kMode == 2) {
             if constexpr (kWide) t = parked[mi][p][r] + t;
             else t = d3[a] + t;
@@ -1215,16 +1360,18 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
           y[r] = t;
         }
         if constexpr (!(kMode == 2 && kWide))
-          store_planes4(c.lds + (kMode == 2 ? kPlaneX : (kWide ? kPlaneW : kPlaneH)), 16 * (mt0 + mi) + 4 * kq,
-                        16 * (P0 + p) + sm, y[0], y[1], y[2], y[3]);
+          store_planes4<LL>(c.lds + (kMode == 2 ? PGx::kX : (kWide ? PGx::kW : PGx::kH)), 16 * (mt0 + mi) + 4 * kq,
+                            16 * (P0 + p) + cl, y[0], y[1], y[2], y[3]);
       }
   };
   using std::integral_constant;
-  if constexpr (FIN == 2) {
-    finish(integral_constant<int, 2>{}, integral_constant<bool, false>{});
-  } else {
-    if (has_ss) finish(integral_constant<int, 1>{}, integral_constant<bool, true>{});
-    else finish(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+  if (live) {
+    if constexpr (FIN == 2) {
+      finish(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+    } else {
+      if (has_ss) finish(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+      else finish(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+    }
   }
   }
   GLDM_WV_STAMP(c, 2, (long long)__builtin_readcyclecounter());
@@ -1442,7 +1589,7 @@ __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInt
 // accumulators.  Replaces a conv phase that stored y plus a LayerNorm phase that read it back (3 barriers).
 // NPW = partner waves of the LayerNorm merge, FULL = every row of the m-tile is a channel (C >= 16): compile-time, so that
 // the per-value code has no wave-uniform branches (each value used to be its own chain of basic blocks)
-template <int NT, int NPW, bool FULL>
+template <int NT, int NPW, bool FULL, int LL = 4>
 __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const float *bias, int mt0, int nt0,
                                             bool active, int p0, const float *src, int cin, float *xres, int C,
                                             const float *gain) {
@@ -1458,7 +1605,7 @@ __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + row0);
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) acc[0][ni] = bv;
-    gemm1_pl<kHidden / 32, 1, NT>(c, wp, mt0, nt0, c.lds + kPlaneH, acc);  // the attention output's planes (cin = 128)
+    gemm1_pl<kHidden / 32, 1, NT, NoPre, 1, LL>(c, wp, mt0, nt0, c.lds + PG<LL>::kH, acc);  // the attention output's planes (cin = 128)
     gv = *reinterpret_cast<const f32x4 *>(gain + row0);
     const float inv_n = __builtin_amdgcn_rcpf((float)nloc);
 #pragma unroll
@@ -1511,20 +1658,22 @@ __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const
           xn[r] = x3[a] + (acc[0][ni][r] - mean) * rstd * gv[r];
           x3[a] = xn[r];
         }
-      if (FULL && C >= 32) store_planes4(c.lds + kPlaneX, row0, cc, xn[0], xn[1], xn[2], xn[3]);  // the new X's planes
+      if (FULL && C >= 16) store_planes4<LL>(c.lds + PG<LL>::kX, row0, cc, xn[0], xn[1], xn[2], xn[3]);  // the new X's planes
     }
   }
   __syncthreads();
 }
 
+template <int LL = 4>
 __device__ __forceinline__ void out_ln_pm(const Ctx &c, int w_off, int b_off, const float *src, int cin, float *xres,
                                           int C, int g_off) {
   const float *wp = c.w + w_off, *bias = c.w + b_off, *gain = c.w + g_off;
   const int mtiles = (C + 15) >> 4, w = c.wave;
-  if (mtiles == 8) out_ln_wave<4, 8, true>(c, wp, bias, w, 0, true, 0, src, cin, xres, C, gain);
-  else if (mtiles == 4) out_ln_wave<2, 4, true>(c, wp, bias, w & 3, 2 * (w >> 2), true, 4 * (w >> 2), src, cin, xres, C, gain);
-  else if (mtiles == 2) out_ln_wave<1, 2, true>(c, wp, bias, w & 1, w >> 1, true, 2 * (w >> 1), src, cin, xres, C, gain);
-  else out_ln_wave<1, 1, false>(c, wp, bias, 0, w & 3, w < 4, w & 3, src, cin, xres, C, gain);
+  if (mtiles == 8) out_ln_wave<4, 8, true, LL>(c, wp, bias, w, 0, true, 0, src, cin, xres, C, gain);
+  else if (mtiles == 4) out_ln_wave<2, 4, true, LL>(c, wp, bias, w & 3, 2 * (w >> 2), true, 4 * (w >> 2), src, cin, xres, C, gain);
+  else if (mtiles == 2) out_ln_wave<1, 2, true, LL>(c, wp, bias, w & 1, w >> 1, true, 2 * (w >> 1), src, cin, xres, C, gain);
+  else if (LL == 16) out_ln_wave<1, 1, true, LL>(c, wp, bias, 0, w & 3, w < 4, w & 3, src, cin, xres, C, gain);   // C = 16
+  else out_ln_wave<1, 1, false, LL>(c, wp, bias, 0, w & 3, w < 4, w & 3, src, cin, xres, C, gain);
 }
 
 // Rows of the per-column LayerNorm statistics the fused qkv + attention phase needs (see qkv_att_pm): wave w owns columns
@@ -1722,38 +1871,200 @@ __device__ __forceinline__ void qkv_att_pm(const Ctx &c, int w_off, int s_off, c
 }
 
 
+// ---- attention block of the 16-position 64-column engine (LL = 16: column = 4 * position + sample) ---------------------
+// PreNorm LayerNorm folded into the to_qkv conv exactly as in qkv_att_pm; a sample's 16 x 16 attention matrix does not
+// fit the lanes, so q | k | v go to LDS as a [384][64] f32 block (over both plane regions: the conv's plane reads end at
+// the barrier in front of the stores) and attention16_pm works from there.  Wave w takes rows 48 w .. 48 w + 47.
+template <int KB32>   // ceil(C / 32): a 16-channel level is one zero-padded block
+__device__ __forceinline__ void qkv_ln16_pm(const Ctx &c, int w_off, int s_off, const float *src, int C, float *dst) {
+  constexpr int NC = 64, MT = 3, NT = 4;
+  using GG = Geo<NC>;
+  const float *wp = c.w + w_off, *srow = c.w + s_off;
+  const int mt0 = 3 * c.wave;
+  const int col = c.lane & 15, kq = c.lane >> 4;
+  f32x4 sv[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) sv[mi] = *reinterpret_cast<const f32x4 *>(srow + 16 * (mt0 + mi) + 4 * kq);
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float inv_c = __builtin_amdgcn_rcpf((float)C);  // C: a power of two -> exact
+  if (C == 16) {
+    auto stats = [&]() { column_stats8<2>(c, src, inv_c); };
+    gemm1_pl<1, MT, NT, decltype(stats), 1, 16>(c, wp, mt0, 0, c.lds + PG<16>::kX, acc, stats);
+  } else {
+    auto stats = [&]() { column_stats8<4 * KB32>(c, src, inv_c); };
+    gemm1_pl<KB32, MT, NT, decltype(stats), 1, 16>(c, wp, mt0, 0, c.lds + PG<16>::kX, acc, stats);
+  }
+  __syncthreads();  // every column's (mean, rstd) is in LDS, every wave is past its plane reads
+  const lds_f *mean3 = (const lds_f *)(c.lds + GG::kMiscRed1), *rstd3 = (const lds_f *)(c.lds + GG::kMiscRed2);
+  lds_f *d3 = (lds_f *)dst;
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const float rstd = rstd3[16 * ni + col];
+    const float mr = mean3[16 * ni + col] * rstd;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int row0 = 16 * (mt0 + mi) + 4 * kq, cf = 16 * ni + col;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d3[pswz(row0 + r, cf)] = acc[mi][ni][r] * rstd - mr * sv[mi][r];
+    }
+  }
+  __syncthreads();
+}
+
+// LinearAttention core (resnets.py:223-235) at n = 16 positions, four heads, four samples per tile.  Both softmaxes are
+// normalised in place first -- keys over a sample's 16 positions (four lanes per (row, sample), one per tile; the lanes of
+// a wave walk the tile's four positions in rotated order so that its four rows hit different banks), queries over the 32
+// channels of their head, scaled by dim_head^-0.5 (four lanes per (head, column)) -- then a wave takes two (head,
+// sample) pairs: A = Kn^T Qn (16 x 16, K = 32) and out = V A (32 x 16, K = 16) as 16 f32 MFMAs each, A's accumulator
+// registers being the B operand of the second product as they stand (k-step r = key positions {4 kq + r}).  The output
+// leaves as split planes over the q rows (the H-plane region) once every wave is done reading; the zero entries either side
+// of every plane row, overwritten by the q | k | v block, are restored for the k = 3 convs that follow.
+__device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv) {
+  using G = PG<16>;
+  lds_f *q3 = (lds_f *)qkv;
+  const int t = c.tid;
+  {   // keys
+    const int rs = c.lane >> 4, T = (c.lane >> 2) & 3, s = c.lane & 3;
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      const int row = kHidden + 32 * rd + 4 * c.wave + rs;
+      float k[4], km = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        k[j] = q3[pswz(row, 16 * T + 4 * ((j + rs) & 3) + s)];
+        km = fmaxf(km, k[j]);
+      }
+      km = fmaxf(km, dpp_mov<0x124>(km));   // the other three tiles: row_ror 4, 8
+      km = fmaxf(km, dpp_mov<0x128>(km));
+      float ks = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        k[j] = fast_exp(k[j] - km);
+        ks += k[j];
+      }
+      ks += dpp_mov<0x124>(ks);
+      ks += dpp_mov<0x128>(ks);
+      const float inv = __builtin_amdgcn_rcpf(ks);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q3[pswz(row, 16 * T + 4 * ((j + rs) & 3) + s)] = k[j] * inv;
+    }
+  }
+  {   // queries
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int item = rd * 128 + (t >> 2), qt = t & 3, h = item >> 6, col = item & 63;
+      const int row0 = h * kDimHead + 8 * qt;
+      float q[8], qm = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        q[j] = q3[pswz(row0 + j, col)];
+        qm = fmaxf(qm, q[j]);
+      }
+      qm = fmaxf(qm, dpp_mov<0xB1>(qm));
+      qm = fmaxf(qm, dpp_mov<0x4E>(qm));  // the four channel quarters of a column: one quad
+      float qs = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        q[j] = fast_exp(q[j] - qm);
+        qs += q[j];
+      }
+      qs += dpp_mov<0xB1>(qs);
+      qs += dpp_mov<0x4E>(qs);
+      const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(qs);  // dim_head ** -0.5 / sum
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q3[pswz(row0 + j, col)] = q[j] * sc;
+    }
+  }
+  __syncthreads();
+  const int m = c.lane & 15, kq = c.lane >> 4;
+  f32x4 o[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int pair = 2 * c.wave + e, h = pair >> 2, s = pair & 3;
+    f32x4 am = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // channel d = 4 j + kq
+      const float ka = q3[pswz(kHidden + h * kDimHead + 4 * j + kq, 4 * m + s)];   // Kn^T[key position m][d]
+      const float qb = q3[pswz(h * kDimHead + 4 * j + kq, 4 * m + s)];             // Qn[d][query position m]
+      am = __builtin_amdgcn_mfma_f32_16x16x4f32(ka, qb, am, 0, 0, 0);
+    }
+    // am: lane (query position m, kq), register r = A[key position 4 kq + r][m]
+    o[e][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    o[e][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // k-step r: key positions 4 kq + r
+      const float v0 = q3[pswz(2 * kHidden + h * kDimHead + m, 4 * (4 * kq + r) + s)];
+      const float v1 = q3[pswz(2 * kHidden + h * kDimHead + 16 + m, 4 * (4 * kq + r) + s)];
+      o[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, am[r], o[e][0], 0, 0, 0);
+      o[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, am[r], o[e][1], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // all reads of q, k, v are done
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int pair = 2 * c.wave + e, h = pair >> 2, s = pair & 3;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)   // o[e][u][r]: channel 16 u + 4 kq + r of head h, query position m
+      store_planes4<16>(c.lds + G::kH, kDimHead * h + 16 * u + 4 * kq, 4 * m + s, o[e][u][0], o[e][u][1], o[e][u][2], o[e][u][3]);
+  }
+  // the zero entries of every plane row of both regions (8 blocks x 3 planes x 4 g rows x 8 entries)
+  {
+    lds_u4 *pl = (lds_u4 *)(c.lds + G::kH);
+    const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
+    for (int i = t; i < 8 * 12 * 8; i += 512) {
+      const int rowi = i >> 3, e8 = i & 7;
+      pl[rowi * G::kCols + (e8 < 4 ? e8 : 64 + e8)] = z4;
+    }
+  }
+  __syncthreads();
+}
+
 // A whole ResnetBlock of the position-major engine as ONE op: conv1 (GroupNorm, scale/shift, SiLU -> H), barrier, conv2
 // (GroupNorm, SiLU, X += ...).  Straight-line code, so the first weight fragments of conv2 can be requested while conv1's
 // epilogue runs and be there when its k-loop starts: requested cold at the top of the loop they cost ~1.8 k cycles per
 // conv (a build that loads no fragments at all runs the step 8 % faster; across two tape ops the compiler waits for
 // such loads at the op switch).  One tape decode and dispatch less, too.
-template <int MT, int P0, int NP, int GK>
+template <int MT, int P0, int NP, int GK, int LL = 4>
 __device__ __forceinline__ void resblock_pm_wave(const Ctx &c, const float *wp1, const float *b1, const float *wp2,
                                                  const float *b2, int mt0, float *X, float *H, int C,
-                                                 const GnEpilogue &g1, const GnEpilogue &g2, long long *stamp2) {
+                                                 const GnEpilogue &g1, const GnEpilogue &g2, long long *stamp2,
+                                                 bool live = true) {
   PreA<MT> pa;
   const WStream wv2(wp2, c.lane);
-  auto ask = [&]() { pa.request(wv2, mt0, C); };
-  conv_pm3_wave<MT, P0, NP, GK, 1, NoPreA, decltype(ask)>(c, wp1, b1, mt0, X, C, H, C, false, g1, NoPreA(), ask);
+  const int cin = C < 32 ? 32 : C;   // a 16-channel level is one zero-padded 32-channel block of planes
+  auto ask = [&]() { pa.request(wv2, mt0, cin); };
+  conv_pm3_wave<MT, P0, NP, GK, 1, NoPreA, decltype(ask), LL>(c, wp1, b1, mt0, X, C, H, C, false, g1, NoPreA(), ask, live);
   __syncthreads();
   if (stamp2 && c.tid == 0) *stamp2 = (long long)__builtin_readcyclecounter();
-  conv_pm3_wave<MT, P0, NP, GK, 2, PreA<MT>>(c, wp2, b2, mt0, H, C, X, C, false, g2, pa);
+  conv_pm3_wave<MT, P0, NP, GK, 2, PreA<MT>, NoHook, LL>(c, wp2, b2, mt0, H, C, X, C, false, g2, pa, NoHook(), live);
 }
+template <int LL = 4>
 __device__ __forceinline__ void resblock_pm(const Ctx &c, int w1, int b1, int w2, int b2, float *X, float *H, int C,
                                             const GnEpilogue &g1, const GnEpilogue &g2, long long *stamp2) {
   const float *wp1 = c.w + w1, *bp1 = c.w + b1, *wp2 = c.w + w2, *bp2 = c.w + b2;
   const int w = c.wave;
-  if (C == 256) resblock_pm_wave<2, 0, 4, 0>(c, wp1, bp1, wp2, bp2, 2 * w, X, H, C, g1, g2, stamp2);
-  else if (C == 128) resblock_pm_wave<1, 0, 4, 0>(c, wp1, bp1, wp2, bp2, w, X, H, C, g1, g2, stamp2);
+  if (C == 256) resblock_pm_wave<2, 0, 4, 0, LL>(c, wp1, bp1, wp2, bp2, 2 * w, X, H, C, g1, g2, stamp2);
+  else if (C == 128) resblock_pm_wave<1, 0, 4, 0, LL>(c, wp1, bp1, wp2, bp2, w, X, H, C, g1, g2, stamp2);
   else if (C == 64) {
-    if (w < 4) resblock_pm_wave<1, 0, 2, 1>(c, wp1, bp1, wp2, bp2, w & 3, X, H, C, g1, g2, stamp2);
-    else resblock_pm_wave<1, 2, 2, 1>(c, wp1, bp1, wp2, bp2, w & 3, X, H, C, g1, g2, stamp2);
-  } else {
+    if (w < 4) resblock_pm_wave<1, 0, 2, 1, LL>(c, wp1, bp1, wp2, bp2, w & 3, X, H, C, g1, g2, stamp2);
+    else resblock_pm_wave<1, 2, 2, 1, LL>(c, wp1, bp1, wp2, bp2, w & 3, X, H, C, g1, g2, stamp2);
+  } else if (C == 32 || LL == 4) {
     const int pw = w >> 1;
-    if (pw == 0) resblock_pm_wave<1, 0, 1, 2>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
-    else if (pw == 1) resblock_pm_wave<1, 1, 1, 2>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
-    else if (pw == 2) resblock_pm_wave<1, 2, 1, 2>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
-    else resblock_pm_wave<1, 3, 1, 2>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
+    if (pw == 0) resblock_pm_wave<1, 0, 1, 2, LL>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
+    else if (pw == 1) resblock_pm_wave<1, 1, 1, 2, LL>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
+    else if (pw == 2) resblock_pm_wave<1, 2, 1, 2, LL>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
+    else resblock_pm_wave<1, 3, 1, 2, LL>(c, wp1, bp1, wp2, bp2, w & 1, X, H, C, g1, g2, stamp2);
+  } else if constexpr (LL == 16) {   // C = 16: one m-tile, a tile per wave of 0-3; waves 4-7 shadow them
+    const int t = w & 3;
+    const bool live = w < 4;
+    if (t == 0) resblock_pm_wave<1, 0, 1, 3, 16>(c, wp1, bp1, wp2, bp2, 0, X, H, C, g1, g2, stamp2, live);
+    else if (t == 1) resblock_pm_wave<1, 1, 1, 3, 16>(c, wp1, bp1, wp2, bp2, 0, X, H, C, g1, g2, stamp2, live);
+    else if (t == 2) resblock_pm_wave<1, 2, 1, 3, 16>(c, wp1, bp1, wp2, bp2, 0, X, H, C, g1, g2, stamp2, live);
+    else resblock_pm_wave<1, 3, 1, 3, 16>(c, wp1, bp1, wp2, bp2, 0, X, H, C, g1, g2, stamp2, live);
   }
   __syncthreads();
 }
@@ -1780,19 +2091,21 @@ __device__ __forceinline__ void conv_gemm(const Ctx &c, int w_off, int b_off, co
 #define GLDM_G1(MT, NT, P, mt0, nt0, on) gemm_passes<NC, L, 1, MT, NT, P>(c, wp, mt0, nt0, on, src, cin, dst, cout, bias, alias, act, g)
   if constexpr (NC == 64) {
     if (ktaps == 3) {
-      // position-major engine (L = 4): 8 waves share the m-tiles; the three taps tie the 4 position tiles together
-      if (cin & 15) conv_pm3_cin4(c, wp, bias, src, dst, cout, alias);
-      else if (mtiles == 16) conv_pm3_wave<2, 0, 4, 0>(c, wp, bias, 2 * w, src, cin, dst, cout, alias, g);
-      else if (mtiles == 8) conv_pm3_wave<1, 0, 4, 0>(c, wp, bias, w, src, cin, dst, cout, alias, g);
+      // 64-column engines: 8 waves share the m-tiles (L = 4: the three taps tie the 4 position tiles together; L = 16:
+      // tiles of 4 positions x 4 samples, taps by shifted plane reads).  Only the levels' down convs come this way.
+      constexpr int LL = L == 16 ? 16 : 4;
+      if (LL == 4 && (cin & 15)) conv_pm3_cin4(c, wp, bias, src, dst, cout, alias);
+      else if (mtiles == 16) conv_pm3_wave<2, 0, 4, 0, 0, NoPreA, NoHook, LL>(c, wp, bias, 2 * w, src, cin, dst, cout, alias, g);
+      else if (mtiles == 8) conv_pm3_wave<1, 0, 4, 0, 0, NoPreA, NoHook, LL>(c, wp, bias, w, src, cin, dst, cout, alias, g);
       else if (mtiles == 4) {
-        if (w < 4) conv_pm3_wave<1, 0, 2, 1>(c, wp, bias, w & 3, src, cin, dst, cout, alias, g);
-        else conv_pm3_wave<1, 2, 2, 1>(c, wp, bias, w & 3, src, cin, dst, cout, alias, g);
-      } else {  // 2 m-tiles: wave = (m-tile, position)
+        if (w < 4) conv_pm3_wave<1, 0, 2, 1, 0, NoPreA, NoHook, LL>(c, wp, bias, w & 3, src, cin, dst, cout, alias, g);
+        else conv_pm3_wave<1, 2, 2, 1, 0, NoPreA, NoHook, LL>(c, wp, bias, w & 3, src, cin, dst, cout, alias, g);
+      } else {  // 2 m-tiles: wave = (m-tile, position / tile)
         const int pw = w >> 1;
-        if (pw == 0) conv_pm3_wave<1, 0, 1, 2>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
-        else if (pw == 1) conv_pm3_wave<1, 1, 1, 2>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
-        else if (pw == 2) conv_pm3_wave<1, 2, 1, 2>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
-        else conv_pm3_wave<1, 3, 1, 2>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
+        if (pw == 0) conv_pm3_wave<1, 0, 1, 2, 0, NoPreA, NoHook, LL>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
+        else if (pw == 1) conv_pm3_wave<1, 1, 1, 2, 0, NoPreA, NoHook, LL>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
+        else if (pw == 2) conv_pm3_wave<1, 2, 1, 2, 0, NoPreA, NoHook, LL>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
+        else conv_pm3_wave<1, 3, 1, 2, 0, NoPreA, NoHook, LL>(c, wp, bias, w & 1, src, cin, dst, cout, alias, g);
       }
     }
     // 1x1 layers (layout agnostic): 8 waves x 4 n-tiles; also the fused set abstraction
@@ -2174,7 +2487,7 @@ struct RunArgs {
 // down conv).  It is written once per workgroup into LDS (12 ints per op) and interpreted by a switch
 // inside the step loop, so every phase body exists once, inlined, with registers allocated across the
 // whole kernel: no calls, no callee-save traffic and no spilled kernel state between phases.
-enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_OUTLN = 6, OP_QKVATT = 7 };
+enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKVLN = 5, OP_OUTLN = 6, OP_QKVATT = 7 };
 // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9 | (scale/shift table offset / 4) << 12
 constexpr int kFlagAlias = 1 << 8;
 constexpr int kFlagFused = 1 << 11;   // position-major engine: this conv and the next tape entry are one ResnetBlock op
@@ -2331,7 +2644,11 @@ __host__ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *
       // position-major engine (C <= 128 at attention levels): X rows [0, 128) | q,k,v of the four heads: 384 rows, o in
       // place of q.  The PreNorm LayerNorm is folded into the qkv conv (C = 4: computed in the lanes of the qkv phase).
       int Oa = O;
-      if (NC == 64) {   // PreNorm + to_qkv + attention core of the four heads: one op, the output as planes (kPlaneH)
+      if (NC == 64 && d.seq_len == 16) {   // 16 positions: q | k | v through LDS (over the plane regions), output as planes
+        emit(OP_QKVLN, v.qkvn_w3, v.qkvn_s, X, 128 * NC, C);
+        emit(OP_ATT, 128 * NC);
+        Oa = kPlaneH;
+      } else if (NC == 64) {   // PreNorm + to_qkv + attention core of the four heads: one op, the output as planes (kPlaneH)
         emit(OP_QKVATT, C == 4 ? v.qkvn_w : v.qkvn_w3, v.qkvn_s, X, C);
         Oa = kPlaneH;
       } else {
@@ -2341,13 +2658,13 @@ __host__ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *
         emit(OP_CONV, v.qkv_w[1], -1, Y, QKV, C, 192, 1);
         emit(OP_ATT, QKV, O + 64 * NC);
       }
-      if (NC == 64 && (C == 4 || C == 32 || C == 64 || C == 128)) {  // to_out conv + LayerNorm + residual: one phase
+      if (NC == 64 && (C == 4 || C == 16 || C == 32 || C == 64 || C == 128)) {  // to_out conv + LayerNorm + residual: one phase
         emit(OP_OUTLN, v.out_w3, v.out_b, Oa, X, kHidden, C, v.ln2_g);
       } else {
         emit(OP_CONV, v.out_w, v.out_b, Oa, Y, kHidden, C, 1);
         emit(OP_LN, Y, -1, X, C, v.ln2_g);
       }
-      emit(OP_CONV, (NC == 64 && C >= 32) ? v.down_w3 : v.down_w, v.down_b, X, X, C, Cn, 3 | kFlagAlias);
+      emit(OP_CONV, (NC == 64 && C >= 16) ? v.down_w3 : v.down_w, v.down_b, X, X, C, Cn, 3 | kFlagAlias);
     }
   }
 #pragma unroll
@@ -2405,7 +2722,7 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, kernarg
             read_op<KARG>(tape, ktape, op + 1, q);
             const GnEpilogue g1{1, o[8], o[9], o[10], o[11], E, o[6], o[6] / 4, c.lds + o[4], (o[7] >> kFlagTabShift) << 2};
             const GnEpilogue g2{2, q[8], q[9], -1, 0, E, q[6], q[6] / 4, c.lds + q[4], 0};
-            resblock_pm(c, o[1], o[2], q[1], q[2], c.lds + o[3], c.lds + o[4], o[6], g1, g2, stamps ? stamps + op + 1 : nullptr);
+            resblock_pm<L == 16 ? 16 : 4>(c, o[1], o[2], q[1], q[2], c.lds + o[3], c.lds + o[4], o[6], g1, g2, stamps ? stamps + op + 1 : nullptr);
             ++op;
             break;
           }
@@ -2418,13 +2735,20 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, kernarg
       }
       case OP_RES4:
         if (!GLDM_SKIP(c, 8)) {
-          if constexpr (NC == 64) resblock4_pm(c, o, E);
-          else resblock4_valu<NC>(c, o, E);
+          if constexpr (NC == 64 && L == 4) resblock4_pm(c, o, E);
+          else if constexpr (NC != 64) resblock4_valu<NC>(c, o, E);
         }
         if (o[11]) __syncthreads();
         break;
+      case OP_QKVLN:
+        if constexpr (NC == 64 && L == 16) {
+          if (o[5] == 128) qkv_ln16_pm<4>(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4]);
+          else if (o[5] == 64) qkv_ln16_pm<2>(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4]);
+          else qkv_ln16_pm<1>(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4]);
+        }
+        break;
       case OP_QKVATT:
-        if constexpr (NC == 64) {
+        if constexpr (NC == 64 && L == 4) {
           if (o[4] == 128) qkv_att_pm<4>(c, o[1], o[2], c.lds + o[3], o[4]);
           else if (o[4] == 64) qkv_att_pm<2>(c, o[1], o[2], c.lds + o[3], o[4]);
           else if (o[4] == 32) qkv_att_pm<1>(c, o[1], o[2], c.lds + o[3], o[4]);
@@ -2432,7 +2756,7 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, kernarg
         }
         break;
       case OP_OUTLN:
-        if constexpr (NC == 64) out_ln_pm(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4], o[6], o[7]);
+        if constexpr (NC == 64) out_ln_pm<L == 16 ? 16 : 4>(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4], o[6], o[7]);
         break;
       case OP_LN:
         layer_norm_pass<NC>(c, c.lds + o[1], o[2] >= 0 ? c.lds + o[2] : nullptr, o[3] >= 0 ? c.lds + o[3] : nullptr,
@@ -2440,6 +2764,7 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, kernarg
         break;
       default:
         if constexpr (NC != 64) attention_pair<NC, L>(c, c.lds + o[1], c.lds + o[2]);
+        else if constexpr (L == 16) attention16_pm(c, c.lds + o[1]);
         break;
     }
   }
@@ -2494,11 +2819,13 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   constexpr int S = NC / L;
   // column <-> (sample, position): sample-major tiles (column = sample * L + position) or, for the 64-column
   // engine of the L = 4 denoiser, position-major ones (column = 16 * position + sample)
+  // (4 positions: column = 16 * position + sample, 16 samples) or of the 16-position nets (column = 4 * position + sample,
+  // 4 samples)
   constexpr bool PM = NC == 64;
-  static_assert(!PM || L == 4, "the position-major engine is built for 4-position latents");
-  auto samp_of = [](int n) { return PM ? (n & 15) : n / L; };
-  auto pos_of = [](int n) { return PM ? (n >> 4) : n % L; };
-  auto col_of = [](int sm, int l) { return PM ? 16 * l + sm : sm * L + l; };
+  static_assert(!PM || L == 4 || L == 16, "64-column engines: 4- and 16-position nets");
+  auto samp_of = [](int n) { return PM ? (L == 4 ? (n & 15) : (n & 3)) : n / L; };
+  auto pos_of = [](int n) { return PM ? (L == 4 ? (n >> 4) : (n >> 2)) : n % L; };
+  auto col_of = [](int sm, int l) { return PM ? (L == 4 ? 16 * l + sm : 4 * l + sm) : sm * L + l; };
   Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
         a.skip, GG::kNT};
   if constexpr (PM) c.park = a.park + (size_t)blockIdx.x * (kParkBytes / 4);
@@ -2571,10 +2898,15 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   const int nsamp = min(S, a.n_samples - samp0);  // samples this tile holds (the batch's last tile may be short)
   c.nta = (nsamp * L <= 16) ? 1 : GG::kNT;
   if (L == 16 && a.ss_tab) {
+    if constexpr (PM) {   // this lane's sample (lane & 3) -> its cloud's rows
+      const int gi = min(samp0 + min(c.lane & 3, nsamp - 1), a.n_samples - 1);
+      c.ss_lane = a.ss_tab + (size_t)(gi / a.samples_per_cond) * a.ss_stride;
+    } else {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int gi = min(samp0 + min(q, nsamp - 1), a.n_samples - 1);
-      c.ss_row[q] = a.ss_tab + (size_t)(gi / a.samples_per_cond) * a.ss_stride;
+      for (int q = 0; q < 2; ++q) {
+        const int gi = min(samp0 + min(q, nsamp - 1), a.n_samples - 1);
+        c.ss_row[q] = a.ss_tab + (size_t)(gi / a.samples_per_cond) * a.ss_stride;
+      }
     }
   }
   // ---- latent row for this tile: from the input (first step) or from the slot that ran the steps before s0
@@ -2664,6 +2996,15 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       X[PM ? pswz(ch, n) : swz<NC>(ch, n)] = acc;
     }
     __syncthreads();
+    if constexpr (PM && L == 16) {   // the first ResnetBlock reads the planes of the init conv's 16 rows
+      if (c.tid < 256) {
+        const int rg = c.tid >> 6, n = c.tid & 63;
+        const lds_f *x3 = (const lds_f *)X;
+        store_planes4<16>(lds + PG<16>::kX, 4 * rg, n, x3[pswz(4 * rg, n)], x3[pswz(4 * rg + 1, n)], x3[pswz(4 * rg + 2, n)],
+                          x3[pswz(4 * rg + 3, n)]);
+      }
+      __syncthreads();
+    }
 
     run_tape<NC, L>(c, tape, ktape, n_ops, E, blockIdx.x == 0 ? GLDM_STAMPS(a.stamps) : nullptr);
     if (GLDM_STAMPS(a.stamps) && blockIdx.x == 0 && c.tid == 0) a.stamps[n_ops] = (long long)__builtin_readcyclecounter();
@@ -2725,7 +3066,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       if (s < nsamp && gi < a.n_samples) {
         const float *wr = a.weights + d.head_w + r * L;
         float acc = a.weights[d.head_b + r];
-        for (int l = 0; l < L; ++l) acc += wr[l] * epsr[s * L + l];
+        for (int l = 0; l < L; ++l) acc += wr[l] * epsr[col_of(s, l)];
         if (r < 6) a.out0[(size_t)gi * 6 + r] = acc;
         else a.out1[gi] = acc;
       }
@@ -2847,7 +3188,7 @@ __global__ __launch_bounds__(Geo<64>::kThreads, 2) void sa_mlp_kernel(const SaAr
   // ---- grouped MLP (1x1 convs + folded BN + ReLU), ping-pong X <-> H
   float *src = X, *dst = H;
   for (int l = 0; l < a.n_layers; ++l) {
-    conv_gemm<NC, 16>(c, a.w_off[l], a.b_off[l], src, a.cin_pad[l], 1, dst, a.cout[l], false, 1);
+    conv_gemm<NC, 4>(c, a.w_off[l], a.b_off[l], src, a.cin_pad[l], 1, dst, a.cout[l], false, 1);   // 1x1 layers only (L is the k = 3 convs' layout)
     float *t = src; src = dst; dst = t;
   }
   // ---- max over the U neighbours of each centre
@@ -2913,13 +3254,53 @@ bool pm_supported(const gldm_r1d_desc *d) {
   return true;
 }
 
+// The 16-position 64-column engine (r1d_kernel<64, 16>: tiles of 4 samples x 16 positions, column = 4 * position +
+// sample, split-bf16 GEMMs on pre-split planes) serves the nets both shipped experiments run at 16 positions: the pose
+// decoder (latent_dim > 0, heads) and the ppc experiment's latent denoiser.  emb_dim 64, a 16-channel first level
+// and 32..256-channel ones after it, every split-bf16 weight copy present (ABI 5 packers; 16-channel levels zero-padded
+// to one 32-channel block: r1d_pack.pad_cin32).
+bool pm16_supported(const gldm_r1d_desc *d) {
+  if (d->seq_len != 16 || d->emb_dim != 64 || d->groups != 4 || d->dims[0] != 16 || d->cond_rows > 4) return false;
+  for (int i = 0; i < d->n_levels; ++i)
+    if (d->lv[i].qkvn_w3 <= 0 || d->lv[i].qkvn_s <= 0 || d->lv[i].out_w3 <= 0 || d->lv[i].down_w3 <= 0) return false;
+  for (int i = 0; i <= 2 * d->n_levels; ++i)
+    if (d->rb[i].c1_w3 <= 0 || d->rb[i].c2_w3 <= 0) return false;
+  for (int i = 1; i <= d->n_levels; ++i) {
+    const int C = d->dims[i];
+    if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false;
+    if (i < d->n_levels && C > 128) return false;
+  }
+  return true;
+}
+bool wide_engine(const gldm_r1d_desc *d) { return pm_supported(d) || pm16_supported(d); }   // 64-column tiles
+
 using gldm_dev::cu_count;
 
 // Scratch behind the hand-off granules where the position-major engine parks the residual stream of a 256-channel last
 // level (kPlaneW): 64 KiB per workgroup of the launch (at most one per CU), 256-byte aligned.  *base is rounded up to the
 // alignment; returns the bytes to add behind it (0: this descriptor never parks).
+struct WsLayout { long long tiles, ss_off, park_off, total; int nc; };
+long long park_bytes(const gldm_r1d_desc *d, long long tiles, long long *base);
+// header | hand-off granules | (256-byte aligned) the decoder's scale/shift table | (256-byte aligned) park scratch
+WsLayout ws_layout(const gldm_r1d_desc *d, int n_samples) {
+  WsLayout w{};
+  w.nc = wide_engine(d) ? 64 : engine_nc();
+  const int S = w.nc / d->seq_len;
+  w.tiles = (n_samples + S - 1) / S;
+  long long bytes = kChainHdrBytes + w.tiles * w.nc * 8;
+  w.ss_off = -1;
+  if (ss_table_rows(d) > 0) {
+    bytes = (bytes + 255) & ~255LL;
+    w.ss_off = bytes;
+    bytes += (long long)n_samples * ss_table_rows(d) * 4;
+  }
+  const long long pb = park_bytes(d, w.tiles, &bytes);
+  w.park_off = pb > 0 ? bytes : -1;
+  w.total = bytes + pb;
+  return w;
+}
 long long park_bytes(const gldm_r1d_desc *d, long long tiles, long long *base) {
-  if (!pm_supported(d) || d->dims[d->n_levels] != 256) return 0;
+  if (!wide_engine(d) || d->dims[d->n_levels] != 256) return 0;
   *base = (*base + 255) & ~255LL;
   const long long wgs = tiles < cu_count() ? tiles : cu_count();
   return wgs * kParkBytes;
@@ -2968,7 +3349,7 @@ int launch_one(const RunArgs &a, int tiles, hipStream_t s) {
 }
 
 int launch_r1d(const RunArgs &a_in, hipStream_t s) {
-  const bool pm = pm_supported(&a_in.d);
+  const bool pm4 = pm_supported(&a_in.d), pm16 = !pm4 && pm16_supported(&a_in.d), pm = pm4 || pm16;
   const int L = a_in.d.seq_len, nc = pm ? 64 : engine_nc();
   const Plan pl = make_plan(a_in.n_samples, a_in.n_steps, L, nc, a_in.sched_kind != GLDM_SCHED_DPMPP);
   const int tiles = pl.grid;
@@ -2978,11 +3359,10 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   a.park = nullptr;
   a.pm_nops = 0;
   if (pm) {
-    static_assert(7 * GLDM_R1D_MAX_LEVELS + 2 <= kPmMaxOps, "position-major tape");
+    static_assert(8 * GLDM_R1D_MAX_LEVELS + 2 <= kPmMaxOps && sizeof(RunArgs) <= 4096, "64-column tape in the kernel arguments");
     a.pm_nops = build_tape<64>(a_in.d, a.pm_tape);
-    const long long all_tiles = (a_in.n_samples + 16 - 1) / 16;
-    long long off = kChainHdrBytes + all_tiles * 64 * 8;
-    if (park_bytes(&a_in.d, all_tiles, &off) > 0) a.park = reinterpret_cast<float *>(reinterpret_cast<char *>(a_in.ws) + off);
+    const WsLayout wl = ws_layout(&a_in.d, a_in.n_samples);
+    if (wl.park_off >= 0) a.park = reinterpret_cast<float *>(reinterpret_cast<char *>(a_in.ws) + wl.park_off);
   }
   a.n_cus = cu_count();
 #ifdef GLDM_DEBUG_KNOBS
@@ -3001,8 +3381,9 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   static long long *dstamps = nullptr;
   if (stamp && !dstamps) (void)hipMalloc(&dstamps, (kMaxOps + 2) * sizeof(long long));
   a.stamps = stamp ? dstamps : nullptr;
-  const int rc = pm ? launch_one<64, 4>(a, tiles, s)
-                    : (L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s));
+  const int rc = pm4 ? launch_one<64, 4>(a, tiles, s)
+                     : (pm16 ? launch_one<64, 16>(a, tiles, s)
+                             : (L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s)));
   if (stamp) {
     static long long host[kMaxOps + 2];
     static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "", "OUTLN", "QKVAT"};
@@ -3686,20 +4067,14 @@ GLDM_API int gldm_r1d_cond_embed(const float *z_cond, const float *w, const floa
 
 GLDM_API long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples) {
   if (validate(desc) != GLDM_OK || n_samples <= 0) return -1;
-  // header + one 8-byte hand-off granule per activation column of every tile (see ChainHdr)
-  const int nc = pm_supported(desc) ? 64 : engine_nc();
-  const int S = nc / desc->seq_len;
-  const long long tiles = (n_samples + S - 1) / S;
-  long long bytes = kChainHdrBytes + tiles * nc * 8;
-  if (ss_table_rows(desc) > 0) bytes = ((bytes + 255) & ~255LL) + (long long)n_samples * ss_table_rows(desc) * 4;
-  bytes += park_bytes(desc, tiles, &bytes);
-  return bytes;
+  // header + one 8-byte hand-off granule per activation column of every tile (see ChainHdr) + table + park scratch
+  return ws_layout(desc, n_samples).total;
 }
 
 GLDM_API int gldm_r1d_tile_columns(const gldm_r1d_desc *desc) {
   const int st = validate(desc);
   if (st != GLDM_OK) return st;
-  return pm_supported(desc) ? 64 : engine_nc();
+  return wide_engine(desc) ? 64 : engine_nc();
 }
 
 GLDM_API int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,
@@ -3739,9 +4114,7 @@ GLDM_API int gldm_decode(const gldm_r1d_desc *desc, const float *weights, const 
   a.out0 = tmrp; a.out1 = logit; a.ws = reinterpret_cast<float *>(workspace);
   const int rows = ss_table_rows(desc);
   if (rows > 0) {  // the table lives behind the hand-off granules of the workspace (gldm_r1d_workspace_bytes)
-    const int nc = engine_nc(), S = nc / desc->seq_len;
-    const long long tiles = (n_samples + S - 1) / S;
-    const long long off = ((kChainHdrBytes + tiles * nc * 8) + 255) & ~255LL;
+    const long long off = ws_layout(desc, n_samples).ss_off;
     float *tab = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + off);
     const int n_cond = (n_samples + samples_per_cond - 1) / samples_per_cond;
     hipLaunchKernelGGL(ss_table_kernel, dim3(n_cond), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *desc, weights,

@@ -87,6 +87,18 @@ def conv_as_gemm(w):
     return w.permute(0, 2, 1).reshape(w.shape[0], -1)
 
 
+def pad_cin32(w2d, cin, taps):
+    """[Cout, taps * cin] (k = tap * cin + ci) -> [Cout, taps * 32] with every tap's channels zero-padded to 32: a
+    16-channel level of the 64-column engines reads its activations as one 32-channel block of split planes whose upper
+    half is never written (finite leftovers), so the weights of those channels are zero."""
+    if cin % 32 == 0:
+        return w2d
+    cp = (cin + 31) // 32 * 32
+    out = torch.zeros(w2d.shape[0], taps, cp, dtype=w2d.dtype)
+    out[:, :, :cin] = w2d.reshape(w2d.shape[0], taps, cin)
+    return out.reshape(w2d.shape[0], taps * cp)
+
+
 def weight_standardize(w):
     mean = w.mean(dim=(1, 2), keepdim=True)
     var = w.var(dim=(1, 2), unbiased=False, keepdim=True)
@@ -153,9 +165,9 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
         rb.ss_w = buf.add(mfma_a_fragments(mw))
         rb.ss_b = buf.add(comb)
         w1, w2 = (conv_as_gemm(weight_standardize(sd[q + f"block{i}.proj.weight"])) for i in (1, 2))
-        if c % 32 == 0:   # split-bf16 copies for the position-major engine (K = 3 C is then a multiple of 32 per tap)
-            rb.c1_w3 = buf.add(mfma_a_fragments_bf16x3(w1))
-            rb.c2_w3 = buf.add(mfma_a_fragments_bf16x3(w2))
+        if c % 16 == 0:   # split-bf16 copies for the 64-column engines (per tap a multiple of 32 channels: 16 is padded)
+            rb.c1_w3 = buf.add(mfma_a_fragments_bf16x3(pad_cin32(w1, c, 3)))
+            rb.c2_w3 = buf.add(mfma_a_fragments_bf16x3(pad_cin32(w2, c, 3)))
         rb.c1_w = buf.add(mfma_a_fragments(conv_as_gemm(weight_standardize(sd[q + "block1.proj.weight"]))))
         rb.c1_b = buf.add(sd[q + "block1.proj.bias"])
         rb.n1_w = buf.add(sd[q + "block1.norm.weight"])
@@ -192,9 +204,9 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
         lv.out_b = buf.add(sd[q + "2.fn.fn.to_out.0.bias"])
         lv.ln2_g = buf.add(sd[q + "2.fn.fn.to_out.1.g"])
         lv.down_w = buf.add(mfma_a_fragments(conv_as_gemm(sd[q + "3.weight"])))
-        if c % 32 == 0:
-            lv.qkvn_w3 = buf.add(mfma_a_fragments_bf16x3(wn))
-            lv.down_w3 = buf.add(mfma_a_fragments_bf16x3(conv_as_gemm(sd[q + "3.weight"])))
+        if c % 16 == 0:
+            lv.qkvn_w3 = buf.add(mfma_a_fragments_bf16x3(pad_cin32(wn, c, 1)))
+            lv.down_w3 = buf.add(mfma_a_fragments_bf16x3(pad_cin32(conv_as_gemm(sd[q + "3.weight"]), c, 3)))
         lv.out_w3 = buf.add(mfma_a_fragments_bf16x3(sd[q + "2.fn.fn.to_out.0.weight"][:, :, 0]))
         lv.down_b = buf.add(sd[q + "3.bias"])
     resblock(p + "final_res_block.", dims[-1], slot)

@@ -142,8 +142,9 @@ def test_packed_descriptor_of_denoiser(fpc_state_dict):
 
 
 def test_decoder_workspace_holds_the_scale_shift_table():
-    """gldm_r1d_workspace_bytes of the pose decoder: header + hand-off granules (2 samples per 32-column tile), rounded
-    to 256 bytes, + one row set per sample (upper bound of one grasp per cloud) of 2 C floats per ResnetBlock."""
+    """gldm_r1d_workspace_bytes of the pose decoder (16-position 64-column engine): header + hand-off granules (4 samples
+    per 64-column tile), rounded to 256 bytes, + one row set per sample (upper bound of one grasp per cloud) of 2 C floats
+    per ResnetBlock, rounded again, + 64 KiB per workgroup where the 256-channel level parks its residual stream."""
     import ctypes
     from graspldm_amd import _lib
     from graspldm_amd.pipeline import build_fpc_ldm
@@ -159,8 +160,15 @@ def test_decoder_workspace_holds_the_scale_shift_table():
     assert dims == [16, 32, 64, 128, 256] and d.emb_dim == 64 and d.seq_len == 16
     rows = sum(2 * dims[i // 2] for i in range(2 * d.n_levels)) + 2 * dims[d.n_levels]
     n = 50
+    assert _lib.lib().gldm_r1d_tile_columns(ptr) == 64
+    tiles = (n + 3) // 4
+    base = (256 + tiles * 64 * 8 + 255) // 256 * 256 + n * rows * 4
+    assert _lib.lib().gldm_r1d_workspace_bytes(ptr, n) == (base + 255) // 256 * 256 + tiles * 65536
+    d.emb_dim = 32   # not a shape of the 64-column engine -> the sample-major one: 2 samples per 32-column tile, no park
+    assert _lib.lib().gldm_r1d_tile_columns(ptr) == 32
     base = 256 + ((n + 1) // 2) * 32 * 8
     assert _lib.lib().gldm_r1d_workspace_bytes(ptr, n) == (base + 255) // 256 * 256 + n * rows * 4
+    d.emb_dim = 64
 
 
 def test_folded_prenorm_qkv_block_of_the_descriptor(fpc_state_dict):
