@@ -1923,7 +1923,7 @@ __device__ __forceinline__ void qkv_ln16_pm(const Ctx &c, int w_off, int s_off, 
 // registers being the B operand of the second product as they stand (k-step r = key positions {4 kq + r}).  The output
 // leaves as split planes over the q rows (the H-plane region) once every wave is done reading; the zero entries either side
 // of every plane row, overwritten by the q | k | v block, are restored for the k = 3 convs that follow.
-__device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv) {
+__device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv, int C) {
   using G = PG<16>;
   lds_f *q3 = (lds_f *)qkv;
   const int t = c.tid;
@@ -2018,6 +2018,16 @@ __device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv) {
     for (int i = t; i < 8 * 12 * 8; i += 512) {
       const int rowi = i >> 3, e8 = i & 7;
       pl[rowi * G::kCols + (e8 < 4 ? e8 : 64 + e8)] = z4;
+    }
+    // A 16-channel level reads its planes as ONE 32-channel block whose upper half has zero weights -- but 0 x the bit
+    // patterns the q | k | v block left there can be 0 x NaN: channels 16 .. 31 (g = 2, 3) of block 0 of the X planes are
+    // cleared (the H region's hold this phase's attention output, finite, and later finite H values)
+    if (C == 16) {
+      lds_u4 *xb = (lds_u4 *)(c.lds + G::kX);
+      for (int j = t; j < 3 * 2 * 64; j += 512) {
+        const int plane = j / 128, gg = 2 + ((j >> 6) & 1), col = j & 63;
+        xb[(plane * 4 + gg) * G::kCols + G::kOff + col] = z4;
+      }
     }
   }
   __syncthreads();
@@ -2646,7 +2656,7 @@ __host__ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *
       int Oa = O;
       if (NC == 64 && d.seq_len == 16) {   // 16 positions: q | k | v through LDS (over the plane regions), output as planes
         emit(OP_QKVLN, v.qkvn_w3, v.qkvn_s, X, 128 * NC, C);
-        emit(OP_ATT, 128 * NC);
+        emit(OP_ATT, 128 * NC, C);
         Oa = kPlaneH;
       } else if (NC == 64) {   // PreNorm + to_qkv + attention core of the four heads: one op, the output as planes (kPlaneH)
         emit(OP_QKVATT, C == 4 ? v.qkvn_w : v.qkvn_w3, v.qkvn_s, X, C);
@@ -2764,7 +2774,7 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, kernarg
         break;
       default:
         if constexpr (NC != 64) attention_pair<NC, L>(c, c.lds + o[1], c.lds + o[2]);
-        else if constexpr (L == 16) attention16_pm(c, c.lds + o[1]);
+        else if constexpr (L == 16) attention16_pm(c, c.lds + o[1], o[2]);
         break;
     }
   }
