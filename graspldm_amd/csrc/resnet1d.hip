@@ -1923,6 +1923,19 @@ __device__ __forceinline__ void qkv_ln16_pm(const Ctx &c, int w_off, int s_off, 
 // registers being the B operand of the second product as they stand (k-step r = key positions {4 kq + r}).  The output
 // leaves as split planes over the q rows (the H-plane region) once every wave is done reading; the zero entries either side
 // of every plane row, overwritten by the q | k | v block, are restored for the k = 3 convs that follow.
+// The four zero entries either side of every plane row (8 blocks x 3 planes x 4 g rows x 8 entries) of the 16-position
+// engine.  Two things overwrite them with f32 data: the q | k | v block of an attention phase and the f32 rows of the
+// 256-channel level's output (rows 128 .. 255 of X lie over the first H-plane blocks): restored behind each.
+__device__ __forceinline__ void zero_plane_pads16(float *lds, int t) {
+  using G = PG<16>;
+  lds_u4 *pl = (lds_u4 *)(lds + G::kH);
+  const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
+  for (int i = t; i < 8 * 12 * 8; i += 512) {
+    const int rowi = i >> 3, e8 = i & 7;
+    pl[rowi * G::kCols + (e8 < 4 ? e8 : 64 + e8)] = z4;
+  }
+}
+
 __device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv, int C) {
   using G = PG<16>;
   lds_f *q3 = (lds_f *)qkv;
@@ -2011,14 +2024,10 @@ __device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv, int C) 
     for (int u = 0; u < 2; ++u)   // o[e][u][r]: channel 16 u + 4 kq + r of head h, query position m
       store_planes4<16>(c.lds + G::kH, kDimHead * h + 16 * u + 4 * kq, 4 * m + s, o[e][u][0], o[e][u][1], o[e][u][2], o[e][u][3]);
   }
-  // the zero entries of every plane row of both regions (8 blocks x 3 planes x 4 g rows x 8 entries)
+  // the zero entries of every plane row of both regions
   {
-    lds_u4 *pl = (lds_u4 *)(c.lds + G::kH);
+    zero_plane_pads16(c.lds, t);
     const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
-    for (int i = t; i < 8 * 12 * 8; i += 512) {
-      const int rowi = i >> 3, e8 = i & 7;
-      pl[rowi * G::kCols + (e8 < 4 ? e8 : 64 + e8)] = z4;
-    }
     // A 16-channel level reads its planes as ONE 32-channel block whose upper half has zero weights -- but 0 x the bit
     // patterns the q | k | v block left there can be 0 x NaN: channels 16 .. 31 (g = 2, 3) of block 0 of the X planes are
     // cleared (the H region's hold this phase's attention output, finite, and later finite H values)
@@ -3007,6 +3016,15 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     }
     __syncthreads();
     if constexpr (PM && L == 16) {   // the first ResnetBlock reads the planes of the init conv's 16 rows
+      zero_plane_pads16(lds, c.tid);   // the previous step's (or tile's) 256-channel output rows lie over some of them
+      {   // ... and over channels 16 .. 31 of H-plane block 0, which the 16-channel level multiplies with zero weights
+        lds_u4 *hb = (lds_u4 *)(lds + PG<16>::kH);
+        const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
+        if (c.tid < 3 * 2 * 64) {
+          const int plane = c.tid / 128, gg = 2 + ((c.tid >> 6) & 1), col = c.tid & 63;
+          hb[(plane * 4 + gg) * PG<16>::kCols + PG<16>::kOff + col] = z4;
+        }
+      }
       if (c.tid < 256) {
         const int rg = c.tid >> 6, n = c.tid & 63;
         const lds_f *x3 = (const lds_f *)X;
