@@ -38,6 +38,21 @@ DENOISER_FLOP_PER_LATENT_STEP_PPC = 30_783_104   # the ppc experiment's 16-posit
 DECODER_FLOP_PER_GRASP = 30.7e6
 
 
+def denoiser_executed_mfma_flop_l16():
+    """The same count for a 16-position net on the 64-column engine (ppc denoiser; the pose decoder's trunk is the same
+    graph): every (tap, position) product of a k = 3 conv is issued (48 per output position block of 16; the two that fall on
+    the zero entries beside a sample's ends included), a 16-channel level as one zero-padded 32-channel block, the attention
+    products (16 x 16 per head and sample) on the f32 matrix pipe."""
+    dims = (16, 32, 64, 128, 256)
+    pad = lambda c: max(c, 32)
+    k3 = sum(4 * pad(c) * c for c in dims[:4]) + 2 * 256 * 256 + sum(pad(a) * b for a, b in zip(dims[:4], dims[1:]))
+    flop = 2 * 16 * 3 * k3                                        # k = 3 convs: 16 positions x 3 taps
+    flop += 2 * 16 * sum(384 * pad(c) + 128 * max(c, 16) for c in dims[:4])   # qkv and to_out 1x1 convs
+    flop += 4 * 4 * 2 * (16 * 16 * 32 + 32 * 16 * 16)             # attention: 4 levels x 4 heads x (K^T Q + V A)
+    flop += 2 * sum(2 * c * 64 for c in (16, 16, 32, 32, 64, 64, 128, 128, 256))   # scale/shift rows (E = 64), per sample
+    return flop
+
+
 def denoiser_executed_mfma_flop_fpc():
     """FLOP the position-major engine really issues on the matrix pipes per latent and step (f32-equivalent: one per
     algorithmic multiply-add pair, before the x6 of the split): the k = 3 convs multiply 10 of their 12 (tap, position)
@@ -352,8 +367,9 @@ def main():
                                   "tools/pmc_denoise.sh; not re-measured in this run)")
                 break
         if pm_engine:
-            exec_flop = B * G * S * denoiser_executed_mfma_flop_fpc()
-            roof = dict(kernel="r1d_kernel<64, 4> (gldm_denoise: %d %s steps fused, position-major tiles, split-bf16 GEMMs)" % (S, args.scheduler.upper()),
+            exec_flop = B * G * S * (denoiser_executed_mfma_flop_fpc() if D == 4 else denoiser_executed_mfma_flop_l16())
+            roof = dict(kernel="r1d_kernel<64, %d> (gldm_denoise: %d %s steps fused, 64-column tiles = %s, split-bf16 GEMMs)"
+                               % (D, S, args.scheduler.upper(), "16 samples x 4 positions" if D == 4 else "4 samples x 16 positions"),
                         bound="mfma",
                         achieved=flop / t_den / 1e12, peak=PEAK_SPLIT_TFLOPS, unit="TFLOP/s",
                         frac=flop / t_den / 1e12 / PEAK_SPLIT_TFLOPS, traffic=traffic, traffic_source=traffic_source,
@@ -369,8 +385,9 @@ def main():
                                   "so 6 executed bf16 FLOP per algorithmic FLOP",
                         timing="HIP events around 3 launches on their own (no other stream active); in the pipelined "
                                "steps the other stream's encoder kernels share the GPU with the launch",
-                        flop_note="algorithmic FLOP = the reference graph's count (7,589,120 per latent and step, = torch's "
-                                  "flop counter over the reference module, which counts a k=3 conv's zero-padding taps).  "
+                        flop_note=f"algorithmic FLOP = the reference graph's count ({flop_ls:,} per latent and step, = torch's "
+                                  "flop counter over the reference module, which counts a k=3 conv's zero-padding taps: "
+                                  "tests/golden/r1d_flops.json).  "
                                   "Arithmetic: f32 in, f32 out, f32 accumulation; products formed from bf16 pieces whose dropped "
                                   "cross terms are <= 2^-23 relative (parity bars unchanged: 2e-5 single forward, 1e-4 poses)")
         else:
@@ -388,6 +405,7 @@ def main():
           # ---- stage split and the set-abstraction gather (north-star HBM kernel), same run
           t_enc = event_time(lambda: ldm.vae_model.encode_pc(pcs), 6)
           dec = ldm.vae_model.decoder
+          dec_cols = L.lib().gldm_r1d_tile_columns(dec._get_engine(dev, z.shape[1])._desc_ptr())
           lat = dn().squeeze(-2)
           t_dec = event_time(lambda: dec(lat, z, samples_per_cond=G), 10, lead=2)
           if N == 1024:
@@ -406,9 +424,12 @@ def main():
                                "1536 layer, 96 -> 768 layer and the 48 / 96-channel voxel convs: split-bf16, 2500 / 6 TFLOP/s; the "
                                "rest: f32 MFMA, 157.3): frac = that time / measured, memory passes counted as zero"
                                % (ENCODER_FLOP_PER_CLOUD / 1e9), **enc_rec),
-                     dict(kernel="r1d_kernel<32, 16> (gldm_decode)", bound="mfma", avg_ms=t_dec * 1e3,
-                          achieved=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
-                          unit="TFLOP/s", frac=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12 / PEAK_F32_MFMA_TFLOPS)]
+                     dict(kernel="r1d_kernel<64, 16> (gldm_decode: 64-column tiles = 4 samples x 16 positions, split-bf16 GEMMs)"
+                                 if dec_cols == 64 else "r1d_kernel<32, 16> (gldm_decode, f32 matrix pipe)", bound="mfma",
+                          avg_ms=t_dec * 1e3, achieved=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12,
+                          peak=PEAK_SPLIT_TFLOPS if dec_cols == 64 else PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                          frac=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12 / (PEAK_SPLIT_TFLOPS if dec_cols == 64 else PEAK_F32_MFMA_TFLOPS),
+                          note="algorithmic FLOP = torch's flop counter over the reference decoder trunk (tests/golden/r1d_flops.json)")]
           # ---- the same launch on the f32 matrix pipe only: a descriptor without the split-bf16 weight copies (what an
           # ABI-4 packer produces) runs the sample-major engine, exact f32 fma chains -- for comparison with the split
           # arithmetic of the headline path

@@ -691,24 +691,28 @@ __device__ __forceinline__ void gemm_sm3_pl(const Ctx &c, const float *__restric
   };
   const int last = kb32 - 1;
   if constexpr (MT == 1) {
-    u32x4 bs[2][NT][3];
-    auto load_b = [&](int buf, int kb, int t) {
+    // ONE rolling set of B fragments: the moment a tile's six MFMAs of a tap step have issued, its registers are refilled
+    // with the same tile's planes of the NEXT tap step, which then have the other tiles' MFMAs to arrive (two full sets
+    // were 96 registers at four tiles: spills inside the loop)
+    u32x4 bs[NT][3];
+    auto load_b1 = [&](int q, int kb, int t) {
 #pragma unroll
-      for (int q = 0; q < NT; ++q)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bs[buf][q][pl] = pl3[(kb * 3 + pl) * G::kPlaneU4 + 16 * q + 4 * t];
+      for (int pl = 0; pl < 3; ++pl) bs[q][pl] = pl3[(kb * 3 + pl) * G::kPlaneU4 + 16 * q + 4 * t];
     };
-    load_b(0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) load_b1(q, 0, 0);
     first_a();
-    // st: tap step inside a trip of two blocks (0..5); B set st & 1, A set = tap
+    // st: tap step inside a trip of two blocks (0..5); A set = tap
     auto step = [&](int st, int kb0) {
       const int t = st % 3, kb = kb0 + st / 3;
-      const int nt = (st + 1) % 3, nkb = kb0 + (st + 1) / 3;
-      load_b((st + 1) & 1, nkb < last ? nkb : last, nt);
-      __builtin_amdgcn_sched_barrier(0);
+      const int nt = (st + 1) % 3, nkb0 = kb0 + (st + 1) / 3, nkb = nkb0 < last ? nkb0 : last;
 #pragma unroll
-      for (int q = 0; q < NT; ++q) acc[0][q] = mfma_split6(a[t][0], bs[st & 1][q], acc[0][q]);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int q = 0; q < NT; ++q) {
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][q] = mfma_split6(a[t][0], bs[q], acc[0][q]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b1(q, nkb, nt);
+      }
       load_a(t, t, kb < last ? kb + 1 : last);
     };
     if (kb32 == 1) {
@@ -1940,15 +1944,20 @@ __device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv, int C) 
   using G = PG<16>;
   lds_f *q3 = (lds_f *)qkv;
   const int t = c.tid;
-  {   // keys
+  // Addresses are formed once per phase: a row's swizzle (pswz: the column's bits 4-5 XOR bits 3-4 of the row) is constant
+  // over the 8 rows of an octet and over rows 32 apart, so everything below is a lane base plus immediates.
+  {   // keys: row = 128 + 32 rd + 4 wave + rs, rd = 0..3; swizzle = (wave >> 1) & 3 whatever rd
     const int rs = c.lane >> 4, T = (c.lane >> 2) & 3, s = c.lane & 3;
+    const int base = (kHidden + 4 * c.wave + rs) * 64 + ((16 * T) ^ (((c.wave >> 1) & 3) << 4)) + s;
+    int off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) off[j] = base + ((4 * j + 4 * rs) & 12);   // rotated walk of the tile's positions
 #pragma unroll
     for (int rd = 0; rd < 4; ++rd) {
-      const int row = kHidden + 32 * rd + 4 * c.wave + rs;
       float k[4], km = -3.0e38f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        k[j] = q3[pswz(row, 16 * T + 4 * ((j + rs) & 3) + s)];
+        k[j] = q3[off[j] + 2048 * rd];
         km = fmaxf(km, k[j]);
       }
       km = fmaxf(km, dpp_mov<0x124>(km));   // the other three tiles: row_ror 4, 8
@@ -1963,18 +1972,18 @@ __device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv, int C) 
       ks += dpp_mov<0x128>(ks);
       const float inv = __builtin_amdgcn_rcpf(ks);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q3[pswz(row, 16 * T + 4 * ((j + rs) & 3) + s)] = k[j] * inv;
+      for (int j = 0; j < 4; ++j) q3[off[j] + 2048 * rd] = k[j] * inv;
     }
   }
-  {   // queries
+  {   // queries: item = 128 rd + (t >> 2): head 2 rd + (t >> 8), column (t >> 2) & 63, channel quarter t & 3
+    const int qt = t & 3, col = (t >> 2) & 63;
+    const int base = ((t >> 8) * kDimHead + 8 * qt) * 64 + (col ^ (qt << 4));
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
-      const int item = rd * 128 + (t >> 2), qt = t & 3, h = item >> 6, col = item & 63;
-      const int row0 = h * kDimHead + 8 * qt;
       float q[8], qm = -3.0e38f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        q[j] = q3[pswz(row0 + j, col)];
+        q[j] = q3[base + 64 * j + 4096 * rd];
         qm = fmaxf(qm, q[j]);
       }
       qm = fmaxf(qm, dpp_mov<0xB1>(qm));
@@ -1989,31 +1998,41 @@ __device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv, int C) 
       qs += dpp_mov<0x4E>(qs);
       const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(qs);  // dim_head ** -0.5 / sum
 #pragma unroll
-      for (int j = 0; j < 8; ++j) q3[pswz(row0 + j, col)] = q[j] * sc;
+      for (int j = 0; j < 8; ++j) q3[base + 64 * j + 4096 * rd] = q[j] * sc;
     }
   }
   __syncthreads();
   const int m = c.lane & 15, kq = c.lane >> 4;
+  const int h = c.wave >> 1;   // the wave's two (head, sample) pairs: head h, samples 2 (wave & 1) + e
   f32x4 o[2][2];
+  {
+    const int qrow = (h * kDimHead + kq) * 64, krow = qrow + kHidden * 64;
+    const int vrow = (2 * kHidden + h * kDimHead + m) * 64;
+    const int vx0 = 16 * (kq ^ (m >> 3)), vx1 = 16 * (kq ^ (2 + (m >> 3)));   // rows m and 16 + m: swizzled tile of key position 4 kq + r
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int pair = 2 * c.wave + e, h = pair >> 2, s = pair & 3;
-    f32x4 am = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 2; ++e) {
+      const int cm = 4 * m + 2 * (c.wave & 1) + e;
+      int cx[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {  // channel d = 4 j + kq
-      const float ka = q3[pswz(kHidden + h * kDimHead + 4 * j + kq, 4 * m + s)];   // Kn^T[key position m][d]
-      const float qb = q3[pswz(h * kDimHead + 4 * j + kq, 4 * m + s)];             // Qn[d][query position m]
-      am = __builtin_amdgcn_mfma_f32_16x16x4f32(ka, qb, am, 0, 0, 0);
-    }
-    // am: lane (query position m, kq), register r = A[key position 4 kq + r][m]
-    o[e][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    o[e][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int x = 0; x < 4; ++x) cx[x] = cm ^ (x << 4);
+      f32x4 am = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {  // k-step r: key positions 4 kq + r
-      const float v0 = q3[pswz(2 * kHidden + h * kDimHead + m, 4 * (4 * kq + r) + s)];
-      const float v1 = q3[pswz(2 * kHidden + h * kDimHead + 16 + m, 4 * (4 * kq + r) + s)];
-      o[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, am[r], o[e][0], 0, 0, 0);
-      o[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, am[r], o[e][1], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) {  // channel d = 4 j + kq: rows 4 j + kq of the head, swizzle (j >> 1) & 3
+        const float ka = q3[krow + 256 * j + cx[(j >> 1) & 3]];   // Kn^T[key position m][d]
+        const float qb = q3[qrow + 256 * j + cx[(j >> 1) & 3]];   // Qn[d][query position m]
+        am = __builtin_amdgcn_mfma_f32_16x16x4f32(ka, qb, am, 0, 0, 0);
+      }
+      // am: lane (query position m, kq), register r = A[key position 4 kq + r][m]
+      o[e][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      o[e][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int sv = 2 * (c.wave & 1) + e;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // k-step r: key positions 4 kq + r
+        const float v0 = q3[vrow + vx0 + 4 * r + sv];
+        const float v1 = q3[vrow + 16 * 64 + vx1 + 4 * r + sv];
+        o[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, am[r], o[e][0], 0, 0, 0);
+        o[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, am[r], o[e][1], 0, 0, 0);
+      }
     }
   }
   __syncthreads();  // all reads of q, k, v are done
@@ -3414,7 +3433,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
                              : (L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s)));
   if (stamp) {
     static long long host[kMaxOps + 2];
-    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "", "OUTLN", "QKVAT"};
+    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "QKVLN", "OUTLN", "QKVAT"};
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(host, dstamps, sizeof(host), hipMemcpyDeviceToHost);
     // the tape is rebuilt on the host only to label the stamps
@@ -3432,9 +3451,10 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
     for (int lv = 0; lv < a.d.n_levels; ++lv) {
       const int C = dims[lv];
       resblock(C); resblock(C);
-      if (pm) line(7, C, 384, 1);
+      if (pm16) { line(5, C, 384, 1); line(4, C, 128, 0); }
+      else if (pm) line(7, C, 384, 1);
       else { line(3, C, C, 0); line(1, C, 192, 1); line(4, C, 64, 0); line(1, C, 192, 1); line(4, C, 64, 0); }
-      if (pm && (C == 4 || C == 32 || C == 64 || C == 128)) line(6, 128, C, 1);
+      if (pm && (C == 4 || C == 16 || C == 32 || C == 64 || C == 128)) line(6, 128, C, 1);
       else { line(1, 128, C, 1); line(3, C, C, 0); }
       line(1, C, dims[lv + 1], 3);
     }
