@@ -49,6 +49,7 @@ _SIGNATURES = {
     "gldm_pointwise_mlp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_pointwise_mlp2": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_pointwise_small": [_vp, _vp, _vp, _i, _i, _i, ctypes.c_longlong, _i, _vp, _vp],
+    "gldm_pointwise_any": [_vp, _vp, _vp, _i, _i, _i, ctypes.c_longlong, _i, _vp, _vp],
     "gldm_linear_rows": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp_bf16x3": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_pointwise_mlp2_bf16x3": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],

@@ -749,6 +749,70 @@ __global__ __launch_bounds__(256) void pointwise_small_kernel(const float *__res
   }
 }
 
+// ---- any-shape k = 1 conv (SharedMLP / feature-propagation layers outside the fused launches' shape sets) --------------
+// y[b, co, i] = act(bias[co] + sum_ci W[co][ci] x[b, ci, i]) for ANY (cin, cout, n), weights as stored by nn.Conv1d
+// ([cout][cin], BatchNorm folded by the caller): exact f32 products on v_mfma_f32_16x16x4_f32.  A 256-thread workgroup
+// owns a 64-row x 64-point output tile (wave = m-tile, four n-tiles); K is staged 16 channels at a time through LDS with
+// bounds masks (W rows padded to 17 words, x rows to 80: both fragment reads conflict free).  Replaces the library GEMM
+// (rocBLAS / MIOpen through F.conv1d) + bias / activation pass these layers used to take: PointNet++ / PVCNN2 widths such
+// as 384 -> 256 over 128 centres.  Not a speed-of-light kernel (one 16-deep stage per barrier pair); the shipped encoder
+// never comes here.
+__global__ __launch_bounds__(256) void pointwise_any_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, int cin, int cout, long long n,
+                                                            int relu, float *__restrict__ y) {
+  __shared__ float Ws[64 * 17];
+  __shared__ float Xs[16 * 80];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, kq = lane >> 4;
+  const long long c0 = (long long)blockIdx.x * 64;
+  const int r0 = blockIdx.y * 64, b = blockIdx.z;
+  x += (size_t)b * cin * n;
+  y += (size_t)b * cout * n;
+  f32x4 acc[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wr = tid >> 2, wk = (tid & 3) * 4;          // W stage: row, first k of the thread's four
+  const int xk = tid >> 4, xc = (tid & 15) * 4;         // x stage: channel, first point of the thread's four
+  for (int k0 = 0; k0 < cin; k0 += 16) {
+    float wv[4], xv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool okw = r0 + wr < cout && k0 + wk + q < cin;
+      wv[q] = okw ? w[(size_t)(r0 + wr) * cin + k0 + wk + q] : 0.f;
+      const bool okx = k0 + xk < cin && c0 + xc + q < n;
+      xv[q] = okx ? x[(size_t)(k0 + xk) * n + c0 + xc + q] : 0.f;
+    }
+    __syncthreads();   // the previous stage's readers are done
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Ws[wr * 17 + wk + q] = wv[q];
+      Xs[xk * 80 + xc + q] = xv[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = Ws[(16 * wave + col) * 17 + 4 * j + kq];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Xs[(4 * j + kq) * 80 + 16 * ni + col], acc[ni], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = r0 + 16 * wave + 4 * kq + r;
+    if (row < cout) {
+      const float bv = bias ? bias[row] : 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const long long i = c0 + 16 * ni + col;
+        if (i < n) {
+          const float v = acc[ni][r] + bv;
+          y[(size_t)row * n + i] = relu ? fmaxf(v, 0.f) : v;
+        }
+      }
+    }
+  }
+}
+
 // y[row, o] = bias[o] + sum_n W[o, n] x[row, n]: one workgroup per row (rows = batch x channels: a few hundred),
 // the row staged in LDS, thread = output feature, four interleaved k-ordered fma chains.
 __global__ __launch_bounds__(256) void linear_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
@@ -983,6 +1047,16 @@ GLDM_API int gldm_pointwise_small(const float *x, const float *w, const float *b
   GLDM_PS_CASE(3) GLDM_PS_CASE(6) GLDM_PS_CASE(16) GLDM_PS_CASE(24) GLDM_PS_CASE(32) GLDM_PS_CASE(48) GLDM_PS_CASE(64)
 #undef GLDM_PS_CASE
   return GLDM_ERR_UNSUPPORTED;
+}
+
+GLDM_API int gldm_pointwise_any(const float *x, const float *w, const float *bias, int b, int cin, int cout, long long n,
+                                int relu, float *y, gldm_stream_t stream) {
+  if (!x || !w || !y || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
+  const long long tiles = (n + 63) / 64;
+  if (tiles > 0x7fffffffLL || b > 65535 || (cout + 63) / 64 > 65535) return GLDM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pointwise_any_kernel, dim3((unsigned)tiles, (cout + 63) / 64, b), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, w, bias, cin, cout, n, relu, y);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 
 GLDM_API int gldm_linear_rows(const float *x, const float *w, const float *bias, int rows, int n, int nout, float *y,

@@ -1,21 +1,12 @@
-"""Dense k = 1 layers of the point-cloud encoders.  On the shipped PVCNN encoder every one of them is a hand-written
-launch: the wide SharedMLP layers + head (gldm_pointwise_mlp*: MFMA GEMMs, the 768 -> 1536 one on split-bf16 operands),
-the narrow point-branch convs (gldm_pointwise_small) and the Linear over the point axis (gldm_linear_rows).  Layer shapes
-outside those kernels' sets (PVCNN2 / PointNet++ widths such as 64 -> 128 over a few hundred centres) are one library
-GEMM + the fused bias/activation pass.  Voxel convs have no library path at all (csrc/voxel_conv.hip, with a direct VALU
-kernel for shapes without an MFMA instantiation).  Never a CPU path: CPU tensors are rejected like everywhere else in
-this package.
+"""Dense k = 1 layers of the point-cloud encoders: every one of them a hand-written launch, on every encoder.  Shipped
+PVCNN encoder: the wide SharedMLP layers + head (gldm_pointwise_mlp*: MFMA GEMMs, the 768 -> 1536 one on split-bf16
+operands), the narrow point-branch convs (gldm_pointwise_small) and the Linear over the point axis (gldm_linear_rows).
+Layer shapes outside those kernels' sets (PVCNN2 / PointNet++ widths such as 384 -> 256 over 128 centres) run in the
+any-shape f32-MFMA kernel (gldm_pointwise_any); since round 4 nothing here reaches rocBLAS / MIOpen, and the package no
+longer sets MIOPEN_FIND_MODE.  Voxel convs have no library path either (csrc/voxel_conv.hip, with a direct VALU kernel
+for shapes without an MFMA instantiation).  Never a CPU path: CPU tensors are rejected like everywhere else in this package.
 """
-import os
-
-# The k = 1 convolutions go to MIOpen, whose default "find" benchmarks every solver (including a naive
-# reference kernel) on the first call of each new shape: ~7 s of GPU time for the encoder's shapes.  The fast
-# mode picks the same rocBLAS GEMM solver here without the search.  Set before MIOpen initialises; a value
-# the user exported wins.
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
-
-import torch  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
+import torch
 
 
 def _need_cuda(x, name="input"):
@@ -33,33 +24,20 @@ SMALL_CIN = (3, 6, 16, 24, 32, 48, 64)   # widths gldm_pointwise_small is instan
 
 def _gemm_bias_act(x, w2d, bias, relu):
     """act(W x + b) over [B, Cin, ...].  Narrow inputs (cin in SMALL_CIN: the PVConv point branches of the shipped
-    encoder) run in the hand-written lane-per-point kernel (gldm_pointwise_small); wider layers that the fused
-    MFMA launches are not built for (PVCNN2 / PointNet++ shapes outside the shipped encoder) are one library GEMM (the
-    k = 1 convolution without bias) + ONE in-place epilogue pass (gldm_bias_act)."""
+    encoder) run in the hand-written lane-per-point kernel (gldm_pointwise_small); every other shape the fused MFMA
+    launches are not built for (PVCNN2 / PointNet++ widths outside the shipped encoder) in the any-shape f32-MFMA kernel
+    (gldm_pointwise_any: GEMM + bias + activation in one launch).  No library GEMM."""
     from . import _lib as L
     shape = x.shape
-    x3 = x.reshape(shape[0], shape[1], -1)
-    if shape[1] in SMALL_CIN and x3.is_contiguous():
-        n = x3.shape[-1]
-        y = torch.empty((shape[0], w2d.shape[0], n), dtype=torch.float32, device=x.device)
-        wc = w2d.contiguous()
-        bc = bias.contiguous() if bias is not None else None
-        with torch.cuda.device(x.device):
-            L.call("gldm_pointwise_small", L.ptr(x3), L.ptr(wc), L.ptr(bc), int(shape[0]), int(shape[1]),
-                   int(w2d.shape[0]), n, int(relu), L.ptr(y), L.current_stream(x.device))
-        return y.reshape(shape[0], w2d.shape[0], *shape[2:])
-    y = F.conv1d(x3, w2d.unsqueeze(-1))
-    n = y.shape[-1]
-    if bias is not None or relu:
-        if n % 4 == 0 and y.is_contiguous():
-            b = bias if bias is not None else torch.zeros(w2d.shape[0], dtype=y.dtype, device=y.device)
-            L.call("gldm_bias_act", L.ptr(y), L.ptr(b.contiguous()), int(y.shape[0]), int(y.shape[1]), n, int(relu),
-                   L.current_stream(y.device))
-        else:
-            if bias is not None:
-                y = y + bias.view(1, -1, 1)
-            if relu:
-                y = torch.relu_(y)
+    x3 = x.reshape(shape[0], shape[1], -1).contiguous()
+    n = x3.shape[-1]
+    y = torch.empty((shape[0], w2d.shape[0], n), dtype=torch.float32, device=x.device)
+    wc = w2d.contiguous()
+    bc = bias.contiguous() if bias is not None else None
+    entry = "gldm_pointwise_small" if shape[1] in SMALL_CIN else "gldm_pointwise_any"
+    with torch.cuda.device(x.device):
+        L.call(entry, L.ptr(x3), L.ptr(wc), L.ptr(bc), int(shape[0]), int(shape[1]), int(w2d.shape[0]), n, int(relu),
+               L.ptr(y), L.current_stream(x.device))
     return y.reshape(shape[0], w2d.shape[0], *shape[2:])
 
 
@@ -182,4 +160,7 @@ def linear(x, lin):
             L.call("gldm_linear_rows", L.ptr(xf), L.ptr(w), L.ptr(lin.bias), rows, n, nout, L.ptr(y),
                    L.current_stream(x.device))
         return y
-    return F.linear(x, lin.weight, lin.bias)
+    # other row lengths: the same product as a k = 1 conv over the transposed rows (gldm_pointwise_any), rare
+    xt = x.reshape(-1, n).float().t().contiguous().unsqueeze(0)                     # [1, n, rows]
+    yt = _gemm_bias_act(xt, lin.weight.float(), lin.bias, False)                      # [1, nout, rows]
+    return yt[0].t().reshape(*x.shape[:-1], nout).contiguous()

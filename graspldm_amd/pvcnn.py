@@ -12,7 +12,6 @@ import functools
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as TF
 
 from . import _lib as L
 from . import dense
@@ -271,13 +270,22 @@ class SE3d(nn.Module):
                                 nn.Linear(channel // reduction, channel, bias=False), nn.Sigmoid())
         self.use_relu = use_relu
 
-    def gate(self, mean):
-        h = TF.linear(mean, self.fc[0].weight)
-        h = torch.relu(h) if self.use_relu else h * torch.sigmoid(h)
-        return torch.sigmoid(TF.linear(h, self.fc[2].weight))
+    def gate(self, chan_sum, r):
+        """sigmoid(W2 act(W1 mean)) from the per-channel SUMS over the r^3 voxels [B, C]: one launch (gldm_se_gate)."""
+        if not chan_sum.is_cuda:
+            raise RuntimeError("SE3d runs on the GPU only (graspldm_amd has no CPU path)")
+        w1, w2 = self.fc[0].weight, self.fc[2].weight
+        b, c = chan_sum.shape
+        gate = torch.empty((b, c), dtype=torch.float32, device=chan_sum.device)
+        with torch.cuda.device(chan_sum.device):
+            L.call("gldm_se_gate", L.ptr(chan_sum.contiguous().float()), L.ptr(w1), L.ptr(w2), b, c, w1.shape[0], int(r),
+                   1 if self.use_relu else 0, L.ptr(gate), L.current_stream(chan_sum.device))
+        return gate
 
     def forward(self, inputs):
-        return inputs * self.gate(inputs.mean(dim=(2, 3, 4))).view(inputs.shape[0], inputs.shape[1], 1, 1, 1)
+        """se.py:12-25 on [B, C, r, r, r] (inside PVConv the gate is folded into the devoxelize pass instead)."""
+        g = self.gate(inputs.sum(dim=(2, 3, 4)), inputs.shape[-1])
+        return inputs * g.view(inputs.shape[0], inputs.shape[1], 1, 1, 1)
 
 
 class PVConv(nn.Module):

@@ -314,6 +314,13 @@ int gldm_pointwise_mlp2(const float *x /*[b,cin0,n]*/, const float *w0_packed, c
 int gldm_pointwise_small(const float *x /*[b,cin,n]*/, const float *w /*[cout,cin]*/, const float *bias /*[cout] or NULL*/,
                          int b, int cin, int cout, long long n, int relu, float *y /*[b,cout,n]*/, gldm_stream_t stream);
 
+/* ref: the same module for EVERY other shape (ext/pvcnn/modules/shared_mlp.py:6-35, ext/pvcnn/modules/pointnet.py:117-135:
+ * the feature-propagation SharedMLPs of PointNet++ / PVCNN2, e.g. 384 -> 256 over 128 centres): any cin, cout, n; weights
+ * [cout][cin] as stored (BatchNorm folded by the caller), exact f32 products on the f32 matrix pipe, 64 x 64 output tiles.
+ * These layers went to the GEMM library (rocBLAS / MIOpen through F.conv1d) + gldm_bias_act before ABI 7. */
+int gldm_pointwise_any(const float *x /*[b,cin,n]*/, const float *w /*[cout,cin]*/, const float *bias /*[cout] or NULL*/,
+                       int b, int cin, int cout, long long n, int relu, float *y /*[b,cout,n]*/, gldm_stream_t stream);
+
 /* ref: pc_encoders.py:60-82,104-111: out_layer[1] = nn.Linear(n_points, latent) applied over the POINT axis of
  * [B, C, N]: y[row, :] = W x[row, :] + bias for rows = B * C; n % 4 == 0, n <= 16384. */
 int gldm_linear_rows(const float *x /*[rows,n]*/, const float *w /*[nout,n]*/, const float *bias /*[nout] or NULL*/,
