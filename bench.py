@@ -473,8 +473,10 @@ def main():
           for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_point_ops_pmc.json")), reverse=True):
               rec = json.load(open(pmc_path)).get("sa_group_kernel")
               if rec and rec.get("clouds") == B:
-                  sa_traffic = rec["fetch_bytes_corrected"] + rec["write_bytes"]
-                  sa_src = "static: " + os.path.relpath(pmc_path, ROOT) + " (rocprofv3 --pmc passes, tools/pmc_point_ops.sh)"
+                  sa_traffic = rec["fetch_bytes_raw"] + rec["write_bytes"]
+                  sa_src = ("static: " + os.path.relpath(pmc_path, ROOT) + " (rocprofv3 --pmc passes of tools/run_sa_once.py, tools/pmc_kernels.sh; "
+                            "FETCH_SIZE as reported: the reads are 4-byte gathers, for which the gfx950 doubling is not calibrated -- "
+                            f"doubled, the total is {rec['fetch_bytes_corrected'] + rec['write_bytes']} bytes)")
                   break
           kernels.append(dict(kernel="sa_group_kernel (PointNet2SSG SA2 gather: N=512 M=128 U=64 C=128)", bound="hbm",
                               avg_ms=t_sa * 1e3, achieved=by / t_sa / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",

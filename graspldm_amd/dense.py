@@ -133,13 +133,13 @@ def folded_conv_bn(conv, bn, device):
 
 def pointwise_conv_bn_relu(x, conv, bn):
     """relu(BN_eval(conv(x))) with BN folded into the weights: y = relu(W' x + b').  Wide layers (cin % 32 == 0,
-    cout % 256 == 0) run as ONE hand-written launch (GEMM + bias + ReLU in the native layout); the others as a
-    library GEMM + the fused bias/ReLU pass."""
+    cout % 256 == 0) run as ONE hand-written MFMA launch (GEMM + bias + ReLU in the native layout); the others in the
+    narrow lane-per-point kernel or the any-shape f32-MFMA kernel (_gemm_bias_act)."""
     _need_cuda(x)
     w, b, wp, ws = folded_conv_bn(conv, bn, x.device)
     x = x.float()
     if wp is not None and fused_mlp_supported(x, w.shape[1], w.shape[0]):
-        if ws is not None:
+        if ws is not None and split_supported(w.shape[1]):   # (narrow layers keep split fragments as FRONT layers only)
             return pointwise_mlp(x, ws, b, w.shape[0], True, split=True)[0]
         return pointwise_mlp(x, wp, b, w.shape[0], True)[0]
     return _gemm_bias_act(x, w, b, True)

@@ -101,9 +101,11 @@ class PVCNNEncoder(nn.Module):
         key = params_key([cd.weight, cd.bias, o0.weight, o0.bias], cd.weight.device)
         hit = self.__dict__.get("_head_cache")
         if hit is None or hit[0] != key:
-            wo, wd = o0.weight[:, :, 0].double(), cd.weight[:, :, 0].double()
-            w = (wo @ wd).float().contiguous()
-            b = (wo @ cd.bias.double() + o0.bias.double()).float().contiguous()
+            # folded on the HOST (f64 there; on the device this product was the path's last library GEMM, once per weight version)
+            dev = cd.weight.device
+            wo, wd = o0.weight[:, :, 0].detach().double().cpu(), cd.weight[:, :, 0].detach().double().cpu()
+            w = (wo @ wd).float().contiguous().to(dev)
+            b = (wo @ cd.bias.detach().double().cpu() + o0.bias.detach().double().cpu()).float().contiguous().to(dev)
             hit = (key, w, b)
             self.__dict__["_head_cache"] = hit
             publish(cd.weight.device)

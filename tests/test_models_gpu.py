@@ -602,3 +602,18 @@ def test_dense_layers_make_no_library_call():
         h = h * torch.sigmoid(h)
         exp_se = v * torch.sigmoid(h @ se.fc[2].weight.T).view(2, 32, 1, 1, 1)
         assert _err(se.cuda()(v.cuda()), exp_se) < 2e-6
+
+
+def test_standalone_wide_layer_with_narrow_input_runs_the_f32_launch():
+    """A SharedMLP layer with cin % 32 == 0, cin < 128 and cout % 256 == 0 (PVCNN at half width: 64 -> 256) keeps split
+    fragments only for use as a FRONT layer; on its own it runs the f32 MFMA launch (the split launch needs cin % 128 == 0)."""
+    import torch.nn as nn
+    from graspldm_amd import dense
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 64, 1024, generator=g)
+    conv, bn = nn.Conv1d(64, 256, 1), nn.BatchNorm1d(256)
+    conv.eval(), bn.eval()
+    with torch.no_grad():
+        exp = torch.relu(bn(conv(x)))
+        got = dense.pointwise_conv_bn_relu(x.cuda(), conv.cuda(), bn.cuda())
+    assert _err(got, exp) < 2e-5

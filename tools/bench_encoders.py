@@ -101,7 +101,13 @@ def main():
         models = {k: v for k, v in models.items() if k == args.only}
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "encoder_flops.json")) as f:
         flops = {k: v["flop_per_cloud"] for k, v in json.load(f)["models"].items()}
-    PEAK = 157.3
+    PEAK = 157.3                      # f32 MFMA, dense
+    PEAK_SPLIT = 2500.0 / 6           # f32 products as six bf16 partial products on the bf16 matrix pipe
+    # Executed FLOP per cloud by the pipe they run on, where part of a model runs as split-bf16 products: the shipped
+    # PVCNNEncoder (768 -> 1536 layer + its 96 -> 768 front layer + the 48 / 96-channel voxel convs; head convs folded into
+    # one 1536 -> 3 GEMM: 2.4 GFLOP of the reference graph never executed).  Every other model here runs on the f32 pipe.
+    split_exec = {"PVCNNEncoder(fpc)": (2 * 1024 * (96 * 768 + 768 * 1536) + 2 * 27 * (48 * 48 * 24 ** 3 + 48 * 96 * 12 ** 3 + 96 * 96 * 12 ** 3),
+                                        8.115050112e9 - 2 * 768 * 1536 * 1024 - 2 * 3 * 768 * 1024 + 2 * 3 * 1536 * 1024)}
     results = {}
     for name, m in models.items():
         load_synthetic_weights(m, seed=0)
@@ -111,12 +117,22 @@ def main():
             fl = flops.get(name) if args.points == 1024 else None
             r["reference_gflop_per_cloud"] = fl / 1e9 if fl else None
             r["achieved_tflops"] = fl * b / (r["avg_latency_ms"] * 1e-3) / 1e12 if fl else None
-            r["frac_f32_mfma_peak"] = r["achieved_tflops"] / PEAK if fl else None
+            # fraction of the peak of the pipe(s) the model runs on: never above 1 (a split-bf16 kernel rated against the f32
+            # peak read 1.6 in round 3).  Mixed models: executed FLOP / the time every GEMM would take at its own pipe's peak.
+            if fl and name in split_exec and args.points == 1024:
+                f_split, f_exec = split_exec[name]
+                t_floor = b * (f_split / (PEAK_SPLIT * 1e12) + (f_exec - f_split) / (PEAK * 1e12))
+                r["executed_gflop_per_cloud"] = f_exec / 1e9
+                r["frac_of_pipe_peak"] = t_floor / (r["avg_latency_ms"] * 1e-3)
+                r["pipes"] = "split-bf16 (2500 / 6 TFLOP/s) + f32 MFMA (157.3), time-weighted"
+            else:
+                r["frac_of_pipe_peak"] = r["achieved_tflops"] / PEAK if fl else None
+                r["pipes"] = "f32 MFMA (157.3 TFLOP/s)"
             print(f"{name:18s} B={b:4d}  avg {r['avg_latency_ms']:8.3f} ms  p95 {r['p95_latency_ms']:8.3f}  "
                   f"{r['throughput_samples_per_sec']:10.1f} clouds/s  peak {r['peak_memory_mb']:8.1f} MB", flush=True)
     ref = "PVCNN" if "PVCNN" in results else next(iter(results))
     lines = ["| Batch Size | Model | Avg Latency (ms) | P95 (ms) | P99 (ms) | Throughput (clouds/s) | Peak Memory (MB) | "
-             "Relative Speedup | Parameters (MB) | GFLOP / cloud (reference graph) | TFLOP/s | of f32 MFMA peak |",
+             "Relative Speedup | Parameters (MB) | GFLOP / cloud (reference graph) | TFLOP/s (reference FLOP) | of the peak of the pipe(s) it runs on |",
              "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for b in args.batch_sizes:
         for name, res in results.items():
@@ -124,7 +140,7 @@ def main():
             lines.append(f"| {b} | {name} | {r['avg_latency_ms']:.3f} | {r['p95_latency_ms']:.3f} | {r['p99_latency_ms']:.3f} | "
                          f"{r['throughput_samples_per_sec']:.1f} | {r['peak_memory_mb']:.1f} | "
                          f"{results[ref][b]['avg_latency_ms'] / r['avg_latency_ms']:.2f}x | {r['model_parameters_mb']:.1f} | "
-                         + (f"{r['reference_gflop_per_cloud']:.3f} | {r['achieved_tflops']:.2f} | {100 * r['frac_f32_mfma_peak']:.1f} % |"
+                         + (f"{r['reference_gflop_per_cloud']:.3f} | {r['achieved_tflops']:.2f} | {100 * r['frac_of_pipe_peak']:.1f} % |"
                             if r.get("achieved_tflops") else "- | - | - |"))
     table = "\n".join(lines)
     print(table)

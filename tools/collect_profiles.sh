@@ -27,3 +27,11 @@ cp gpurun_out/pmc_$tag.json $out/${tag}_denoise_pmc.json
 cp gpurun_out/pmc_$tag.txt $out/${tag}_denoise_pmc_counters.txt
 rm -rf $out/prof_s1
 head -c 600 $out/${tag}_bench.json; echo; head -c 300 $out/${tag}_bench_c5.json; echo; head -5 $out/${tag}_bench_streams1_kernel_stats.csv | cut -c1-160
+# round 4 additions: the ppc experiment, the decoder alone, the set-abstraction kernels and the encoder kernels under counters
+cd $root
+python bench.py --experiment ppc --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_ppc.json 2>> $out/bench.err
+bash tools/pmc_kernels.sh ${tag}_sa tools/run_sa_once.py 256 > $out/pmck_sa.log 2>&1
+cp gpurun_out/pmck_${tag}_sa.json $out/${tag}_point_ops_pmc_raw.json
+bash tools/prof_kernels.sh ${tag}_enc tools/bench_encoders.py --shipped --only "PVCNNEncoder(fpc)" --batch-sizes 256 --iterations 5 > $out/${tag}_encoder_kernels.txt 2>&1
+bash tools/prof_kernels.sh ${tag}_ssg tools/bench_encoders.py --only PointNet2 --batch-sizes 256 --iterations 5 > $out/${tag}_shootout_ssg_kernels.txt 2>&1
+bash tools/prof_kernels.sh ${tag}_pvcnn2 tools/bench_encoders.py --only PVCNN2 --batch-sizes 256 --iterations 5 > $out/${tag}_shootout_pvcnn2_kernels.txt 2>&1
