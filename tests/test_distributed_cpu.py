@@ -175,3 +175,6 @@ def test_bench_workload_label_follows_arguments():
     assert "configs[4]" in b.workload_label(8, 200, 4096, 1000, "ddpm")
     assert "configs[2]" not in b.workload_label(8, 200, 4096, 1000, "ddpm")
     assert "custom" in b.workload_label(256, 20, 1024, 50, "ddim")
+    assert "ppc_1a" in b.workload_label(256, 20, 1024, 1000, "ddpm", "ppc") and "not a BASELINE.json configuration" in b.workload_label(256, 20, 1024, 1000, "ddpm", "ppc")
+    assert b.denoiser_executed_mfma_flop_fpc() == 6193152 and 0.7 < b.denoiser_executed_mfma_flop_fpc() / b.DENOISER_FLOP_PER_LATENT_STEP < 0.9
+    assert 0.9 < b.denoiser_executed_mfma_flop_l16() / b.DENOISER_FLOP_PER_LATENT_STEP_PPC < 1.3

@@ -243,3 +243,33 @@ def test_conv3d_split_packing_walks_tap_pairs():
     # the empty half of the last pair
     assert (f[:, 13, :, 32:, :] == 0).all() and (f[:, 27, :, 32:, :] == 0).all()
     assert split_conv_supported(48, 48, 24) and split_conv_supported(96, 96, 12) and not split_conv_supported(3, 48, 24)
+
+
+def test_pad_cin32_and_16_position_descriptors():
+    """16-channel levels of the 64-column engines read one zero-padded 32-channel block of planes: the packer pads every
+    tap's channels to 32 with zero weights (r1d_pack.pad_cin32) and provides every split-bf16 copy for both 16-position
+    nets of the shipped experiments (pose decoder, ppc denoiser), which then run on 64-column tiles."""
+    import ctypes
+    from graspldm_amd import _lib
+    from graspldm_amd.pipeline import build_fpc_ldm
+    from graspldm_amd.r1d_pack import pack_resnet1d, pad_cin32
+    w = torch.arange(2 * 3 * 16, dtype=torch.float32).reshape(2, 48)          # [cout 2, taps 3 x cin 16]
+    p = pad_cin32(w, 16, 3)
+    assert p.shape == (2, 96)
+    assert torch.equal(p.reshape(2, 3, 32)[:, :, :16], w.reshape(2, 3, 16)) and p.reshape(2, 3, 32)[:, :, 16:].abs().sum() == 0
+    assert pad_cin32(torch.ones(4, 64), 64, 1).shape == (4, 64)                # multiples of 32 pass through
+    ldm = build_fpc_ldm(device=None, latent=16, pc_latent=256)
+    den = ldm.diffusion_model.model
+    sd = {k: v.detach().float().cpu() for k, v in den.state_dict().items()}
+    d = pack_resnet1d(sd, "", groups=den.groups, seq_len=16, num_steps=1000)["desc"]
+    assert list(d.dims)[:5] == [16, 32, 64, 128, 256] and d.emb_dim == 64 and d.seq_len == 16
+    assert all(d.rb[i].c1_w3 > 0 and d.rb[i].c2_w3 > 0 for i in range(2 * d.n_levels + 1))
+    assert all(d.lv[i].qkvn_w3 > 0 and d.lv[i].out_w3 > 0 and d.lv[i].down_w3 > 0 for i in range(d.n_levels))
+    ptr = ctypes.cast(ctypes.pointer(d), ctypes.c_void_p)
+    assert _lib.lib().gldm_r1d_tile_columns(ptr) == 64
+    n = 10   # 3 tiles of 4 samples; no decoder table; park scratch for the 256-channel level
+    assert _lib.lib().gldm_r1d_workspace_bytes(ptr, n) == (256 + 3 * 64 * 8 + 255) // 256 * 256 + 3 * 65536
+    keep = d.rb[0].c1_w3
+    d.rb[0].c1_w3 = 0   # a packer without the padded 16-channel copies -> the sample-major f32 engine
+    assert _lib.lib().gldm_r1d_tile_columns(ptr) == 32
+    d.rb[0].c1_w3 = keep
