@@ -69,5 +69,14 @@ class GraspLatentDDM(nn.Module):
             steps.append([t.detach().cpu() for t in o])
         return final, steps
 
+    def check_engines(self):
+        """Raise GldmError if any fused denoise launch so far lost a step-segment hand-off between workgroups (its latents
+        are NaN then): the synchronising form of the check every launch makes without a host sync.  The inference harness
+        calls the same check before results leave the device; direct callers of generate_grasps call this."""
+        denoiser = self.diffusion_model.net if self.is_elucidated_diffusion else self.diffusion_model.model
+        eng = getattr(denoiser, "_engine", None)
+        if eng is not None:
+            eng.check()
+
     def forward(self, *a, **k):
         raise NotImplementedError("LDM training forward is out of scope: graspldm_amd is the generation path")
