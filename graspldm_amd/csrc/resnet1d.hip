@@ -755,9 +755,13 @@ __device__ __forceinline__ void gemm_sm3_pl(const Ctx &c, const float *__restric
 
 // 1x1 conv with the B operand from pre-split planes (the folded-LayerNorm qkv conv reads the X planes).
 // MS: stride between the wave's m-tiles (the fused qkv + attention phase takes a head's q, k and v rows: 8 m-tiles apart).
-template <int KB32, int MT, int NT, class PRE = NoPre, int MS = 1, int LL = 4>
+// FIRST: NoFirst, or Frag3 = block 0's fragments of the first m-tile, requested by the caller ahead of the call (by value in
+// registers: a pointer to them would put the array on the stack).
+struct NoFirst { static constexpr bool on = false; };
+struct Frag3 { static constexpr bool on = true; u32x4 p[3]; };
+template <int KB32, int MT, int NT, class PRE = NoPre, int MS = 1, int LL = 4, class FIRST = NoFirst>
 __device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__ wp3, int mt0, int nt0, const float *planes,
-                                         f32x4 (&acc)[MT][NT], const PRE &pre = PRE()) {
+                                         f32x4 (&acc)[MT][NT], const PRE &pre = PRE(), const FIRST &first = FIRST()) {
   const int col = c.lane & 15, g = c.lane >> 4;
   const WStream wv(wp3, c.lane);
   using PGx = PG<LL>;
@@ -776,7 +780,20 @@ __device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) bs[buf][pl] = pl3[(kb * 3 + pl) * PGx::kPlaneU4 + 16 * ni];
   };
-  load_a(0, 0);
+  if constexpr (FIRST::on) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) a[0][0][pl] = first.p[pl];
+    if constexpr (MT > 1) {
+#pragma unroll
+      for (int mi = 1; mi < MT; ++mi) {
+        const int sb = ((mt0 + mi * MS) * KB32) * 3072;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[0][mi][pl] = wv.raw_at(sb, pl * 1024);
+      }
+    }
+  } else {
+    load_a(0, 0);
+  }
   load_b(0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
   pre();
@@ -4093,6 +4110,174 @@ __global__ __launch_bounds__(512, 1) void sa_mlp2_kernel(const SaArgs a, int row
 }
 
 
+// ======================================================== fused set abstraction on split-bf16 planes ==
+// The same module core (gather + grouped MLP + max over the neighbours, ext/pvcnn/modules/pointnet.py:100-111) with the
+// GEMMs on the bf16 matrix pipe: every f32 product as six bf16 partial products (hi / mid / lo splits of both operands,
+// f32 accumulation: see the split-bf16 core above), 6/16 of the f32-MFMA time.  A tile is 64 columns = 64 / U centres x U
+// neighbours; the gathered tile and every hidden layer's output live in LDS as pre-split planes in B-fragment order
+// (the position-major engine's geometry: 12 KiB per 32 channels), written once by their producer (the gather threads hold
+// four consecutive channels of a column; a layer's epilogue its accumulators' four consecutive rows), so the k-loops are
+// ds_read_b128 + buffer loads + MFMA (gemm1_pl).  Region A: the gathered tile, later the odd hidden layers' outputs;
+// region B: the even ones'.  The last layer is never stored: max over a centre's neighbours on the accumulators.
+// Persistent workgroups; the next tile's gather is requested in front of the last layer and stored behind it.
+// Shapes: cin_pad a multiple of 32 (zero weights beyond the real rows), hidden widths multiples of 32 up to 256, U in
+// {16, 32, 64}; anything else runs on the f32 kernels above.
+constexpr int kSa3Quads = 9;   // row quads per gather thread: 8 threads per column x 9 x 4 rows >= 259 + padding
+template <int NT, class FIRST>
+__device__ __forceinline__ void sa3_gemm(const Ctx &c, const float *wp, int kb, int mt, int nt0, const float *planes,
+                                         f32x4 (&acc)[1][NT], const FIRST &first) {
+  switch (kb) {
+    case 1: gemm1_pl<1, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;
+    case 2: gemm1_pl<2, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;
+    case 3: gemm1_pl<3, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;
+    case 4: gemm1_pl<4, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;
+    case 5: gemm1_pl<5, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;
+    case 6: gemm1_pl<6, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;
+    default: gemm1_pl<8, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;
+  }
+}
+// The wave's first m-tile of layer l (the mapping of sa_mlp3_kernel) and the request for its block-0 fragments: issued
+// right behind the previous layer's k-loop, in flight under its epilogue and the barrier (each layer of a tile used to
+// start with a cold L2 round trip: ~1.9 k cycles against 2-5 k of MFMAs).
+__device__ __forceinline__ int sa3_first_mt(const SaArgs &a, int l, int w) {
+  const int mtiles = a.cout[l] >> 4;
+  return (l + 1 < a.n_layers && mtiles < 8) ? (mtiles == 4 ? (w & 3) : (w & 1)) : w;
+}
+__device__ __forceinline__ Frag3 sa3_request(const Ctx &c, const SaArgs &a, int l) {
+  const WStream wv(a.weights + a.w_off[l], c.lane);
+  const int mt = sa3_first_mt(a, l, c.wave), kb = a.cin_pad[l] >> 5;
+  const int mtc = mt < (a.cout[l] >> 4) ? mt : 0;   // waves beyond a narrow last layer: any valid fragment
+  Frag3 f;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) f.p[pl] = wv.raw_at(mtc * kb * 3072, pl * 1024);
+  return f;
+}
+template <int NT, class FIRST>
+__device__ __forceinline__ void sa3_hidden(const Ctx &c, const SaArgs &a, int l, int mt, int nt0, const float *src, float *dst,
+                                           const FIRST &first) {
+  const int col = c.lane & 15, kq = c.lane >> 4;
+  f32x4 acc[1][NT];
+  const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq);
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) acc[0][ni] = bv;
+  sa3_gemm<NT, FIRST>(c, a.weights + a.w_off[l], a.cin_pad[l] >> 5, mt, nt0, src, acc, first);
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+    store_planes4(dst, 16 * mt + 4 * kq, 16 * (nt0 + ni) + col, fmaxf(acc[0][ni][0], 0.f), fmaxf(acc[0][ni][1], 0.f),
+                  fmaxf(acc[0][ni][2], 0.f), fmaxf(acc[0][ni][3], 0.f));
+}
+// last layer: m-tile mt over all four n-tiles, max over each centre's U / 16 tiles and 16 columns, ReLU, one value per row
+template <class FIRST>
+__device__ __forceinline__ void sa3_last(const Ctx &c, const SaArgs &a, int l, int mt, const float *src, int j0, float *outb,
+                                         const FIRST &first) {
+  const int col = c.lane & 15, kq = c.lane >> 4;
+  f32x4 acc[1][4];
+  const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) acc[0][ni] = bv;
+  sa3_gemm<4, FIRST>(c, a.weights + a.w_off[l], a.cin_pad[l] >> 5, mt, 0, src, acc, first);
+  const int tpc = a.u >> 4;   // n-tiles per centre: 1, 2 or 4
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float m[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) m[ni] = acc[0][ni][r];
+    if (tpc >= 2) { m[0] = fmaxf(m[0], m[1]); m[2] = fmaxf(m[2], m[3]); }
+    if (tpc >= 4) m[0] = fmaxf(m[0], m[2]);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      if (ni % tpc) continue;  // wave uniform
+      const float v = fmaxf(row16_max(m[ni]), 0.f);
+      const int jj = ni / tpc;
+      if (col == 0 && j0 + jj < a.m) outb[(size_t)(16 * mt + 4 * kq + r) * a.m + j0 + jj] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blocks_a, int tiles_per_cloud, int total_tiles) {
+  extern __shared__ float lds[];
+  Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
+        0, 4};
+  const int cpt = 64 / a.u;  // centres per tile
+  float *A = lds, *B = lds + (size_t)blocks_a * 3072;
+  const int w = c.wave, col = c.lane, qg = c.wave;   // gather: thread = (column, row-quad group)
+  const int nquads = a.cin_pad[0] >> 2;
+  float gv[kSa3Quads][4];
+  auto gather_load = [&](int t) {
+    const int b = t / tiles_per_cloud, tile = t - b * tiles_per_cloud, j0 = tile * cpt, jj = col / a.u;
+    const bool live = j0 + jj < a.m;
+    const float *pts = a.points + (size_t)b * 3 * a.n, *ctr = a.centers + (size_t)b * 3 * a.m;
+    const float *feat = a.feat ? a.feat + (size_t)b * a.c * a.n : a.points;
+    const int32_t *idx = a.idx + ((size_t)b * a.m + j0) * a.u;
+    const int id = live ? idx[col] : 0;
+    const int jc = live ? j0 + jj : 0, cmax = a.c > 0 ? a.c - 1 : 0;
+#pragma unroll
+    for (int i = 0; i < kSa3Quads; ++i) {
+      const int rq = qg + 8 * i;   // rows 4 rq .. 4 rq + 3: [x y z f0] for quad 0, f[4 rq - 3 ..] after it
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ch = 4 * rq + e;
+        float v;
+        if (ch < 3) v = pts[ch * a.n + id] - ctr[ch * a.m + jc];
+        else { const int f = ch - 3; v = feat[(size_t)(f < cmax ? f : cmax) * a.n + id]; v = f < a.c ? v : 0.f; }
+        gv[i][e] = live ? v : 0.f;
+      }
+    }
+  };
+  auto gather_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < kSa3Quads; ++i) {
+      const int rq = qg + 8 * i;
+      if (rq < nquads) store_planes4(A, 4 * rq, col, gv[i][0], gv[i][1], gv[i][2], gv[i][3]);
+    }
+  };
+  Frag3 frag;   // block-0 fragments of the wave's first m-tile of the NEXT layer to run
+  // The request for the next layer's first fragments sits behind this layer's (first) k-loop, in front of its stores: in
+  // flight under the epilogue and the barrier.  Straight-line code: the fragments travel by value.
+  auto hidden = [&](int l, const float *src, float *dst) {
+    const int mtiles = a.cout[l] >> 4;
+    Ctx cl = c;
+    asm volatile("" : "+v"(cl.tid), "+v"(cl.lane));
+    const Frag3 cur = frag;
+    if (mtiles >= 8) {
+      sa3_hidden<4, Frag3>(cl, a, l, w, 0, src, dst, cur);
+      for (int p = 1; p < (mtiles >> 3); ++p) sa3_hidden<4, NoFirst>(cl, a, l, w + 8 * p, 0, src, dst, NoFirst());
+    } else if (mtiles == 4) sa3_hidden<2, Frag3>(cl, a, l, w & 3, 2 * (w >> 2), src, dst, cur);
+    else sa3_hidden<1, Frag3>(cl, a, l, w & 1, w >> 1, src, dst, cur);
+    frag = sa3_request(c, a, l + 1);
+  };
+  int t = blockIdx.x;
+  gather_load(t);
+  frag = sa3_request(c, a, 0);
+  gather_store();
+  __syncthreads();
+  for (; t < total_tiles; t += gridDim.x) {
+    const int b = t / tiles_per_cloud, j0 = (t - b * tiles_per_cloud) * cpt;
+    float *outb = a.out + (size_t)b * a.cout[a.n_layers - 1] * a.m;
+    float *src = A, *dst = B;
+    for (int l = 0; l + 1 < a.n_layers; ++l) {
+      hidden(l, src, dst);
+      __syncthreads();
+      float *tsw = src; src = dst; dst = tsw;
+    }
+    const int tn = t + (int)gridDim.x < total_tiles ? t + (int)gridDim.x : t;
+    gather_load(tn);
+    {
+      const int l = a.n_layers - 1, mtiles = a.cout[l] >> 4;
+      Ctx cl = c;
+      asm volatile("" : "+v"(cl.tid), "+v"(cl.lane));
+      const Frag3 cur = frag;
+      if (w < mtiles) sa3_last<Frag3>(cl, a, l, w, src, j0, outb, cur);
+      for (int mt = w + 8; mt < mtiles; mt += 8) sa3_last<NoFirst>(cl, a, l, mt, src, j0, outb, NoFirst());
+      frag = sa3_request(c, a, 0);   // the next tile's first layer
+    }
+    __syncthreads();  // the last layer may have been reading region A
+    gather_store();
+    __syncthreads();
+  }
+}
+
+
 // Scale / shift rows of every ResnetBlock for one conditioning cloud (ResnetBlock.mlp, resnets.py:125-151, when the
 // embedding has no time part: the pose decoder):  ss[rb][row] = comb_b[row] + sum_e W[row][e] G[e],  G = sum over the
 // cond rows of SiLU(cemb) -- the value the conv epilogue would compute with MFMAs for every sample and column.
@@ -4313,6 +4498,45 @@ GLDM_API int gldm_pointwise_mlp2_bf16x3(const float *x, const float *w0_packed, 
   if (!w0_packed) return GLDM_ERR_INVALID_ARG;
   return launch_pointwise(x, w0_packed, bias0, cin0, w_split, bias, b, cin, cout, n, 1, head_w_packed, head_bias,
                           hout, y, z, reinterpret_cast<hipStream_t>(stream), true);
+}
+
+GLDM_API int gldm_sa_mlp_forward_bf16x3(const float *points, const float *centers, const float *features,
+                                        const int32_t *idx, const float *weights, int b, int c, int n, int m, int u,
+                                        int n_layers, const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off,
+                                        const int32_t *b_off, float *out, gldm_stream_t stream) {
+  if (!points || !centers || !idx || !weights || !out || !cin_pad || !cout || !w3_off || !b_off || b <= 0 || c < 0 ||
+      n <= 0 || m <= 0 || u <= 0)
+    return GLDM_ERR_INVALID_ARG;
+  if (c > 0 && !features) return GLDM_ERR_INVALID_ARG;
+  if (n_layers < 1 || n_layers > 4 || !(u == 16 || u == 32 || u == 64)) return GLDM_ERR_UNSUPPORTED;
+  SaArgs a{};
+  a.points = points; a.centers = centers; a.feat = c > 0 ? features : nullptr; a.idx = idx; a.weights = weights;
+  a.out = out; a.c = c; a.n = n; a.m = m; a.u = u; a.n_layers = n_layers;
+  int blocks_a = 0, blocks_b = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    const int kb = cin_pad[l] >> 5, mt = cout[l] >> 4;
+    if (cin_pad[l] <= 0 || (cin_pad[l] & 31) || !(kb <= 6 || kb == 8) || cout[l] <= 0 || (cout[l] & 15)) return GLDM_ERR_UNSUPPORTED;
+    if (l > 0 && cin_pad[l] != cout[l - 1]) return GLDM_ERR_INVALID_ARG;
+    if (l + 1 < n_layers) {   // hidden layer: its output is the next layer's planes
+      if ((cout[l] & 31) || !(mt == 2 || mt == 4 || mt == 8 || mt == 16)) return GLDM_ERR_UNSUPPORTED;
+      int &blk = (l & 1) ? blocks_a : blocks_b;
+      blk = blk > (cout[l] >> 5) ? blk : (cout[l] >> 5);
+    }
+    a.cin_pad[l] = cin_pad[l]; a.cout[l] = cout[l]; a.w_off[l] = w3_off[l]; a.b_off[l] = b_off[l];
+  }
+  if (cin_pad[0] < 3 + c || cin_pad[0] > 32 * kSa3Quads) return GLDM_ERR_UNSUPPORTED;
+  blocks_a = blocks_a > (cin_pad[0] >> 5) ? blocks_a : (cin_pad[0] >> 5);
+  const size_t lds_bytes = (size_t)(blocks_a + blocks_b) * 3072 * sizeof(float);
+  if (lds_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
+  struct Sa3Tag { int site; };
+  gldm_dev::allow_dynamic_lds<Sa3Tag>(reinterpret_cast<const void *>(&sa_mlp3_kernel), 160 * 1024);
+  const int cpt = 64 / u, tpc = (m + cpt - 1) / cpt, total = tpc * b;
+  const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
+  int grid = cu_count() * per_cu;
+  if (grid > total) grid = total;
+  hipLaunchKernelGGL(sa_mlp3_kernel, dim3(grid), dim3(512), lds_bytes, reinterpret_cast<hipStream_t>(stream), a, blocks_a,
+                     tpc, total);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 
 GLDM_API int gldm_sa_mlp_forward(const float *points, const float *centers, const float *features,

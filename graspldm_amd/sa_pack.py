@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .r1d_pack import _Buf, mfma_a_fragments
+from .r1d_pack import _Buf, mfma_a_fragments, mfma_a_fragments_bf16x3
 
 _OK_MTILES = (1, 2, 4, 8, 12, 16)
 
@@ -29,12 +29,30 @@ def fusable(shared_mlp, num_neighbors):
     return (layers[0].weight.shape[1] + 31) // 32 * 32 <= 256
 
 
+def split_plan_ok(cins, couts, num_neighbors):
+    """Shapes gldm_sa_mlp_forward_bf16x3 takes (csrc/resnet1d.hip: sa_mlp3_kernel): 64-column tiles on split-bf16 planes."""
+    if int(num_neighbors) not in (16, 32, 64) or not 1 <= len(couts) <= 4:
+        return False
+    kpad = [(cins[0] + 31) // 32 * 32] + list(couts[:-1])
+    if any(k % 32 or not (k // 32 <= 6 or k // 32 == 8) for k in kpad) or any(c % 16 for c in couts):
+        return False
+    if any(c not in (32, 64, 128, 256) for c in couts[:-1]):
+        return False
+    blocks_a = max([kpad[0] // 32] + [couts[l] // 32 for l in range(1, len(couts) - 1, 2)])
+    blocks_b = max([0] + [couts[l] // 32 for l in range(0, len(couts) - 1, 2)])
+    return (blocks_a + blocks_b) * 3072 * 4 <= 160 * 1024
+
+
 class SaMlpPlan:
-    """Packed weights of one SharedMLP(dim=2) on the device + the layer tables."""
+    """Packed weights of one SharedMLP(dim=2) on the device + the layer tables.  Where the layer plan fits the split-bf16
+    kernel (split_plan_ok: the PointNet++ / PVCNN2 set-abstraction shapes), `run` takes that one; the f32-MFMA plan
+    is packed either way (other neighbour counts / widths)."""
 
     def __init__(self, shared_mlp, device):
         layers = shared_mlp.layers
         n = len(layers) // 3
+        self._split = None
+        self._layers = shared_mlp
         buf = _Buf()
         cin_pad, cout, w_off, b_off = [], [], [], []
         for i in range(n):
@@ -53,12 +71,44 @@ class SaMlpPlan:
         arr = ctypes.c_int32 * n
         self.cin_pad, self.cout, self.w_off, self.b_off = arr(*cin_pad), arr(*cout), arr(*w_off), arr(*b_off)
         self.cout_last = cout[-1]
+        self._device = device
+
+    def _split_plan(self):
+        """Split-bf16 fragments [cout x K padded to 32] per layer + biases, packed on first use."""
+        if self._split is None:
+            layers = self._layers.layers
+            n = len(layers) // 3
+            buf = _Buf()
+            cin_pad, cout, w_off, b_off = [], [], [], []
+            for i in range(n):
+                w, b = fold_conv_bn(layers[3 * i], layers[3 * i + 1])
+                kpad = (w.shape[1] + 31) // 32 * 32
+                wp = torch.zeros(w.shape[0], kpad)
+                wp[:, : w.shape[1]] = w.cpu()
+                cin_pad.append(kpad)
+                cout.append(w.shape[0])
+                w_off.append(buf.add(mfma_a_fragments_bf16x3(wp)))
+                b_off.append(buf.add(b.cpu()))
+            arr = ctypes.c_int32 * n
+            self._split = (buf.tensor().to(self._device), arr(*cin_pad), arr(*cout), arr(*w_off), arr(*b_off))
+        return self._split
 
     def run(self, points, centers, features, idx):
         b, _, n = points.shape
         m, u = idx.shape[1], idx.shape[2]
         c = 0 if features is None else features.shape[1]
         out = torch.empty((b, self.cout_last, m), dtype=torch.float32, device=points.device)
+        lay = self._layers.layers
+        cins = [lay[3 * i].weight.shape[1] for i in range(self.n_layers)]
+        couts = [lay[3 * i].weight.shape[0] for i in range(self.n_layers)]
+        if split_plan_ok(cins, couts, u):
+            w3, cin_pad, cout, w_off, b_off = self._split_plan()
+            with torch.cuda.device(points.device):
+                L.call("gldm_sa_mlp_forward_bf16x3", L.ptr(points), L.ptr(centers), L.ptr(features), L.ptr(idx), L.ptr(w3),
+                       b, c, n, m, u, self.n_layers, ctypes.cast(cin_pad, ctypes.c_void_p), ctypes.cast(cout, ctypes.c_void_p),
+                       ctypes.cast(w_off, ctypes.c_void_p), ctypes.cast(b_off, ctypes.c_void_p), L.ptr(out),
+                       L.current_stream(points.device))
+            return out
         with torch.cuda.device(points.device):
             L.call("gldm_sa_mlp_forward", L.ptr(points), L.ptr(centers), L.ptr(features), L.ptr(idx), L.ptr(self.weights),
                    b, c, n, m, u, self.n_layers, ctypes.cast(self.cin_pad, ctypes.c_void_p),

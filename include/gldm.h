@@ -287,6 +287,18 @@ int gldm_sa_mlp_forward(const float *points /*[b,3,n]*/, const float *centers /*
                         const int32_t *cin_pad, const int32_t *cout, const int32_t *w_off, const int32_t *b_off,
                         float *out /*[b,cout_last,m]*/, gldm_stream_t stream);
 
+/* The same module core with the GEMMs on the bf16 matrix pipe (every f32 product as six bf16 partial products of the exact
+ * hi / mid / lo splits of both operands, f32 accumulation: the arithmetic of the denoiser engines): 64-column tiles whose
+ * gathered rows and hidden-layer outputs live in LDS as pre-split planes.  `weights` holds, per layer, the split-bf16 A
+ * fragments of [cout x cin_pad] at w3_off[l] (graspldm_amd/r1d_pack.py: mfma_a_fragments_bf16x3; cin_pad a multiple of 32,
+ * zero beyond the real rows) and the folded bias at b_off[l].  Shapes: cin_pad[0] <= 288, hidden widths multiples of 32
+ * (32 / 64 / 128 / 256), U in {16, 32, 64}; GLDM_ERR_UNSUPPORTED otherwise (callers then use gldm_sa_mlp_forward). */
+int gldm_sa_mlp_forward_bf16x3(const float *points /*[b,3,n]*/, const float *centers /*[b,3,m]*/,
+                               const float *features /*[b,c,n] or NULL*/, const int32_t *idx /*[b,m,u]*/,
+                               const float *weights, int b, int c, int n, int m, int u, int n_layers,
+                               const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off, const int32_t *b_off,
+                               float *out /*[b,cout_last,m]*/, gldm_stream_t stream);
+
 /* ref: grasp_ldm/models/modules/ext/pvcnn/modules/shared_mlp.py:6-35 (Conv1d k = 1 + eval BatchNorm folded + ReLU),
  * one layer, in the native [b, c, n] layout: y = act(W x + bias).  `w_packed` = the folded weight [cout, cin] in MFMA
  * A-fragment order (graspldm_amd/r1d_pack.py: mfma_a_fragments).  Optional fused head on the accumulators:
