@@ -363,18 +363,22 @@ constexpr int kPairs = 14;  // tap pairs per 16-channel block (the last one hold
 // workgroup of 8 waves per CU (3 n-tiles each); the 12^3 brick 48 KiB, 4 waves, three workgroups per CU.
 // Staging: an item = (voxel, 8-channel half): 8 dword loads one channel apart (coalesced along z), 36 VALU, three
 // ds_write_b128; the next block's raw values are requested before the tap loop and split / stored after it.
-template <int MT, int R, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) void conv3d_k3_pl_kernel(const float *__restrict__ x,
+// R: grid resolution; ZB: z extent of the brick (R, or a divisor of it: the 24^3 grid runs as two 4 x 4 x 12 half bricks per
+// (x, y) -- 48 KiB of planes instead of 90, three workgroups of 4 waves per CU instead of one of 8, so that one brick's
+// staging, barriers and epilogue run under another's MFMAs, like the 12^3 conv always did; the two halves of a brick add
+// their GroupNorm partials into one zeroed slot with atomics: two addends, so the sum does not depend on their order).
+template <int MT, int R, int ZB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) void conv3d_k3_pl_kernel(const float *__restrict__ x,
                                                                                       const float *__restrict__ wp3,
                                                                                       const float *__restrict__ bias, int cin,
                                                                                       int cout, float *__restrict__ y,
                                                                                       float *__restrict__ partial) {
-  constexpr int r = R, NTW = R / WAVES, kThreads = 64 * WAVES;
-  static_assert(NTW % 3 == 0 && MT % 3 == 0, "tiles walked in 3 x 3 groups");
+  constexpr int r = R, NTW = ZB / WAVES, kThreads = 64 * WAVES, kZParts = R / ZB;
+  static_assert(NTW % 3 == 0 && MT % 3 == 0 && R % ZB == 0, "tiles walked in 3 x 3 groups");
   constexpr int MG = MT / 3, NG = NTW / 3;
   // (Measured and kept out: 4 waves x 6 n-tiles on the 24^3 brick -- half the weight-fragment deliveries, but more than
   // 256 registers, hence one wave per SIMD -- 0.74 ms per launch against 0.67 for 8 waves x 3 n-tiles.)
-  constexpr int zp = r + 2, nvox = 36 * zp, r3 = r * r * r;
+  constexpr int zp = ZB + 2, nvox = 36 * zp, r3 = r * r * r;
   constexpr int kItems = 2 * nvox, kRounds = (kItems + kThreads - 1) / kThreads;
   extern __shared__ float lds[];
   GLDM_C3_STAMP(0);
@@ -382,7 +386,8 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 15, kq = lane >> 4;
   const int bpr = r / kBrick;
-  const int bx0 = (blockIdx.x / bpr) * kBrick, by0 = (blockIdx.x % bpr) * kBrick;
+  const int bxy = blockIdx.x / kZParts, bz0 = (blockIdx.x % kZParts) * ZB;
+  const int bx0 = (bxy / bpr) * kBrick, by0 = (bxy % bpr) * kBrick;
   const int b = blockIdx.y;
   const int cblocks = (cin + 15) >> 4, kblocks = kPairs * cblocks;
   x += (size_t)b * cin * r3;
@@ -396,9 +401,9 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
 #pragma unroll
   for (int ni = 0; ni < NTW; ++ni) {
     const int o = 16 * (wave * NTW + ni) + col;
-    const int iz = o % r, ixy = o / r, ix = ixy >> 2, iy = ixy & 3;
+    const int iz = o % ZB, ixy = o / ZB, ix = ixy >> 2, iy = ixy & 3;
     vb[ni] = 2 * ((ix * 6 + iy) * zp + iz) + (kq & 1);
-    gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + iz;
+    gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + bz0 + iz;
   }
   f32x4 acc[MT][NTW];
 #pragma unroll
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
     if (it < kItems) {
       const int h = it / nvox, v = it - h * nvox;       // half-major: a wave's loads run along z
       const int ixy = v / zp, izp = v - ixy * zp;
-      const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1, gz = izp - 1;
+      const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1, gz = bz0 + izp - 1;
       s_lds[q] = 2 * v + h;
       if ((unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r && (unsigned)gz < (unsigned)r)
         s_glb[q] = (gx * r + gy) * r + gz + 8 * h * r3;
@@ -554,9 +559,14 @@ __global__ __launch_bounds__(64 * WAVES, (R * 16 / WAVES / 16 >= 6) ? 1 : 2) voi
       s += s_part[(w * MT * 16 + tid) * 2];
       s2 += s_part[(w * MT * 16 + tid) * 2 + 1];
     }
-    float *p = partial + (((size_t)b * gridDim.x + blockIdx.x) * cout + tid) * 2;
-    p[0] = s;
-    p[1] = s2;
+    float *p = partial + (((size_t)b * (gridDim.x / kZParts) + bxy) * cout + tid) * 2;
+    if constexpr (kZParts == 1) {
+      p[0] = s;
+      p[1] = s2;
+    } else {   // the slot was zeroed by the launcher; two addends: order independent
+      atomicAdd(p, s);
+      atomicAdd(p + 1, s2);
+    }
   }
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi)
@@ -963,15 +973,18 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
   return GLDM_ERR_UNSUPPORTED;
 }
 
-template <int MT, int R, int WAVES>
+template <int MT, int R, int ZB, int WAVES>
 int launch_conv_pl(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
                    hipStream_t s) {
-  const size_t lds_bytes = (size_t)3 * 36 * (R + 2) * 32;
+  const size_t lds_bytes = (size_t)3 * 36 * (ZB + 2) * 32;
   struct Tag {};
-  gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_pl_kernel<MT, R, WAVES>), (int)lds_bytes);
+  gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_pl_kernel<MT, R, ZB, WAVES>), (int)lds_bytes);
   const int bpr = R / kBrick;
-  hipLaunchKernelGGL((conv3d_k3_pl_kernel<MT, R, WAVES>), dim3(bpr * bpr, b), dim3(64 * WAVES), lds_bytes, s, x, wp3, bias,
-                     cin, cout, y, partial);
+  if (R != ZB) {   // the halves of a brick add their partials into one slot
+    if (hipMemsetAsync(partial, 0, (size_t)b * bpr * bpr * cout * 2 * sizeof(float), s) != hipSuccess) return GLDM_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((conv3d_k3_pl_kernel<MT, R, ZB, WAVES>), dim3(bpr * bpr * (R / ZB), b), dim3(64 * WAVES), lds_bytes, s, x,
+                     wp3, bias, cin, cout, y, partial);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 
@@ -996,8 +1009,11 @@ GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const f
     }
   } dump{s, cin, cout, r, b};
 #endif
-  if (cout == 48 && r == 24) return launch_conv_pl<3, 24, 8>(x, w_split, bias, b, cin, cout, y, partial, s);
-  if (cout == 96 && r == 12) return launch_conv_pl<6, 12, 4>(x, w_split, bias, b, cin, cout, y, partial, s);
+  // (4 x 4 x 12 half bricks at 24^3 -- <3, 24, 12, 4>: 48 KiB of planes, two co-resident workgroups of 4 waves -- measured
+  // 2.12 ms against 2.05 for the full-z brick: the kernel's 220 registers allow two waves per SIMD either way, and the
+  // halves pay a z halo and the weight stream twice.  Kept as an instantiable option, not used.)
+  if (cout == 48 && r == 24) return launch_conv_pl<3, 24, 24, 8>(x, w_split, bias, b, cin, cout, y, partial, s);
+  if (cout == 96 && r == 12) return launch_conv_pl<6, 12, 12, 4>(x, w_split, bias, b, cin, cout, y, partial, s);
   return GLDM_ERR_UNSUPPORTED;
 }
 

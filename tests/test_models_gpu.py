@@ -163,13 +163,21 @@ def test_ddpm_sampler_runs_and_is_seed_reproducible(ldm):
                                              (2, 32, 1024, 1024, 32, (32, 64)), (1, 5, 300, 37, 16, (16, 32, 32, 64)),
                                              (2, 64, 256, 37, 32, (64, 128)), (300, 16, 128, 5, 16, (32, 64, 128, 256)),
                                              (1, 160, 200, 9, 64, (128, 128))])
-def test_fused_sa_mlp_equals_unfused_oracle(b, c, n, m, u, chans):
-    """gldm_sa_mlp_forward (gather + grouped MLP + max, fused) vs the oracle's
-    ball_group -> shared_mlp -> max on the same weights.  Cases 1-3, 5, 6 run on the 128-column kernel (sa_mlp2_kernel:
-    2 / 4 / 8 centres per tile, ragged last tiles, more tiles than persistent workgroups, 4 layers), cases 4 and 7 on
-    the 64-column one (a 16-row layer; more feature channels than the gather prefetch holds)."""
+@pytest.mark.parametrize("split", [True, False])
+def test_fused_sa_mlp_equals_unfused_oracle(b, c, n, m, u, chans, split, monkeypatch):
+    """gldm_sa_mlp_forward_bf16x3 / gldm_sa_mlp_forward (gather + grouped MLP + max, fused) vs the oracle's
+    ball_group -> shared_mlp -> max on the same weights.  split=True: every case but the fourth (a 16-row hidden layer) runs
+    on the split-bf16 64-column kernel (sa_mlp3_kernel: 1 / 2 / 4 centres per tile, ragged last tiles, more tiles than
+    persistent workgroups, 2-4 layers, 1-6 input blocks).  split=False forces the f32 kernels: cases 1-3, 5, 6 on the
+    128-column one (sa_mlp2_kernel), cases 4 and 7 on the 64-column one (sa_mlp_kernel)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    from graspldm_amd import sa_pack
+    if not split:
+        monkeypatch.setattr(sa_pack, "split_plan_ok", lambda *a, **k: False)
+    elif chans != (16, 32, 32, 64):
+        cins = [c + 3] + list(chans[:-1])
+        assert sa_pack.split_plan_ok(cins, list(chans), u)
     from graspldm_amd.pvcnn import PointNetSAModule
     from graspldm_amd.synthetic import load_synthetic_weights
     from oracle import torch_ref as R
