@@ -397,3 +397,49 @@ def test_untamed_gains_short_horizon(engines):
         e = R.resnet1d_forward(sd, pre, xs, z_cond=z, time=torch.full((n,), tt, dtype=torch.long))
         xs = sched.step(e, tt, xs).prev_sample
     assert _err(out, xs) < 1e-4, _err(out, xs)
+
+
+@pytest.mark.parametrize("block_channels", [(32,), (32, 64), (32, 64, 128, 256), (64, 128)])
+def test_sixteen_position_engine_other_depths(block_channels):
+    """The 16-position 64-column engine (r1d_kernel<64, 16>) on other depth / width sequences of its supported set (first
+    level 16 channels, then 32..256), with per-sample timesteps and a batch that does not fill its last 4-sample tile:
+    against the oracle, one forward (2e-5) and an 8-step DDIM run (1e-4); the same descriptor without the padded 16-channel
+    split copies runs the sample-major f32 engine with the same result."""
+    import ctypes
+    from oracle import torch_ref as R
+    from graspldm_amd import _lib as L
+    from graspldm_amd.resnets import TimeConditionedResNet1D
+    from graspldm_amd.r1d import SCHED_DDIM
+    from graspldm_amd.synthetic import load_synthetic_weights
+    net = TimeConditionedResNet1D(dim=16, channels=1, block_channels=block_channels, input_conditioning_dims=64,
+                                  resnet_block_groups=4, dropout=0.1, is_time_conditioned=True, learned_variance=False,
+                                  learned_sinusoidal_cond=False, random_fourier_features=True)
+    load_synthetic_weights(net, seed=3 + len(block_channels))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    n = 23   # five full tiles of 4 samples + one of 3
+    x = torch.randn(n, 1, 16, generator=g)
+    z = torch.randn(n, 3, 64, generator=g)
+    t = torch.randint(0, 1000, (n,), generator=g)
+    eng = net.engine(torch.device("cuda:0"))
+    assert L.lib().gldm_r1d_tile_columns(eng._desc_ptr()) == 64
+    exp = R.resnet1d_forward(sd, "", x, z_cond=z, time=t)
+    eps = net(x.cuda(), time=t.cuda(), z_cond=z.cuda())
+    assert _err(eps, exp) < 2e-5, _err(eps, exp)
+    ts, coef = _ddim_tables(100)
+    ts, coef = ts[-8:].contiguous(), coef[-8:].contiguous()
+    out = eng.denoise(x.cuda(), eng.cond_embed(z.cuda()), 1, timesteps=ts.cuda(), sched_kind=SCHED_DDIM, coef=coef.cuda())
+    sched = R.make_scheduler("ddim")
+    sched.set_timesteps(100)
+    xs = x.clone()
+    for tt in ts.tolist():
+        e = R.resnet1d_forward(sd, "", xs, z_cond=z, time=torch.full((n,), tt, dtype=torch.long))
+        xs = sched.step(e, tt, xs).prev_sample
+    assert _err(out, xs) < 1e-4, _err(out, xs)
+    keep = eng.desc.rb[0].c1_w3
+    eng.desc.rb[0].c1_w3 = 0   # no padded split copy of the 16-channel level -> the f32 engine
+    assert L.lib().gldm_r1d_tile_columns(eng._desc_ptr()) == 32
+    eps32 = eng.denoise(x.cuda(), eng.cond_embed(z.cuda()), 1, sample_t=t.int().cuda())
+    eng.desc.rb[0].c1_w3 = keep
+    assert _err(eps32, exp) < 2e-5, _err(eps32, exp)
