@@ -4152,19 +4152,24 @@ __device__ __forceinline__ Frag3 sa3_request(const Ctx &c, const SaArgs &a, int 
   for (int pl = 0; pl < 3; ++pl) f.p[pl] = wv.raw_at(mtc * kb * 3072, pl * 1024);
   return f;
 }
-template <int NT, class FIRST>
-__device__ __forceinline__ void sa3_hidden(const Ctx &c, const SaArgs &a, int l, int mt, int nt0, const float *src, float *dst,
-                                           const FIRST &first) {
+// REQ: request the next layer's first fragments right behind this k-loop (in flight under the epilogue and the barrier)
+template <int NT, class FIRST, bool REQ>
+__device__ __forceinline__ Frag3 sa3_hidden(const Ctx &c, const SaArgs &a, int l, int mt, int nt0, const float *src, float *dst,
+                                            const FIRST &first) {
   const int col = c.lane & 15, kq = c.lane >> 4;
   f32x4 acc[1][NT];
   const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq);
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) acc[0][ni] = bv;
   sa3_gemm<NT, FIRST>(c, a.weights + a.w_off[l], a.cin_pad[l] >> 5, mt, nt0, src, acc, first);
+  Frag3 nxt{};
+  if constexpr (REQ) nxt = sa3_request(c, a, l + 1);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni)
     store_planes4(dst, 16 * mt + 4 * kq, 16 * (nt0 + ni) + col, fmaxf(acc[0][ni][0], 0.f), fmaxf(acc[0][ni][1], 0.f),
                   fmaxf(acc[0][ni][2], 0.f), fmaxf(acc[0][ni][3], 0.f));
+  return nxt;
 }
 // last layer: m-tile mt over all four n-tiles, max over each centre's U / 16 tiles and 16 columns, ReLU, one value per row
 template <class FIRST>
@@ -4239,12 +4244,12 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
     Ctx cl = c;
     asm volatile("" : "+v"(cl.tid), "+v"(cl.lane));
     const Frag3 cur = frag;
-    if (mtiles >= 8) {
-      sa3_hidden<4, Frag3>(cl, a, l, w, 0, src, dst, cur);
-      for (int p = 1; p < (mtiles >> 3); ++p) sa3_hidden<4, NoFirst>(cl, a, l, w + 8 * p, 0, src, dst, NoFirst());
-    } else if (mtiles == 4) sa3_hidden<2, Frag3>(cl, a, l, w & 3, 2 * (w >> 2), src, dst, cur);
-    else sa3_hidden<1, Frag3>(cl, a, l, w & 1, w >> 1, src, dst, cur);
-    frag = sa3_request(c, a, l + 1);
+    if (mtiles == 8) frag = sa3_hidden<4, Frag3, true>(cl, a, l, w, 0, src, dst, cur);
+    else if (mtiles == 16) {
+      sa3_hidden<4, Frag3, false>(cl, a, l, w, 0, src, dst, cur);
+      frag = sa3_hidden<4, NoFirst, true>(cl, a, l, w + 8, 0, src, dst, NoFirst());
+    } else if (mtiles == 4) frag = sa3_hidden<2, Frag3, true>(cl, a, l, w & 3, 2 * (w >> 2), src, dst, cur);
+    else frag = sa3_hidden<1, Frag3, true>(cl, a, l, w & 1, w >> 1, src, dst, cur);
   };
   int t = blockIdx.x;
   gather_load(t);
