@@ -443,3 +443,43 @@ def test_sixteen_position_engine_other_depths(block_channels):
     eps32 = eng.denoise(x.cuda(), eng.cond_embed(z.cuda()), 1, sample_t=t.int().cuda())
     eng.desc.rb[0].c1_w3 = keep
     assert _err(eps32, exp) < 2e-5, _err(eps32, exp)
+
+
+@pytest.mark.parametrize("extra_tiles,steps,kind", [(3, 6, "ddim"), (40, 9, "ddpm")])
+def test_step_split_chain_on_the_sixteen_position_engine(extra_tiles, steps, kind):
+    """The same invariance on r1d_kernel<64, 16> (tiles of 4 samples, one workgroup per CU): a batch of one full round of
+    tiles plus a few is cut along the step axis over chains of workgroups; every sample's result is BITWISE what it is
+    in a launch without chains, the workspace (hand-off granules + park scratch) re-arms itself."""
+    from graspldm_amd.diffusion import make_schedule_tables
+    from graspldm_amd.r1d import SCHED_DDIM, SCHED_DDPM
+    from graspldm_amd.resnets import TimeConditionedResNet1D
+    from graspldm_amd.synthetic import load_synthetic_weights
+    from graspldm_amd import _lib as L
+    net = TimeConditionedResNet1D(dim=16, channels=1, block_channels=(32, 64, 128, 256), input_conditioning_dims=64,
+                                  resnet_block_groups=4, dropout=0.1, is_time_conditioned=True, learned_variance=False,
+                                  learned_sinusoidal_cond=False, random_fourier_features=True)
+    load_synthetic_weights(net, seed=21)
+    den = net.cuda().eval().engine(torch.device("cuda:0"))
+    assert L.lib().gldm_r1d_tile_columns(den._desc_ptr()) == 64
+    full = torch.cuda.get_device_properties(0).multi_processor_count * 4   # one 4-sample tile per CU
+    n = full + extra_tiles * 4 - 1        # ragged: the last tile holds 3 samples
+    spc = 4
+    g = torch.Generator().manual_seed(200 + extra_tiles)
+    x = torch.randn(n, 1, 16, generator=g).cuda()
+    z = torch.randn((n + spc - 1) // spc, 3, 64, generator=g).cuda()
+    ts, coef = make_schedule_tables(kind, 1000, 5e-5, 1e-3, "linear", "fixed_large", 100)
+    ts, coef = ts[-steps:].contiguous().cuda(), coef[-steps:].contiguous().cuda()
+    noise = torch.randn(steps, n, 1, 16, generator=g).cuda() if kind == "ddpm" else None
+    sk = SCHED_DDIM if kind == "ddim" else SCHED_DDPM
+    cemb = den.cond_embed(z)
+    big = den.denoise(x, cemb, spc, timesteps=ts, sched_kind=sk, coef=coef, step_noise=noise)
+    parts, chunk = [], 512     # half a round per launch: no chain
+    for i0 in range(0, n, chunk):
+        i1 = min(n, i0 + chunk)
+        parts.append(den.denoise(x[i0:i1], cemb[i0 // spc:], spc, timesteps=ts, sched_kind=sk, coef=coef,
+                                 step_noise=None if noise is None else noise[:, i0:i1].contiguous()))
+    assert torch.equal(big, torch.cat(parts))
+    assert torch.isfinite(big).all()
+    again = den.denoise(x, cemb, spc, timesteps=ts, sched_kind=sk, coef=coef, step_noise=noise)
+    assert torch.equal(big, again)
+    assert den.workspace_errors() == 0
