@@ -4199,81 +4199,204 @@ __device__ __forceinline__ void sa3_last(const Ctx &c, const SaArgs &a, int l, i
   }
 }
 
-__global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blocks_a, int tiles_per_cloud, int total_tiles) {
+// One layer of the multi-tile form over all `sub` tiles of a workgroup pass: the m-tile's weight fragments (KB blocks x 3
+// planes) are requested ONCE and stay in registers while the tiles' planes stream through -- per tile only LDS reads,
+// MFMAs and the epilogue remain (through gemm1_pl every tile paid the fragments' round trip again: latency bound at 24-96
+// MFMAs per call).  LAST: max over the neighbours instead of the plane stores.
+template <int KB, int NT, bool LAST>
+__device__ __forceinline__ void sa3_layer_multi(const Ctx &c, const SaArgs &a, int l, int mt, int nt0, int sub, int per,
+                                                int src_off, int dst_off, int T, int tiles_per_cloud, int total_tiles) {
+  const int col = c.lane & 15, kq = c.lane >> 4, g = kq;
+  const WStream wv(a.weights + a.w_off[l], c.lane);
+  u32x4 af[KB][3];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) af[kb][pl] = wv.raw_at((mt * KB + kb) * 3072, pl * 1024);
+  const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq);
+  const int cpt = 64 / a.u, tpc = a.u >> 4;
+  for (int st = 0; st < sub; ++st) {
+    const lds_u4 *pl3 = (const lds_u4 *)(c.lds + st * per + src_off) + g * 64 + 16 * nt0 + col;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[ni] = bv;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      u32x4 bs[NT][3];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bs[ni][pl] = pl3[(kb * 3 + pl) * 256 + 16 * ni];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) acc[ni] = mfma_split6(af[kb], bs[ni], acc[ni]);
+    }
+    if constexpr (!LAST) {
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+        store_planes4(c.lds + st * per + dst_off, 16 * mt + 4 * kq, 16 * (nt0 + ni) + col, fmaxf(acc[ni][0], 0.f),
+                      fmaxf(acc[ni][1], 0.f), fmaxf(acc[ni][2], 0.f), fmaxf(acc[ni][3], 0.f));
+    } else {
+      static_assert(!LAST || NT == 4, "the max runs over all four n-tiles of a tile");
+      const int t = T * sub + st;
+      if (t < total_tiles) {   // wave uniform
+        const int b = t / tiles_per_cloud, j0 = (t - b * tiles_per_cloud) * cpt;
+        float *outb = a.out + (size_t)b * a.cout[l] * a.m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float m[4];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) m[ni] = acc[ni < NT ? ni : 0][r];
+          if (tpc >= 2) { m[0] = fmaxf(m[0], m[1]); m[2] = fmaxf(m[2], m[3]); }
+          if (tpc >= 4) m[0] = fmaxf(m[0], m[2]);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            if (ni % tpc) continue;  // wave uniform
+            const float v = fmaxf(row16_max(m[ni]), 0.f);
+            const int jj = ni / tpc;
+            if (col == 0 && j0 + jj < a.m) outb[(size_t)(16 * mt + 4 * kq + r) * a.m + j0 + jj] = v;
+          }
+        }
+      }
+    }
+  }
+}
+template <int NT, bool LAST>
+__device__ __forceinline__ void sa3_layer_multi_kb(const Ctx &c, const SaArgs &a, int l, int mt, int nt0, int sub, int per,
+                                                   int src_off, int dst_off, int T, int tiles_per_cloud, int total_tiles) {
+  switch (a.cin_pad[l] >> 5) {
+    case 1: sa3_layer_multi<1, NT, LAST>(c, a, l, mt, nt0, sub, per, src_off, dst_off, T, tiles_per_cloud, total_tiles); break;
+    case 2: sa3_layer_multi<2, NT, LAST>(c, a, l, mt, nt0, sub, per, src_off, dst_off, T, tiles_per_cloud, total_tiles); break;
+    default: sa3_layer_multi<4, NT, LAST>(c, a, l, mt, nt0, sub, per, src_off, dst_off, T, tiles_per_cloud, total_tiles); break;
+  }
+}
+
+// SUBMAX > 1: narrow nets (SSG SA1: 3 -> 64 -> 64 -> 128 over 512 centres per cloud) have 1.3 k cycles of MFMAs per
+// 64-column tile against ~13 k of per-tile cost (four barriers, three cold layer starts, the gather's round trip): a
+// workgroup then takes `sub` consecutive tiles at once -- their planes side by side in LDS, every layer swept over all of
+// them between two barriers, the weight fragments of the later ones coming from L1.  QUADS: row quads a gather thread
+// holds per tile (9 covers 288 input rows; the multi-tile form takes 32-row inputs: one quad).
+template <int SUBMAX, int QUADS>
+__global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blocks_a, int blocks_b, int sub,
+                                                         int tiles_per_cloud, int total_tiles) {
   extern __shared__ float lds[];
   Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
         0, 4};
   const int cpt = 64 / a.u;  // centres per tile
-  float *A = lds, *B = lds + (size_t)blocks_a * 3072;
+  const int per = (blocks_a + blocks_b) * 3072;   // floats of one tile's two plane regions
   const int w = c.wave, col = c.lane, qg = c.wave;   // gather: thread = (column, row-quad group)
   const int nquads = a.cin_pad[0] >> 2;
-  float gv[kSa3Quads][4];
-  auto gather_load = [&](int t) {
-    const int b = t / tiles_per_cloud, tile = t - b * tiles_per_cloud, j0 = tile * cpt, jj = col / a.u;
-    const bool live = j0 + jj < a.m;
-    const float *pts = a.points + (size_t)b * 3 * a.n, *ctr = a.centers + (size_t)b * 3 * a.m;
-    const float *feat = a.feat ? a.feat + (size_t)b * a.c * a.n : a.points;
-    const int32_t *idx = a.idx + ((size_t)b * a.m + j0) * a.u;
-    const int id = live ? idx[col] : 0;
-    const int jc = live ? j0 + jj : 0, cmax = a.c > 0 ? a.c - 1 : 0;
+  const int supers = (total_tiles + sub - 1) / sub;
+  float gv[SUBMAX][QUADS][4];
+  auto gather_load = [&](int T) {
 #pragma unroll
-    for (int i = 0; i < kSa3Quads; ++i) {
-      const int rq = qg + 8 * i;   // rows 4 rq .. 4 rq + 3: [x y z f0] for quad 0, f[4 rq - 3 ..] after it
+    for (int st = 0; st < SUBMAX; ++st) {
+      const int t0 = T * sub + (st < sub ? st : 0);
+      const int t = t0 < total_tiles ? t0 : total_tiles - 1;   // clamped: every load stays unconditional
+      const int b = t / tiles_per_cloud, tile = t - b * tiles_per_cloud, j0 = tile * cpt, jj = col / a.u;
+      const bool live = j0 + jj < a.m;
+      const float *pts = a.points + (size_t)b * 3 * a.n, *ctr = a.centers + (size_t)b * 3 * a.m;
+      const float *feat = a.feat ? a.feat + (size_t)b * a.c * a.n : a.points;
+      const int32_t *idx = a.idx + ((size_t)b * a.m + j0) * a.u;
+      const int id = live ? idx[col] : 0;
+      const int jc = live ? j0 + jj : 0, cmax = a.c > 0 ? a.c - 1 : 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int ch = 4 * rq + e;
-        float v;
-        if (ch < 3) v = pts[ch * a.n + id] - ctr[ch * a.m + jc];
-        else { const int f = ch - 3; v = feat[(size_t)(f < cmax ? f : cmax) * a.n + id]; v = f < a.c ? v : 0.f; }
-        gv[i][e] = live ? v : 0.f;
+      for (int i = 0; i < QUADS; ++i) {
+        const int rq = qg + 8 * i;   // rows 4 rq .. 4 rq + 3: [x y z f0] for quad 0, f[4 rq - 3 ..] after it
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ch = 4 * rq + e;
+          float v;
+          if (ch < 3) v = pts[ch * a.n + id] - ctr[ch * a.m + jc];
+          else { const int f = ch - 3; v = feat[(size_t)(f < cmax ? f : cmax) * a.n + id]; v = f < a.c ? v : 0.f; }
+          gv[st][i][e] = live ? v : 0.f;
+        }
       }
     }
   };
   auto gather_store = [&]() {
 #pragma unroll
-    for (int i = 0; i < kSa3Quads; ++i) {
-      const int rq = qg + 8 * i;
-      if (rq < nquads) store_planes4(A, 4 * rq, col, gv[i][0], gv[i][1], gv[i][2], gv[i][3]);
+    for (int st = 0; st < SUBMAX; ++st) {
+      if (st < sub) {
+#pragma unroll
+        for (int i = 0; i < QUADS; ++i) {
+          const int rq = qg + 8 * i;
+          if (rq < nquads) store_planes4(lds + st * per, 4 * rq, col, gv[st][i][0], gv[st][i][1], gv[st][i][2], gv[st][i][3]);
+        }
+      }
     }
   };
   Frag3 frag;   // block-0 fragments of the wave's first m-tile of the NEXT layer to run
   // The request for the next layer's first fragments sits behind this layer's (first) k-loop, in front of its stores: in
   // flight under the epilogue and the barrier.  Straight-line code: the fragments travel by value.
-  auto hidden = [&](int l, const float *src, float *dst) {
+  auto hidden = [&](int l, bool a_to_b) {
     const int mtiles = a.cout[l] >> 4;
     Ctx cl = c;
     asm volatile("" : "+v"(cl.tid), "+v"(cl.lane));
+    if constexpr (SUBMAX > 1) {   // weights once per layer, the tiles stream through (sa3_layer_multi)
+      const int so = a_to_b ? 0 : blocks_a * 3072, dof = a_to_b ? blocks_a * 3072 : 0;
+      if (mtiles >= 8) {
+        for (int p = 0; p < (mtiles >> 3); ++p) sa3_layer_multi_kb<4, false>(cl, a, l, w + 8 * p, 0, sub, per, so, dof, 0, 1, 0);
+      } else if (mtiles == 4) sa3_layer_multi_kb<2, false>(cl, a, l, w & 3, 2 * (w >> 2), sub, per, so, dof, 0, 1, 0);
+      else sa3_layer_multi_kb<1, false>(cl, a, l, w & 1, w >> 1, sub, per, so, dof, 0, 1, 0);
+      return;
+    }
     const Frag3 cur = frag;
-    if (mtiles == 8) frag = sa3_hidden<4, Frag3, true>(cl, a, l, w, 0, src, dst, cur);
-    else if (mtiles == 16) {
-      sa3_hidden<4, Frag3, false>(cl, a, l, w, 0, src, dst, cur);
-      frag = sa3_hidden<4, NoFirst, true>(cl, a, l, w + 8, 0, src, dst, NoFirst());
-    } else if (mtiles == 4) frag = sa3_hidden<2, Frag3, true>(cl, a, l, w & 3, 2 * (w >> 2), src, dst, cur);
-    else frag = sa3_hidden<1, Frag3, true>(cl, a, l, w & 1, w >> 1, src, dst, cur);
+    for (int st = 0; st < sub; ++st) {
+      const float *src = lds + st * per + (a_to_b ? 0 : blocks_a * 3072);
+      float *dst = lds + st * per + (a_to_b ? blocks_a * 3072 : 0);
+      if (st == 0) {
+        if (mtiles == 8) frag = sa3_hidden<4, Frag3, true>(cl, a, l, w, 0, src, dst, cur);
+        else if (mtiles == 16) {
+          sa3_hidden<4, Frag3, false>(cl, a, l, w, 0, src, dst, cur);
+          frag = sa3_hidden<4, NoFirst, true>(cl, a, l, w + 8, 0, src, dst, NoFirst());
+        } else if (mtiles == 4) frag = sa3_hidden<2, Frag3, true>(cl, a, l, w & 3, 2 * (w >> 2), src, dst, cur);
+        else frag = sa3_hidden<1, Frag3, true>(cl, a, l, w & 1, w >> 1, src, dst, cur);
+      } else if constexpr (SUBMAX > 1) {
+        if (mtiles == 8) sa3_hidden<4, NoFirst, false>(cl, a, l, w, 0, src, dst, NoFirst());
+        else if (mtiles == 16) {
+          sa3_hidden<4, NoFirst, false>(cl, a, l, w, 0, src, dst, NoFirst());
+          sa3_hidden<4, NoFirst, false>(cl, a, l, w + 8, 0, src, dst, NoFirst());
+        } else if (mtiles == 4) sa3_hidden<2, NoFirst, false>(cl, a, l, w & 3, 2 * (w >> 2), src, dst, NoFirst());
+        else sa3_hidden<1, NoFirst, false>(cl, a, l, w & 1, w >> 1, src, dst, NoFirst());
+      }
+    }
   };
-  int t = blockIdx.x;
-  gather_load(t);
+  int T = blockIdx.x;
+  gather_load(T);
   frag = sa3_request(c, a, 0);
   gather_store();
   __syncthreads();
-  for (; t < total_tiles; t += gridDim.x) {
-    const int b = t / tiles_per_cloud, j0 = (t - b * tiles_per_cloud) * cpt;
-    float *outb = a.out + (size_t)b * a.cout[a.n_layers - 1] * a.m;
-    float *src = A, *dst = B;
+  for (; T < supers; T += gridDim.x) {
+    bool a_to_b = true;
     for (int l = 0; l + 1 < a.n_layers; ++l) {
-      hidden(l, src, dst);
+      hidden(l, a_to_b);
       __syncthreads();
-      float *tsw = src; src = dst; dst = tsw;
+      a_to_b = !a_to_b;
     }
-    const int tn = t + (int)gridDim.x < total_tiles ? t + (int)gridDim.x : t;
-    gather_load(tn);
+    const int Tn = T + (int)gridDim.x < supers ? T + (int)gridDim.x : T;
+    gather_load(Tn);
     {
       const int l = a.n_layers - 1, mtiles = a.cout[l] >> 4;
       Ctx cl = c;
       asm volatile("" : "+v"(cl.tid), "+v"(cl.lane));
+      if constexpr (SUBMAX > 1) {
+        const int so = a_to_b ? 0 : blocks_a * 3072;
+        for (int mt = w; mt < mtiles; mt += 8) sa3_layer_multi_kb<4, true>(cl, a, l, mt, 0, sub, per, so, 0, T, tiles_per_cloud, total_tiles);
+      }
       const Frag3 cur = frag;
-      if (w < mtiles) sa3_last<Frag3>(cl, a, l, w, src, j0, outb, cur);
-      for (int mt = w + 8; mt < mtiles; mt += 8) sa3_last<NoFirst>(cl, a, l, mt, src, j0, outb, NoFirst());
+      for (int st = 0; st < (SUBMAX > 1 ? 0 : sub); ++st) {
+        const int t = T * sub + st;
+        if (t >= total_tiles) break;   // wave uniform
+        const int b = t / tiles_per_cloud, j0 = (t - b * tiles_per_cloud) * cpt;
+        float *outb = a.out + (size_t)b * a.cout[l] * a.m;
+        const float *src = lds + st * per + (a_to_b ? 0 : blocks_a * 3072);
+        if (st == 0) {
+          if (w < mtiles) sa3_last<Frag3>(cl, a, l, w, src, j0, outb, cur);
+        } else {
+          if (w < mtiles) sa3_last<NoFirst>(cl, a, l, w, src, j0, outb, NoFirst());
+        }
+        for (int mt = w + 8; mt < mtiles; mt += 8) sa3_last<NoFirst>(cl, a, l, mt, src, j0, outb, NoFirst());
+      }
       frag = sa3_request(c, a, 0);   // the next tile's first layer
     }
     __syncthreads();  // the last layer may have been reading region A
@@ -4531,16 +4654,32 @@ GLDM_API int gldm_sa_mlp_forward_bf16x3(const float *points, const float *center
   }
   if (cin_pad[0] < 3 + c || cin_pad[0] > 32 * kSa3Quads) return GLDM_ERR_UNSUPPORTED;
   blocks_a = blocks_a > (cin_pad[0] >> 5) ? blocks_a : (cin_pad[0] >> 5);
-  const size_t lds_bytes = (size_t)(blocks_a + blocks_b) * 3072 * sizeof(float);
-  if (lds_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
-  struct Sa3Tag { int site; };
-  gldm_dev::allow_dynamic_lds<Sa3Tag>(reinterpret_cast<const void *>(&sa_mlp3_kernel), 160 * 1024);
+  const size_t tile_bytes = (size_t)(blocks_a + blocks_b) * 3072 * sizeof(float);
+  if (tile_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
   const int cpt = 64 / u, tpc = (m + cpt - 1) / cpt, total = tpc * b;
-  const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
-  int grid = cu_count() * per_cu;
-  if (grid > total) grid = total;
-  hipLaunchKernelGGL(sa_mlp3_kernel, dim3(grid), dim3(512), lds_bytes, reinterpret_cast<hipStream_t>(stream), a, blocks_a,
-                     tpc, total);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // narrow nets (32-row inputs, every K in {32, 64, 128}): the multi-tile kernel -- the layer's weights once per
+  // workgroup pass, `sub` tiles' planes side by side in LDS (SSG SA1: three 48 KiB tiles, 2.52 -> 2.07 ms).  Two
+  // co-resident workgroups of one tile each (the kernel fits 128 registers) measured slower: 2.40 ms.
+  bool kb_ok = cin_pad[0] == 32;
+  for (int l = 0; l < n_layers; ++l) kb_ok = kb_ok && (cin_pad[l] == 32 || cin_pad[l] == 64 || cin_pad[l] == 128);
+  int sub = kb_ok ? (int)((size_t)160 * 1024 / tile_bytes) : 1;
+  if (sub > 4) sub = 4;
+  while (sub > 1 && (total + sub - 1) / sub < 2 * cu_count()) --sub;
+  if (sub > 1) {
+    struct Sa3mTag { int site; };
+    gldm_dev::allow_dynamic_lds<Sa3mTag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<4, 1>), 160 * 1024);
+    const int supers = (total + sub - 1) / sub;
+    const int grid = supers < cu_count() ? supers : cu_count();
+    hipLaunchKernelGGL((sa_mlp3_kernel<4, 1>), dim3(grid), dim3(512), tile_bytes * sub, s, a, blocks_a, blocks_b, sub, tpc, total);
+  } else {
+    struct Sa3Tag { int site; };
+    gldm_dev::allow_dynamic_lds<Sa3Tag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<1, kSa3Quads>), 160 * 1024);
+    const int per_cu = tile_bytes * 2 <= 160 * 1024 ? 2 : 1;
+    int grid = cu_count() * per_cu;
+    if (grid > total) grid = total;
+    hipLaunchKernelGGL((sa_mlp3_kernel<1, kSa3Quads>), dim3(grid), dim3(512), tile_bytes, s, a, blocks_a, blocks_b, 1, tpc, total);
+  }
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 
