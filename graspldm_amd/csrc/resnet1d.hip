@@ -1068,7 +1068,7 @@ __device__ __forceinline__ void gemm_passes(const Ctx &c, const float *wp, int m
             const int mt = mt0 + p * MT + mi;
             const int row0 = 16 * mt + 4 * kq;
             f32x4 sc = sc0[p][mi], sh = sh0[p][mi];
-            const float *tab = L == 16 ? c.ss_row[(nt0 + ni) & 1] : nullptr;  // wave uniform
+            const float *tab = L == 16 ? (((nt0 + ni) & 1) ? c.ss_row[1] : c.ss_row[0]) : nullptr;  // wave uniform (a select: a run-time index keeps Ctx in scratch)
             if (has_ss && wide && tab) {
               // The pose decoder's embedding does not depend on the grasp: the rows were computed once per cloud
               // (ss_table_kernel).  In here they cost 32 MFMAs per m-tile and SAMPLE (E = 64), 17 % on top of a
@@ -2991,12 +2991,14 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     }
   }
   // ---- latent row for this tile: from the input (first step) or from the slot that ran the steps before s0
-  if (c.tid < NC) {
-    const int s = samp_of(c.tid), l = pos_of(c.tid);
+  int tid_s = c.tid;   // opaque (see tid_o below): the segment prologue's pointers are rebuilt per segment, not kept from kernel start
+  asm volatile("" : "+v"(tid_s));
+  if (tid_s < NC) {
+    const int s = samp_of(tid_s), l = pos_of(tid_s);
     const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
     float v;
     if (s0 > 0) {
-      v = chain_take(state + (size_t)tile * NC + c.tid, chain_tag(epoch, s0), &hdr->error);
+      v = chain_take(state + (size_t)tile * NC + tid_s, chain_tag(epoch, s0), &hdr->error);
     } else if (has_in) {
       const float *wi = a.weights + d.in_w + l * d.latent_dim;
       v = a.weights[d.in_b + l];
@@ -3004,7 +3006,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     } else {
       v = a.x_in[(size_t)gi * L + l];
     }
-    lat[c.tid] = v;
+    lat[tid_s] = v;
   }
   __syncthreads();
 
@@ -3015,8 +3017,8 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   constexpr int kMaxR = 4;
   const bool g_fast = S * E <= GG::kThreads && R <= kMaxR && !a.sample_t;
   float ce_reg[kMaxR] = {0.f, 0.f, 0.f, 0.f}, se_reg = 0.f, te_next = 0.f;
-  if (g_fast && c.tid < S * E) {
-    const int s = c.tid / E, e = c.tid - s * E;
+  if (g_fast && tid_s < S * E) {
+    const int s = tid_s / E, e = tid_s - s * E;
     const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
     const float *ce = a.cemb + ((size_t)(gi / a.samples_per_cond) * R) * E + e;
 #pragma unroll
@@ -3026,18 +3028,23 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   }
   for (int step = s0; step < s1; ++step) {
     if (GLDM_STAMPS(a.stamps) && blockIdx.x == 0 && c.tid == 0) a.stamps[kMaxOps + 1] = (long long)__builtin_readcyclecounter();
+    // The thread index as this step's short phases see it: opaque, so that the index maps and LDS addresses derived from
+    // it are recomputed here (a handful of integer instructions) instead of being hoisted out of the step loop, kept
+    // across the whole op tape and spilled (14 scratch reloads per step, each a round trip in front of its use).
+    int tid_o = c.tid;
+    asm volatile("" : "+v"(tid_o));
     // ---- G[s][e] = sum_r silu(temb[t][e] + cemb[cond][r][e])
     if (g_fast) {
-      if (c.tid < S * E) {
+      if (tid_o < S * E) {
         const float te = te_next + se_reg;
-        if (a.temb) te_next = a.temb[(size_t)a.timesteps[step + 1 < s1 ? step + 1 : step] * E + (c.tid % E)];
+        if (a.temb) te_next = a.temb[(size_t)a.timesteps[step + 1 < s1 ? step + 1 : step] * E + (tid_o % E)];
         float g = 0.f;
 #pragma unroll
         for (int r = 0; r < kMaxR; ++r) g += r < R ? silu(te + ce_reg[r]) : 0.f;
-        G[c.tid] = g;
+        G[tid_o] = g;
       }
     } else if (!GLDM_SKIP(c, 32))
-    for (int i = c.tid; i < S * E; i += GG::kThreads) {
+    for (int i = tid_o; i < S * E; i += GG::kThreads) {
       const int s = i / E, e = i - s * E;
       const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
       const float *ce = a.cemb + ((size_t)(gi / a.samples_per_cond) * R) * E + e;
@@ -3057,7 +3064,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     const float in_scale = a.sched_kind == GLDM_SCHED_DPMPP ? a.sched_coef[(size_t)step * GLDM_SCHED_COEF_STRIDE] : 1.0f;
     const bool scale_in = a.sched_kind == GLDM_SCHED_DPMPP;
     if (!GLDM_SKIP(c, 64))
-    for (int i = c.tid; i < C0 * NC; i += GG::kThreads) {
+    for (int i = tid_o; i < C0 * NC; i += GG::kThreads) {
       const int ch = i / NC, n = i - ch * NC;
       const int l = pos_of(n), sm = samp_of(n);
       float acc = a.weights[d.init_b + ch];
@@ -3111,27 +3118,30 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       }
       const float final_b = a.weights[d.final_b];
       float *red1 = lds + GG::kMiscRed1;
-      const int n = c.lane & (NC - 1), slot = c.wave * GG::kRP + c.lane / NC;
+      int tid_f = c.tid;
+      asm volatile("" : "+v"(tid_f));
+      const int lane_f = tid_f & 63;
+      const int n = lane_f & (NC - 1), slot = c.wave * GG::kRP + lane_f / NC;
       float part = 0.f;
       for (int row = slot; row < CF; row += GG::kSlots)
         part += a.weights[d.final_w + row] * X[PM ? pswz(row, n) : swz<NC>(row, n)];
       if (GG::kRP == 2) part = half_sum(part);
       red1[c.wave * NC + n] = part;
       __syncthreads();
-      if (c.tid < NC) {
+      if (tid_f < NC) {
         float e = final_b;
 #pragma unroll
-        for (int q = 0; q < GG::kWaves; ++q) e += red1[q * NC + c.tid];
-        epsr[c.tid] = e;
+        for (int q = 0; q < GG::kWaves; ++q) e += red1[q * NC + tid_f];
+        epsr[tid_f] = e;
         if (a.sched_kind != GLDM_SCHED_NONE) {
-          const int s = samp_of(c.tid), l = pos_of(c.tid);
+          const int s = samp_of(tid_f), l = pos_of(tid_f);
           const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
           const float cf[8] = {cf_lo[0], cf_lo[1], cf_lo[2], cf_lo[3], cf_hi[0], cf_hi[1], cf_hi[2], cf_hi[3]};
           float nz = 0.f;
           if (a.sched_kind == GLDM_SCHED_DDPM && cf[7] != 0.f && a.step_noise)
             nz = a.step_noise[((size_t)step * a.n_samples + gi) * L + l];
-          if (a.sched_kind == GLDM_SCHED_DPMPP) lat[c.tid] = dpmpp_update(a.clip_sample, cf, lat[c.tid], e, lds + GG::kMiscOld + c.tid);
-          else lat[c.tid] = scheduler_update(a.sched_kind, a.clip_sample, cf, lat[c.tid], e, nz);
+          if (a.sched_kind == GLDM_SCHED_DPMPP) lat[tid_f] = dpmpp_update(a.clip_sample, cf, lat[tid_f], e, lds + GG::kMiscOld + tid_f);
+          else lat[tid_f] = scheduler_update(a.sched_kind, a.clip_sample, cf, lat[tid_f], e, nz);
         }
       }
       __syncthreads();
@@ -3139,19 +3149,21 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   }
 
   // ---- outputs of the segment: the result after the last step, else the latent for the next slot of the chain
+  int tid_e = c.tid;   // opaque like tid_o: nothing derived from it lives across the steps
+  asm volatile("" : "+v"(tid_e));
   if (s1 < N) {
-    if (c.tid < NC) chain_give(state + (size_t)tile * NC + c.tid, lat[c.tid], chain_tag(epoch, s1));
+    if (tid_e < NC) chain_give(state + (size_t)tile * NC + tid_e, lat[tid_e], chain_tag(epoch, s1));
   } else if (!has_head) {
-    if (c.tid < NC) {
-      const int s = samp_of(c.tid), l = pos_of(c.tid);
+    if (tid_e < NC) {
+      const int s = samp_of(tid_e), l = pos_of(tid_e);
       const int gi = samp0 + s;
-      if (s < nsamp && gi < a.n_samples) a.out0[(size_t)gi * L + l] = a.sched_kind == GLDM_SCHED_NONE ? epsr[c.tid] : lat[c.tid];
+      if (s < nsamp && gi < a.n_samples) a.out0[(size_t)gi * L + l] = a.sched_kind == GLDM_SCHED_NONE ? epsr[tid_e] : lat[tid_e];
     }
   } else {
     // heads: rows 0..5 tmrp, row 6 class logit; input = the L-vector of each sample
     const int nh = d.n_head;
-    if (c.tid < S * nh) {
-      const int s = c.tid / nh, r = c.tid - s * nh;
+    if (tid_e < S * nh) {
+      const int s = tid_e / nh, r = tid_e - s * nh;
       const int gi = samp0 + s;
       if (s < nsamp && gi < a.n_samples) {
         const float *wr = a.weights + d.head_w + r * L;

@@ -14,4 +14,9 @@ ARGS="$@"
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run mfma GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU
+if [ -n "$PMCK_MORE" ]; then   # optional groups: where the waves wait, LDS conflicts, L2 hit rate
+  run wait GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS
+  run lds GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS
+  run l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+fi
 cd $GRAFT_REPO_ROOT && python3 tools/pmc_kernels_summary.py gpurun_out/pmck_$tag gpurun_out/pmck_$tag.json | tee gpurun_out/pmck_$tag.txt
