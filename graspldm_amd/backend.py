@@ -112,7 +112,7 @@ class _HipBackend:
         r = int(resolution)
         dev = features.device
         ind = torch.zeros((b, n), dtype=torch.int32, device=dev)
-        out = torch.empty((b, c, r ** 3), dtype=torch.float32, device=dev)  # zero-filled by the C entry point
+        out = torch.empty((b, c, r ** 3), dtype=torch.float32, device=dev)  # every voxel is written by the C entry point
         cnt = torch.empty((b, r ** 3), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             L.call("gldm_avg_voxelize_forward", L.ptr(features), L.ptr(coords), b, c, n, r, L.ptr(out), L.ptr(ind),
