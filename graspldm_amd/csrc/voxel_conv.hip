@@ -579,6 +579,139 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   GLDM_C3_STAMP(21);
 }
 
+// ---- split-bf16 conv of a FEW input channels (the encoder's first voxel conv: 3 -> 48 at 24^3) ------------------------
+// With k = tap * 16 + ci (conv3d_k3_kernel, JN = 1) a 3-channel input pays 27 k-steps of 4 on the f32 pipe for 81 real
+// products per output: 0.49 ms per 256 clouds at 0.55 matrix-pipe occupancy, for a tensor whose store takes 0.1 ms.  Here
+// K is packed tap-major, channel-minor without padding between taps: k = tap * CIN + ci < 27 CIN, rounded up ONCE to a
+// multiple of 32 (CIN = 3: 81 -> 96 = three k-blocks of v_mfma_f32_16x16x32_bf16), six bf16 partial products per f32
+// product as everywhere else.  Lane (g, col) of a B fragment gathers its 8 consecutive k = (tap, ci) pairs of its voxel
+// from the f32 brick in LDS (8 ds_read_b32 at per-lane offsets, one n-tile ahead of their use) and splits them; the A
+// planes of a k-block (MT m-tiles x 3 planes) are read once per workgroup.  A workgroup of 8 waves owns a 4 x 4 x R
+// brick, R / 8 n-tiles per wave, 117 registers: two workgroups per CU; the haloed input brick is CIN x 6 x 6 x (R + 2)
+// floats (11 KiB at R = 24).  0.32 ms.  (Measured and dropped: persistent workgroups with the weight planes in LDS and the
+// next brick's input requested under the current k-loop -- 216 registers, one workgroup per CU: 0.41 ms; the same with
+// two 4-wave workgroups per CU spills: 0.59 ms.)  Weights: graspldm_amd/voxel.py: pack_conv3d_fewch_bf16x3.
+template <int MT, int R, int CIN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void conv3d_k3_fewch_bf_kernel(const float *__restrict__ x,
+                                                                           const float *__restrict__ wp3,
+                                                                           const float *__restrict__ bias,
+                                                                           float *__restrict__ y,
+                                                                           float *__restrict__ partial) {
+  constexpr int r = R, NTW = R / WAVES, kThreads = 64 * WAVES, zp = R + 2, nvox = 36 * zp, r3 = r * r * r;
+  static_assert(R % WAVES == 0, "whole n-tiles per wave");
+  constexpr int K = 27 * CIN, KB = (K + 31) / 32, cout = 16 * MT;
+  constexpr int cs = nvox + ((nvox & 31) == 0 ? 8 : 0);   // channel stride in LDS
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 15, g = lane >> 4;
+  const int bpr = r / kBrick;
+  const int bx0 = (blockIdx.x / bpr) * kBrick, by0 = (blockIdx.x % bpr) * kBrick;
+  const int b = blockIdx.y;
+  x += (size_t)b * CIN * r3;
+  y += (size_t)b * cout * r3;
+  // ---- the haloed brick, f32, zero outside the grid
+  for (int i = tid; i < CIN * nvox; i += kThreads) {
+    const int ci = i / nvox, v = i - ci * nvox;
+    const int ixy = v / zp, izp = v - ixy * zp;
+    const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1, gz = izp - 1;
+    float val = 0.f;
+    if ((unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r && (unsigned)gz < (unsigned)r)
+      val = x[(size_t)ci * r3 + (gx * r + gy) * r + gz];
+    lds[ci * cs + v] = val;
+  }
+  int vb[NTW], gvox[NTW];
+#pragma unroll
+  for (int ni = 0; ni < NTW; ++ni) {
+    const int o = 16 * (wave * NTW + ni) + col;
+    const int iz = o % r, ixy = o / r, ix = ixy >> 2, iy = ixy & 3;
+    vb[ni] = (ix * 6 + iy) * zp + iz;
+    gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + iz;
+  }
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const f32x4 bvv = *reinterpret_cast<const f32x4 *>(bias + 16 * mi + 4 * g);
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = bvv;
+  }
+  const WStream wv(wp3, lane);
+  const lds_f *l3 = (const lds_f *)lds;
+  __syncthreads();
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    c3_u32x4 a[MT][3];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[mi][pl] = wv.raw_at(((mi * KB + kb) * 3) * 1024, pl * 1024);
+    int off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 32 * kb + 8 * g + j;
+      const int tap = k / CIN, ci = k - tap * CIN;
+      // k >= K: zero weights; any finite brick element serves
+      off[j] = k < K ? ci * cs + ((tap / 9) * 6 + (tap / 3) % 3) * zp + tap % 3 : 0;
+    }
+    // the gathers run one n-tile ahead of the split + MFMAs that use them
+    float v[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[0][j] = l3[vb[0] + off[j]];
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) {
+      if (ni + 1 < NTW) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[(ni + 1) & 1][j] = l3[vb[ni + 1] + off[j]];
+      }
+      c3_u32x4 b3[3];
+      c3_split(v[ni & 1], b3);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = c3_mfma6(a[mi], b3, acc[mi][ni]);
+    }
+  }
+  // ---- epilogue: per-channel partial statistics of this brick, then the stores (as in conv3d_k3_pl_kernel)
+  __syncthreads();
+  float *s_part = lds;  // [WAVES][MT * 16][2]
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = 16 * mi + 4 * g + q;
+      float s = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < NTW; ++ni) {
+        const float v = acc[mi][ni][q];
+        s += v;
+        s2 += v * v;
+      }
+      s = row16_sum(s);
+      s2 = row16_sum(s2);
+      if (col == 0) {
+        s_part[(wave * MT * 16 + co) * 2] = s;
+        s_part[(wave * MT * 16 + co) * 2 + 1] = s2;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < cout) {
+    float s = 0.f, s2 = 0.f;
+    for (int w = 0; w < WAVES; ++w) {
+      s += s_part[(w * MT * 16 + tid) * 2];
+      s2 += s_part[(w * MT * 16 + tid) * 2 + 1];
+    }
+    float *p = partial + (((size_t)b * gridDim.x + blockIdx.x) * cout + tid) * 2;
+    p[0] = s;
+    p[1] = s2;
+  }
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = 16 * mi + 4 * g + q;
+#pragma unroll
+      for (int ni = 0; ni < NTW; ++ni) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
+    }
+}
+
 // GroupNorm(groups) + Swish over [B, C, r^3]; statistics from the conv's per-brick partials.
 // grid = (groups, B); optional per-channel sum of the OUTPUT (for the SE squeeze).
 __global__ __launch_bounds__(512) void groupnorm_swish_kernel(float *__restrict__ y, const float *__restrict__ partial,
@@ -991,8 +1124,14 @@ int launch_conv_pl(const float *x, const float *wp3, const float *bias, int b, i
 GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const float *bias, int b, int cin, int cout, int r,
                                    float *y, float *partial, gldm_stream_t stream) {
   if (!x || !w_split || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
-  if (cin % 16 || cout % 48) return GLDM_ERR_UNSUPPORTED;   // the kernels below: cout == 16 MT exactly, no row guards
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (cin == 3 && cout == 48 && r == 24) {   // the first voxel conv: K = 81 packed into three k-blocks
+    constexpr int kZp = 26, kNvox = 36 * kZp;
+    const size_t lds_bytes = (size_t)3 * (kNvox + ((kNvox & 31) == 0 ? 8 : 0)) * sizeof(float);
+    hipLaunchKernelGGL((conv3d_k3_fewch_bf_kernel<3, 24, 3, 8>), dim3(36, b), dim3(512), lds_bytes, s, x, w_split, bias, y, partial);
+    return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+  }
+  if (cin % 16 || cout % 48) return GLDM_ERR_UNSUPPORTED;   // the kernels below: cout == 16 MT exactly, no row guards
 #ifdef GLDM_DEBUG_KNOBS
   struct StampDump {  // diagnostic builds: GLDM_C3_STAMP=1 prints the phase clocks of one mid-grid workgroup per call
     hipStream_t s; int cin, cout, r, b;

@@ -24,8 +24,20 @@ def pack_conv3d(weight):
 
 
 def split_conv_supported(cin, cout, r):
-    """Shapes gldm_conv3d_k3_bf16x3 is built for (the shipped PVCNN encoder's 48 ch @ 24^3 and 96 ch @ 12^3)."""
-    return cin % 16 == 0 and (cout, r) in ((48, 24), (96, 12))
+    """Shapes gldm_conv3d_k3_bf16x3 is built for (the shipped PVCNN encoder's 48 ch @ 24^3 and 96 ch @ 12^3, and its
+    first conv 3 -> 48 @ 24^3 with K = 81 packed into three 32-deep blocks)."""
+    return (cin % 16 == 0 and (cout, r) in ((48, 24), (96, 12))) or (cin, cout, r) == (3, 48, 24)
+
+
+def pack_conv3d_fewch_bf16x3(weight):
+    """[cout, cin <= 4, 3, 3, 3] -> split-bf16 A fragments of [cout, roundup(27 cin, 32)], k = tap * cin + ci (tap-major,
+    no padding between taps), zero beyond 27 cin."""
+    from .r1d_pack import mfma_a_fragments_bf16x3
+    cout, cin = weight.shape[:2]
+    k = 27 * cin
+    w = torch.zeros(cout, (k + 31) // 32 * 32, dtype=torch.float32)
+    w[:, :k] = weight.detach().float().cpu().reshape(cout, cin, 27).permute(0, 2, 1).reshape(cout, k)
+    return mfma_a_fragments_bf16x3(w)
 
 
 def pack_conv3d_bf16x3(weight):
@@ -51,7 +63,8 @@ class VoxelBranchPlan:
         # shapes without an MFMA instantiation run the direct kernel on the raw nn.Conv3d weight
         self.generic = [r is not None and not conv_supported(c.out_channels, r) for c in convs]
         self.w = [(c.weight.detach().float().contiguous() if gen else
-                   (pack_conv3d_bf16x3(c.weight) if sp else pack_conv3d(c.weight))).to(device)
+                   ((pack_conv3d_fewch_bf16x3(c.weight) if c.in_channels < 16 else pack_conv3d_bf16x3(c.weight)) if sp
+                    else pack_conv3d(c.weight))).to(device)
                   for c, sp, gen in zip(convs, self.split, self.generic)]
         self.key = None  # set by the owner (PVConv.forward) from _cache.params_key
 

@@ -250,6 +250,38 @@ def test_conv3d_groupnorm_swish_kernels(cin, cout, r):
     assert _err(cs / r ** 3, ref2.mean(dim=(2, 3, 4))) < 1e-5
 
 
+@pytest.mark.parametrize("cin,cout,r", [(3, 48, 24), (48, 48, 24), (48, 96, 12), (96, 96, 12)])
+def test_conv3d_split_bf16_kernels(cin, cout, r):
+    """gldm_conv3d_k3_bf16x3 (the shipped encoder's four voxel convs; 3 -> 48 with K = 81 packed into three k-blocks) vs
+    torch conv3d on the CPU, and its GroupNorm partials through gldm_groupnorm_swish (fp32, 2e-5)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.nn.functional as F
+    from graspldm_amd import _lib as L
+    from graspldm_amd.voxel import pack_conv3d_bf16x3, pack_conv3d_fewch_bf16x3, split_conv_supported
+    assert split_conv_supported(cin, cout, r)
+    g = torch.Generator().manual_seed(cin * 100 + cout + 1)
+    b = 3
+    x = torch.randn(b, cin, r, r, r, generator=g)
+    x[:, :, ::3] = 0
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    bias, gamma, beta = (torch.randn(cout, generator=g) * 0.1 for _ in range(3))
+    gamma = gamma + 1
+    ref = F.conv3d(x, w, bias, padding=1)
+    y = torch.empty(b, cout, r, r, r, device="cuda")
+    part = torch.empty(int(L.lib().gldm_conv3d_partial_floats(b, cout, r)), device="cuda")
+    st = L.current_stream()
+    dw = (pack_conv3d_fewch_bf16x3(w) if cin < 16 else pack_conv3d_bf16x3(w)).cuda()
+    dx, db = x.cuda(), bias.cuda()
+    L.call("gldm_conv3d_k3_bf16x3", L.ptr(dx), L.ptr(dw), L.ptr(db), b, cin, cout, r, L.ptr(y), L.ptr(part), st)
+    assert _err(y, ref) < 2e-5, _err(y, ref)
+    gn = F.group_norm(ref, 8, gamma, beta, 1e-5)
+    ref2 = gn * torch.sigmoid(gn)
+    dg, dbt = gamma.cuda(), beta.cuda()
+    L.call("gldm_groupnorm_swish", L.ptr(y), L.ptr(part), L.ptr(dg), L.ptr(dbt), b, cout, r, 8, 1e-5, None, st)
+    assert _err(y, ref2) < 2e-5, _err(y, ref2)
+
+
 def test_ppc_config_z16_latent_against_oracle():
     """Second shipped experiment (configs/generation/partial_pc/ppc_1a_...z16_pc256: grasp latent 16,
     pc latent [3,256], denoiser dim 16 -> the L=16 time-conditioned engine): end-to-end LDM

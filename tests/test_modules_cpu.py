@@ -242,7 +242,26 @@ def test_conv3d_split_packing_walks_tap_pairs():
         assert f[co // 16, cb * 14 + pair, 0, lane, j].item() == hi[co, ci, tap].item()
     # the empty half of the last pair
     assert (f[:, 13, :, 32:, :] == 0).all() and (f[:, 27, :, 32:, :] == 0).all()
-    assert split_conv_supported(48, 48, 24) and split_conv_supported(96, 96, 12) and not split_conv_supported(3, 48, 24)
+    assert split_conv_supported(48, 48, 24) and split_conv_supported(96, 96, 12) and not split_conv_supported(3, 32, 32)
+
+
+def test_conv3d_few_channel_split_packing_is_tap_major_without_padding():
+    """pack_conv3d_fewch_bf16x3 (the encoder's first voxel conv, 3 -> 48 @ 24^3): k = tap * cin + ci, 81 real columns in
+    three 32-deep blocks, zero beyond."""
+    from graspldm_amd.voxel import pack_conv3d_fewch_bf16x3, split_conv_supported
+    from graspldm_amd.r1d_pack import split_bf16x3
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(48, 3, 3, 3, 3, generator=g)
+    f = pack_conv3d_fewch_bf16x3(w).view(torch.bfloat16).view(3, 3, 3, 64, 8)       # [mt][kb][plane][lane][j]
+    planes = split_bf16x3(w.reshape(48, 3, 27))
+    for co, ci, tap in [(0, 0, 0), (17, 2, 13), (47, 1, 26), (5, 0, 10), (31, 2, 26)]:
+        k = tap * 3 + ci
+        kb, g8, j = k // 32, (k % 32) // 8, k % 8
+        for pl in range(3):
+            assert f[co // 16, kb, pl, (co % 16) + 16 * g8, j].item() == planes[pl][co, ci, tap].item()
+    # columns 81 .. 95: lane groups 2 (j >= 1) and 3 of the last block
+    assert (f[:, 2, :, 48:, :] == 0).all() and (f[:, 2, :, 32:48, 1:] == 0).all()
+    assert split_conv_supported(3, 48, 24)
 
 
 def test_pad_cin32_and_16_position_descriptors():
