@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # GLDM_LIB: another build of the same library (diagnostic builds: make -C graspldm_amd/csrc EXTRA=... OUT=...)
 LIB_PATH = os.environ.get("GLDM_LIB") or os.path.join(_PKG, "libgldm_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GldmError(RuntimeError):
@@ -42,10 +42,14 @@ _SIGNATURES = {
     "gldm_conv3d_k3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_conv3d_k3_generic": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_conv3d_k3_bf16x3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "gldm_conv3d_k3_bf16x3_gn": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "gldm_groupnorm_coef": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
+    "gldm_gn_swish_chan_sum": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "gldm_groupnorm_swish": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "gldm_se_gate": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "gldm_bias_act": [_vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp],
     "gldm_devoxelize_fused": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "gldm_devoxelize_gn_fused": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_pointwise_mlp2": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_pointwise_small": [_vp, _vp, _vp, _i, _i, _i, ctypes.c_longlong, _i, _vp, _vp],

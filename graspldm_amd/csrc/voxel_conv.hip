@@ -357,7 +357,7 @@ constexpr int kPairs = 14;  // tap pairs per 16-channel block (the last one hold
 // Splitting a lane's 8 channels of a voxel for every (tap pair, n-tile) that touches it means ~27 splits per element
 // and wave, 36 VALU instructions per 18-36 MFMAs, with the two waves of a SIMD doing it in lock step.  Here the
 // staging threads split each brick element ONCE and keep the three bf16 planes in LDS, channel-minor:
-//   [plane hi|mid|lo][voxel of the 6 x 6 x (r + 2) haloed brick][16 channels]      (32 B per voxel and plane)
+//   [plane hi|mid|lo][channel half][voxel of the 6 x 6 x (r + 2) haloed brick][8 channels]   (16 B per voxel, half and plane)
 // so a B fragment plane is ONE ds_read_b128 per lane (voxel of its column + the tap of its lane group, channel half)
 // and the tap loop is LDS reads + buffer loads + MFMA.  96 B per voxel instead of 64: the 24^3 brick takes 90 KiB, one
 // workgroup of 8 waves per CU (3 n-tiles each); the 12^3 brick 48 KiB, 4 waves, three workgroups per CU.
@@ -367,12 +367,18 @@ constexpr int kPairs = 14;  // tap pairs per 16-channel block (the last one hold
 // (x, y) -- 48 KiB of planes instead of 90, three workgroups of 4 waves per CU instead of one of 8, so that one brick's
 // staging, barriers and epilogue run under another's MFMAs, like the 12^3 conv always did; the two halves of a brick add
 // their GroupNorm partials into one zeroed slot with atomics: two addends, so the sum does not depend on their order).
-template <int MT, int R, int ZB, int WAVES>
+// ACT: the input is the RAW output of the previous conv and GroupNorm + Swish are applied while the brick is staged:
+// x' = swish(a[b][ch] x + s[b][ch]) per in-grid element, (a, s) = in_coef (gldm_groupnorm_coef: the previous conv's partial
+// statistics folded with the norm's affine).  The zero padding outside the grid is the activated tensor's padding and stays
+// zero.  Replaces a read + write pass of groupnorm_swish_kernel over the tensor (0.26 ms at 48 ch @ 24^3 per 256 clouds) by
+// ~9 VALU instructions per staged element under the co-resident waves' MFMAs.
+template <int MT, int R, int ZB, int WAVES, bool ACT = false>
 __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) void conv3d_k3_pl_kernel(const float *__restrict__ x,
                                                                                       const float *__restrict__ wp3,
                                                                                       const float *__restrict__ bias, int cin,
                                                                                       int cout, float *__restrict__ y,
-                                                                                      float *__restrict__ partial) {
+                                                                                      float *__restrict__ partial,
+                                                                                      const float *__restrict__ in_coef) {
   constexpr int r = R, NTW = ZB / WAVES, kThreads = 64 * WAVES, kZParts = R / ZB;
   static_assert(NTW % 3 == 0 && MT % 3 == 0 && R % ZB == 0, "tiles walked in 3 x 3 groups");
   constexpr int MG = MT / 3, NG = NTW / 3;
@@ -394,7 +400,8 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   y += (size_t)b * cout * r3;
   const WStream wv(wp3, lane);
   typedef __attribute__((address_space(3))) c3_u32x4 lds_c4;
-  lds_c4 *pl = (lds_c4 *)lds;   // 16-byte units: plane * 2 nvox + 2 voxel + half
+  lds_c4 *pl = (lds_c4 *)lds;   // 16-byte units: plane * 2 nvox + half * nvox + voxel: the 16 columns of a fragment row read
+                                // 16 consecutive units (256 B = every bank once); voxel-major pairs (32 B apart) were 2-way conflicts
 
   // fragment read base of (n-tile, lane column): voxel (0,0,0)-tap of the column, this lane's channel half
   int vb[NTW], gvox[NTW];
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   for (int ni = 0; ni < NTW; ++ni) {
     const int o = 16 * (wave * NTW + ni) + col;
     const int iz = o % ZB, ixy = o / ZB, ix = ixy >> 2, iy = ixy & 3;
-    vb[ni] = 2 * ((ix * 6 + iy) * zp + iz) + (kq & 1);
+    vb[ni] = (ix * 6 + iy) * zp + iz + (kq & 1) * nvox;
     gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + bz0 + iz;
   }
   f32x4 acc[MT][NTW];
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
       const int h = it / nvox, v = it - h * nvox;       // half-major: a wave's loads run along z
       const int ixy = v / zp, izp = v - ixy * zp;
       const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1, gz = bz0 + izp - 1;
-      s_lds[q] = 2 * v + h;
+      s_lds[q] = h * nvox + v;
       if ((unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r && (unsigned)gz < (unsigned)r)
         s_glb[q] = (gx * r + gy) * r + gz + 8 * h * r3;
     }
@@ -450,10 +457,27 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
       for (int j = 0; j < 8; ++j) stg[q][j] = xc[(size_t)j * r3 + g0];
     }
   };
-  auto stage_store = [&]() {
+  // ACT: (a, s) of every input channel of this cloud, behind the planes (the launcher adds the room): read back as
+  // wave-wide broadcasts of four 16-byte pairs-of-pairs per staged item
+  float *s_coef = lds + 3 * 2 * nvox * 4;   // [cin][2]
+  if constexpr (ACT) {
+    for (int i = tid; i < 2 * cin; i += kThreads) s_coef[i] = in_coef[(size_t)b * cin * 2 + i];
+  }
+  auto stage_store = [&](int cb) {
 #pragma unroll
     for (int q = 0; q < kRounds; ++q)
       if (s_glb[q] >= 0) {
+        if constexpr (ACT) {
+          const int h = (tid + q * kThreads) / nvox;
+          const f32x4 *cf = reinterpret_cast<const f32x4 *>(s_coef + 2 * (16 * cb + 8 * h));   // (a, s) x 8 channels
+#pragma unroll
+          for (int j2 = 0; j2 < 4; ++j2) {
+            const f32x4 c4 = cf[j2];
+            const float t0 = fmaf(stg[q][2 * j2], c4[0], c4[1]), t1 = fmaf(stg[q][2 * j2 + 1], c4[2], c4[3]);
+            stg[q][2 * j2] = t0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * t0));
+            stg[q][2 * j2 + 1] = t1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * t1));
+          }
+        }
         c3_u32x4 p3[3];
         c3_split(stg[q], p3);
 #pragma unroll
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   for (int cb = 0; cb < cblocks; ++cb) {
     __syncthreads();   // the previous block's readers are done
     if (cb < 3) GLDM_C3_STAMP(3 + 4 * cb);
-    stage_store();
+    stage_store(cb);
     if (cb + 1 < cblocks) stage_load(cb + 1);
     __builtin_amdgcn_sched_barrier(0);
     if (cb < 3) GLDM_C3_STAMP(4 + 4 * cb);
@@ -491,7 +515,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
       const int p = unit / NG, ng = unit - p * NG;
       const int ta = 2 * p, tb = 2 * p + 1 < 27 ? 2 * p + 1 : 26;
       const int offa = ((ta / 9) * 6 + (ta / 3) % 3) * zp + ta % 3, offb = ((tb / 9) * 6 + (tb / 3) % 3) * zp + tb % 3;
-      const int toff = 2 * ((kq >> 1) ? offb : offa);
+      const int toff = (kq >> 1) ? offb : offa;
 #pragma unroll
       for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -804,12 +828,70 @@ __global__ void se_gate_kernel(const float *__restrict__ chan_sum, const float *
   }
 }
 
+// GroupNorm as per-(cloud, channel) coefficients: y = a x + s with a = gamma rstd, s = beta - mean a; statistics from the
+// conv's per-brick partials, combined in f64 in a fixed order exactly as groupnorm_swish_kernel does.  grid = (groups, B).
+__global__ __launch_bounds__(64) void groupnorm_coef_kernel(const float *__restrict__ partial, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int c, int r3, int nbricks,
+                                                            int groups, float eps, float *__restrict__ coef) {
+  const int g = blockIdx.x, b = blockIdx.y, cpg = c / groups, tid = threadIdx.x;
+  double s = 0.0, s2 = 0.0;
+  for (int i = tid; i < nbricks * cpg; i += 64) {
+    const int br = i / cpg, ch = g * cpg + i % cpg;
+    const float *p = partial + (((size_t)b * nbricks + br) * c + ch) * 2;
+    s += (double)p[0];
+    s2 += (double)p[1];
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+  const double n = (double)cpg * r3, mean_d = s / n;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(fmax(s2 / n - mean_d * mean_d, 0.0) + (double)eps));
+  if (tid < cpg) {
+    const int ch = g * cpg + tid;
+    const float a = gamma[ch] * rstd;
+    coef[((size_t)b * c + ch) * 2] = a;
+    coef[((size_t)b * c + ch) * 2 + 1] = beta[ch] - mean * rstd * gamma[ch];
+  }
+}
+
+__device__ __forceinline__ float swish_fast(float t) {
+  return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * t));
+}
+
+// chan_sum[b][ch] = sum over the voxels of swish(a x + s): the SE squeeze of a GroupNorm + Swish output that is never
+// written (read-only pass; the consumers apply the same map on the fly).  grid = (C, B), rows of r^3 floats.
+__global__ __launch_bounds__(256) void gn_swish_sum_kernel(const float *__restrict__ y, const float *__restrict__ coef, int c,
+                                                           int r3, float *__restrict__ chan_sum) {
+  __shared__ float s_red[4];
+  const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float *row = y + ((size_t)b * c + ch) * r3;
+  const float a = coef[((size_t)b * c + ch) * 2], s = coef[((size_t)b * c + ch) * 2 + 1];
+  float acc = 0.f;
+  if ((r3 & 3) == 0) {
+    const float4 *row4 = reinterpret_cast<const float4 *>(row);
+    for (int i = tid; i < (r3 >> 2); i += 256) {
+      const float4 v = row4[i];
+      acc += swish_fast(fmaf(v.x, a, s)) + swish_fast(fmaf(v.y, a, s)) + swish_fast(fmaf(v.z, a, s)) + swish_fast(fmaf(v.w, a, s));
+    }
+  } else {
+    for (int i = tid; i < r3; i += 256) acc += swish_fast(fmaf(row[i], a, s));
+  }
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) chan_sum[(size_t)b * c + ch] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
 // out[b,c,i] = gate[b,c] * trilinear(V[b,c], coords[b,:,i]) + add[b,c,i]
 __global__ __launch_bounds__(256) void devoxelize_fused_kernel(const float *__restrict__ coords,
                                                                const float *__restrict__ feat,
                                                                const float *__restrict__ gate,
                                                                const float *__restrict__ add, int c, int n, int r,
-                                                               float *__restrict__ outs) {
+                                                               float *__restrict__ outs,
+                                                               const float *__restrict__ coef) {
+  // coef != NULL: `feat` is a raw conv output and GroupNorm + Swish are applied to the 8 corners on the fly
+  // (swish(a f + s), (a, s) per cloud and channel: groupnorm_coef_kernel)
   const int b = blockIdx.z;
   const int r2 = r * r, r3 = r2 * r;
   coords += (size_t)b * 3 * n;
@@ -830,8 +912,14 @@ __global__ __launch_bounds__(256) void devoxelize_fused_kernel(const float *__re
   const int c0 = blockIdx.y * 16, c1 = min(c0 + 16, c);
   for (int l = c0; l < c1; ++l) {
     const float *f = feat + (size_t)l * r3;
-    const float v = w000 * f[i000] + w001 * f[i001] + w010 * f[i010] + w011 * f[i011] + w100 * f[i100] +
-                    w101 * f[i101] + w110 * f[i110] + w111 * f[i111];
+    float f0 = f[i000], f1 = f[i001], f2 = f[i010], f3 = f[i011], f4 = f[i100], f5 = f[i101], f6 = f[i110], f7 = f[i111];
+    if (coef) {
+      const float a = coef[((size_t)b * c + l) * 2], s = coef[((size_t)b * c + l) * 2 + 1];
+      f0 = swish_fast(fmaf(f0, a, s)); f1 = swish_fast(fmaf(f1, a, s)); f2 = swish_fast(fmaf(f2, a, s));
+      f3 = swish_fast(fmaf(f3, a, s)); f4 = swish_fast(fmaf(f4, a, s)); f5 = swish_fast(fmaf(f5, a, s));
+      f6 = swish_fast(fmaf(f6, a, s)); f7 = swish_fast(fmaf(f7, a, s));
+    }
+    const float v = w000 * f0 + w001 * f1 + w010 * f2 + w011 * f3 + w100 * f4 + w101 * f5 + w110 * f6 + w111 * f7;
     const float gt = gate ? gate[(size_t)b * c + l] : 1.0f;
     const float ad = add ? add[((size_t)b * c + l) * n + i] : 0.f;
     outs[(size_t)l * n + i] = gt * v + ad;
@@ -1106,24 +1194,31 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
   return GLDM_ERR_UNSUPPORTED;
 }
 
-template <int MT, int R, int ZB, int WAVES>
-int launch_conv_pl(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
-                   hipStream_t s) {
-  const size_t lds_bytes = (size_t)3 * 36 * (ZB + 2) * 32;
+template <int MT, int R, int ZB, int WAVES, bool ACT>
+int launch_conv_pl_act(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
+                       const float *in_coef, hipStream_t s) {
+  const size_t lds_bytes = (size_t)3 * 36 * (ZB + 2) * 32 + (ACT ? (size_t)2 * cin * sizeof(float) : 0);
   struct Tag {};
-  gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_pl_kernel<MT, R, ZB, WAVES>), (int)lds_bytes);
+  gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_pl_kernel<MT, R, ZB, WAVES, ACT>), (int)lds_bytes);
   const int bpr = R / kBrick;
   if (R != ZB) {   // the halves of a brick add their partials into one slot
     if (hipMemsetAsync(partial, 0, (size_t)b * bpr * bpr * cout * 2 * sizeof(float), s) != hipSuccess) return GLDM_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((conv3d_k3_pl_kernel<MT, R, ZB, WAVES>), dim3(bpr * bpr * (R / ZB), b), dim3(64 * WAVES), lds_bytes, s, x,
-                     wp3, bias, cin, cout, y, partial);
+  hipLaunchKernelGGL((conv3d_k3_pl_kernel<MT, R, ZB, WAVES, ACT>), dim3(bpr * bpr * (R / ZB), b), dim3(64 * WAVES), lds_bytes,
+                     s, x, wp3, bias, cin, cout, y, partial, in_coef);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
+template <int MT, int R, int ZB, int WAVES>
+int launch_conv_pl(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
+                   const float *in_coef, hipStream_t s) {
+  return in_coef ? launch_conv_pl_act<MT, R, ZB, WAVES, true>(x, wp3, bias, b, cin, cout, y, partial, in_coef, s)
+                 : launch_conv_pl_act<MT, R, ZB, WAVES, false>(x, wp3, bias, b, cin, cout, y, partial, nullptr, s);
+}
 
-GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const float *bias, int b, int cin, int cout, int r,
-                                   float *y, float *partial, gldm_stream_t stream) {
+static int conv3d_k3_bf16x3_impl(const float *x, const float *in_coef, const float *w_split, const float *bias, int b, int cin,
+                                 int cout, int r, float *y, float *partial, gldm_stream_t stream) {
   if (!x || !w_split || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
+  if (in_coef && cin % 16) return GLDM_ERR_UNSUPPORTED;   // the folded GroupNorm + Swish lives in the plane-staging kernels
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (cin == 3 && cout == 48 && r == 24) {   // the first voxel conv: K = 81 packed into three k-blocks
     constexpr int kZp = 26, kNvox = 36 * kZp;
@@ -1151,9 +1246,38 @@ GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const f
   // (4 x 4 x 12 half bricks at 24^3 -- <3, 24, 12, 4>: 48 KiB of planes, two co-resident workgroups of 4 waves -- measured
   // 2.12 ms against 2.05 for the full-z brick: the kernel's 220 registers allow two waves per SIMD either way, and the
   // halves pay a z halo and the weight stream twice.  Kept as an instantiable option, not used.)
-  if (cout == 48 && r == 24) return launch_conv_pl<3, 24, 24, 8>(x, w_split, bias, b, cin, cout, y, partial, s);
-  if (cout == 96 && r == 12) return launch_conv_pl<6, 12, 12, 4>(x, w_split, bias, b, cin, cout, y, partial, s);
+  if (cout == 48 && r == 24) return launch_conv_pl<3, 24, 24, 8>(x, w_split, bias, b, cin, cout, y, partial, in_coef, s);
+  if (cout == 96 && r == 12) return launch_conv_pl<6, 12, 12, 4>(x, w_split, bias, b, cin, cout, y, partial, in_coef, s);
   return GLDM_ERR_UNSUPPORTED;
+}
+
+GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const float *bias, int b, int cin, int cout, int r,
+                                   float *y, float *partial, gldm_stream_t stream) {
+  return conv3d_k3_bf16x3_impl(x, nullptr, w_split, bias, b, cin, cout, r, y, partial, stream);
+}
+
+GLDM_API int gldm_conv3d_k3_bf16x3_gn(const float *x, const float *in_coef, const float *w_split, const float *bias, int b,
+                                      int cin, int cout, int r, float *y, float *partial, gldm_stream_t stream) {
+  if (!in_coef) return GLDM_ERR_INVALID_ARG;
+  return conv3d_k3_bf16x3_impl(x, in_coef, w_split, bias, b, cin, cout, r, y, partial, stream);
+}
+
+GLDM_API int gldm_groupnorm_coef(const float *partial, const float *gamma, const float *beta, int b, int c, int r, int groups,
+                                 float eps, float *coef, gldm_stream_t stream) {
+  if (!partial || !gamma || !beta || !coef || b <= 0 || c <= 0 || r <= 0 || groups <= 0 || c % groups || c / groups > 64)
+    return GLDM_ERR_INVALID_ARG;
+  const int nbricks = ((r + kBrick - 1) / kBrick) * ((r + kBrick - 1) / kBrick);
+  hipLaunchKernelGGL(groupnorm_coef_kernel, dim3(groups, b), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), partial, gamma,
+                     beta, c, r * r * r, nbricks, groups, eps, coef);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_gn_swish_chan_sum(const float *y, const float *coef, int b, int c, int r, float *chan_sum,
+                                    gldm_stream_t stream) {
+  if (!y || !coef || !chan_sum || b <= 0 || c <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(gn_swish_sum_kernel, dim3(c, b), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, coef, c,
+                     r * r * r, chan_sum);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 
 GLDM_API int gldm_groupnorm_swish(float *y, const float *partial, const float *gamma, const float *beta, int b, int c,
@@ -1178,7 +1302,15 @@ GLDM_API int gldm_devoxelize_fused(const float *coords, const float *features, c
                                    int b, int c, int n, int r, float *out, gldm_stream_t stream) {
   if (!coords || !features || !out || b <= 0 || c <= 0 || n <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(devoxelize_fused_kernel, dim3((n + 255) / 256, (c + 15) / 16, b), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), coords, features, gate, add, c, n, r, out);
+                     reinterpret_cast<hipStream_t>(stream), coords, features, gate, add, c, n, r, out, nullptr);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_devoxelize_gn_fused(const float *coords, const float *features, const float *coef, const float *gate,
+                                      const float *add, int b, int c, int n, int r, float *out, gldm_stream_t stream) {
+  if (!coords || !features || !coef || !out || b <= 0 || c <= 0 || n <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(devoxelize_fused_kernel, dim3((n + 255) / 256, (c + 15) / 16, b), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), coords, features, gate, add, c, n, r, out, coef);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 

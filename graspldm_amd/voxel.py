@@ -70,11 +70,19 @@ class VoxelBranchPlan:
 
 
 def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
-    """vox [B, Cin, r, r, r] -> fused features [B, Cout, N] = gate * devox(voxel stack) + point_feat."""
+    """vox [B, Cin, r, r, r] -> fused features [B, Cout, N] = gate * devox(voxel stack) + point_feat.
+
+    GroupNorm + Swish never run as passes of their own where the consumer can apply them: every conv leaves its raw output
+    and its per-brick statistics; gldm_groupnorm_coef folds those with the norm's affine into (a, s) per cloud and channel;
+    a following split-bf16 conv applies swish(a x + s) while it stages its bricks (gldm_conv3d_k3_bf16x3_gn), the SE squeeze
+    is a read-only pass (gldm_gn_swish_chan_sum) and the devoxelize pass applies it to the eight corners it reads
+    (gldm_devoxelize_gn_fused).  A conv without that staging (f32 / generic kernels) still gets gldm_groupnorm_swish in
+    front of it."""
     dev = vox.device
     b = vox.shape[0]
     st = L.current_stream(dev)
     x = vox.contiguous()
+    coef = None          # (a, s) of the GroupNorm + Swish still to be applied to x, or None
     chan_sum = None
     with torch.cuda.device(dev):
         for i, (conv, gn) in enumerate(zip(convs, norms)):
@@ -82,18 +90,37 @@ def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
             y = torch.empty((b, cout, r, r, r), dtype=torch.float32, device=dev)
             nf = L.lib().gldm_conv3d_partial_floats(b, cout, r)
             partial = torch.empty(int(nf), dtype=torch.float32, device=dev)
-            entry = "gldm_conv3d_k3_generic" if plan.generic[i] else ("gldm_conv3d_k3_bf16x3" if plan.split[i] else "gldm_conv3d_k3")
-            L.call(entry, L.ptr(x), L.ptr(plan.w[i]),
-                   L.ptr(conv.bias), b, cin, cout, r, L.ptr(y), L.ptr(partial), st)
+            if coef is not None:
+                L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(x), L.ptr(coef), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r,
+                       L.ptr(y), L.ptr(partial), st)
+            else:
+                entry = "gldm_conv3d_k3_generic" if plan.generic[i] else ("gldm_conv3d_k3_bf16x3" if plan.split[i] else "gldm_conv3d_k3")
+                L.call(entry, L.ptr(x), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r, L.ptr(y), L.ptr(partial), st)
             last = i == len(convs) - 1
-            if last and se is not None:
-                chan_sum = torch.empty((b, cout), dtype=torch.float32, device=dev)
-            L.call("gldm_groupnorm_swish", L.ptr(y), L.ptr(partial), L.ptr(gn.weight), L.ptr(gn.bias), b, cout, r,
-                   gn.num_groups, float(gn.eps), L.ptr(chan_sum) if (last and se is not None) else None, st)
+            # the consumer of this conv's GroupNorm + Swish: the next conv if it stages planes (cin % 16 == 0 split kernel),
+            # else the SE pass + devoxelize (last conv), else a pass of its own
+            # (measured per 256 clouds: at 24^3 the pass costs 0.26 ms and the staged form 0.1 ms; at 12^3 the pass is
+            # 0.06 ms and the staged form 0.25 ms -- six channel blocks of exp / rcp in front of short tap loops -- so small
+            # grids keep the pass between their convs)
+            foldable = (last or (plan.split[i + 1] and convs[i + 1].in_channels % 16 == 0 and r >= 16)) \
+                and cout // gn.num_groups <= 64
+            if foldable:
+                coef = torch.empty((b, cout, 2), dtype=torch.float32, device=dev)
+                L.call("gldm_groupnorm_coef", L.ptr(partial), L.ptr(gn.weight), L.ptr(gn.bias), b, cout, r, gn.num_groups,
+                       float(gn.eps), L.ptr(coef), st)
+            else:
+                coef = None
+                if last and se is not None:
+                    chan_sum = torch.empty((b, cout), dtype=torch.float32, device=dev)
+                L.call("gldm_groupnorm_swish", L.ptr(y), L.ptr(partial), L.ptr(gn.weight), L.ptr(gn.bias), b, cout, r,
+                       gn.num_groups, float(gn.eps), L.ptr(chan_sum) if (last and se is not None) else None, st)
             x = y
         c = x.shape[1]
         gate = None
         if se is not None:
+            if coef is not None:
+                chan_sum = torch.empty((b, c), dtype=torch.float32, device=dev)
+                L.call("gldm_gn_swish_chan_sum", L.ptr(x), L.ptr(coef), b, c, r, L.ptr(chan_sum), st)
             gate = torch.empty((b, c), dtype=torch.float32, device=dev)
             w1, w2 = se.fc[0].weight, se.fc[2].weight
             L.call("gldm_se_gate", L.ptr(chan_sum), L.ptr(w1), L.ptr(w2), b, c, w1.shape[0], r,
@@ -101,5 +128,9 @@ def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
         n = norm_coords.shape[2]
         out = torch.empty((b, c, n), dtype=torch.float32, device=dev)
         pf = point_feat.contiguous() if point_feat is not None else None
-        L.call("gldm_devoxelize_fused", L.ptr(norm_coords), L.ptr(x), L.ptr(gate), L.ptr(pf), b, c, n, r, L.ptr(out), st)
+        if coef is not None:
+            L.call("gldm_devoxelize_gn_fused", L.ptr(norm_coords), L.ptr(x), L.ptr(coef), L.ptr(gate), L.ptr(pf), b, c, n, r,
+                   L.ptr(out), st)
+        else:
+            L.call("gldm_devoxelize_fused", L.ptr(norm_coords), L.ptr(x), L.ptr(gate), L.ptr(pf), b, c, n, r, L.ptr(out), st)
     return out

@@ -376,10 +376,30 @@ int gldm_conv3d_k3_generic(const float *x /*[b,cin,r^3]*/, const float *w /*[cou
 /* The same conv with split-bf16 weights (graspldm_amd/voxel.py: pack_conv3d_bf16x3: [cout, cblocks * 14 * 32] with
  * k = ((16-channel block) * 14 + tap pair) * 32 + 16 (tap - 2 pair) + channel, as mfma_a_fragments_bf16x3 fragments):
  * six bf16 partial products per f32 product on the bf16 matrix pipe, f32 accumulation.  Built for the shipped
- * encoder's two shapes (cout 48 at r = 24, cout 96 at r = 12; cin % 16 == 0); GLDM_ERR_UNSUPPORTED otherwise. */
+ * encoder's shapes (cout 48 at r = 24, cout 96 at r = 12 with cin % 16 == 0; and the first conv, cin = 3 -> 48 at r = 24,
+ * whose weights are packed tap-major without padding between taps, k = tap * 3 + ci < 81 in three 32-deep blocks:
+ * pack_conv3d_fewch_bf16x3); GLDM_ERR_UNSUPPORTED otherwise. */
 int gldm_conv3d_k3_bf16x3(const float *x /*[b,cin,r^3]*/, const float *w_split, const float *bias /*[cout]*/,
                           int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/, float *partial,
                           gldm_stream_t stream);
+
+/* ref: pvconv.py:57-66 (Conv3d -> GroupNorm(8) -> Swish -> Conv3d): the SECOND conv reading the first one's RAW output,
+ * with x' = swish(a x + s) applied per in-grid element while the bricks are staged; in_coef [b, cin, 2] = (a, s) from
+ * gldm_groupnorm_coef.  The activated tensor is never written.  cin % 16 == 0, the cout / r of gldm_conv3d_k3_bf16x3. */
+int gldm_conv3d_k3_bf16x3_gn(const float *x /*[b,cin,r^3] raw*/, const float *in_coef /*[b,cin,2]*/, const float *w_split,
+                             const float *bias /*[cout]*/, int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/,
+                             float *partial, gldm_stream_t stream);
+
+/* ref: pvconv.py:57-66 (nn.GroupNorm(8, c)) as per-(cloud, channel) coefficients: GN(x) = a x + s, a = gamma rstd,
+ * s = beta - mean a, statistics from a conv's `partial` (combined in f64 in a fixed order, as gldm_groupnorm_swish).
+ * c / groups <= 64. */
+int gldm_groupnorm_coef(const float *partial, const float *gamma, const float *beta, int b, int c, int r, int groups,
+                        float eps, float *coef /*[b,c,2]*/, gldm_stream_t stream);
+
+/* chan_sum[b,c] = sum over the r^3 voxels of swish(a y + s): the SE squeeze (se.py:12-25) of a GroupNorm + Swish output
+ * that is never written (read-only pass over the raw conv output). */
+int gldm_gn_swish_chan_sum(const float *y /*[b,c,r^3] raw*/, const float *coef /*[b,c,2]*/, int b, int c, int r,
+                           float *chan_sum /*[b,c]*/, gldm_stream_t stream);
 
 /* ref: pvconv.py:57-66 (nn.GroupNorm(8, c) + Swish), in place on y; statistics from `partial`
  * (combined in f64 in a fixed order).  chan_sum [b,c] (optional) receives the per-channel sum of
@@ -397,6 +417,12 @@ int gldm_se_gate(const float *chan_sum /*[b,c]*/, const float *w1 /*[hidden,c]*/
 int gldm_devoxelize_fused(const float *coords /*[b,3,n]*/, const float *features /*[b,c,r^3]*/,
                           const float *gate /*[b,c]*/, const float *add /*[b,c,n]*/, int b, int c, int n, int r,
                           float *out /*[b,c,n]*/, gldm_stream_t stream);
+
+/* The same pass over a RAW conv output: GroupNorm + Swish (coef [b,c,2] from gldm_groupnorm_coef) applied to the eight
+ * corner values of every point before the trilinear blend: out = gate * trilinear(swish(a V + s)) + add. */
+int gldm_devoxelize_gn_fused(const float *coords /*[b,3,n]*/, const float *features /*[b,c,r^3] raw*/,
+                             const float *coef /*[b,c,2]*/, const float *gate /*[b,c]*/, const float *add /*[b,c,n]*/,
+                             int b, int c, int n, int r, float *out /*[b,c,n]*/, gldm_stream_t stream);
 
 /* y[b, c, :] = act(y[b, c, :] + bias[c]) in place (relu != 0: ReLU).  Epilogue of the k = 1 Conv1d /
  * Conv2d + BatchNorm(eval, folded) + ReLU of ext/pvcnn/modules/shared_mlp.py:24-36 when the GEMM itself

@@ -282,6 +282,52 @@ def test_conv3d_split_bf16_kernels(cin, cout, r):
     assert _err(y, ref2) < 2e-5, _err(y, ref2)
 
 
+def test_groupnorm_folded_into_its_consumers():
+    """Conv3d -> GroupNorm -> Swish -> Conv3d -> GroupNorm -> Swish -> SE sum -> devoxelize with no GroupNorm pass:
+    gldm_groupnorm_coef + gldm_conv3d_k3_bf16x3_gn + gldm_gn_swish_chan_sum + gldm_devoxelize_gn_fused against torch on the
+    CPU (fp32, 2e-5)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.nn.functional as F
+    from graspldm_amd import _lib as L
+    from graspldm_amd.voxel import pack_conv3d_bf16x3
+    g = torch.Generator().manual_seed(77)
+    b, c, r, n = 3, 48, 24, 256
+    x = torch.randn(b, c, r, r, r, generator=g)
+    w1, w2 = (torch.randn(c, c, 3, 3, 3, generator=g) / (27 * c) ** 0.5 for _ in range(2))
+    b1, b2, g1, be1, g2, be2 = (torch.randn(c, generator=g) * 0.1 for _ in range(6))
+    g1, g2 = g1 + 1, g2 + 1
+    h = F.group_norm(F.conv3d(x, w1, b1, padding=1), 8, g1, be1, 1e-5)
+    h = h * torch.sigmoid(h)
+    z = F.group_norm(F.conv3d(h, w2, b2, padding=1), 8, g2, be2, 1e-5)
+    z = z * torch.sigmoid(z)
+    st = L.current_stream()
+    nf = int(L.lib().gldm_conv3d_partial_floats(b, c, r))
+    dx = x.cuda()
+    y1, y2 = torch.empty(b, c, r, r, r, device="cuda"), torch.empty(b, c, r, r, r, device="cuda")
+    p1, p2 = torch.empty(nf, device="cuda"), torch.empty(nf, device="cuda")
+    c1, c2 = torch.empty(b, c, 2, device="cuda"), torch.empty(b, c, 2, device="cuda")
+    dw1, dw2 = pack_conv3d_bf16x3(w1).cuda(), pack_conv3d_bf16x3(w2).cuda()
+    d = [t.cuda() for t in (b1, b2, g1, be1, g2, be2)]
+    L.call("gldm_conv3d_k3_bf16x3", L.ptr(dx), L.ptr(dw1), L.ptr(d[0]), b, c, c, r, L.ptr(y1), L.ptr(p1), st)
+    L.call("gldm_groupnorm_coef", L.ptr(p1), L.ptr(d[2]), L.ptr(d[3]), b, c, r, 8, 1e-5, L.ptr(c1), st)
+    L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(y1), L.ptr(c1), L.ptr(dw2), L.ptr(d[1]), b, c, c, r, L.ptr(y2), L.ptr(p2), st)
+    L.call("gldm_groupnorm_coef", L.ptr(p2), L.ptr(d[4]), L.ptr(d[5]), b, c, r, 8, 1e-5, L.ptr(c2), st)
+    cs = torch.empty(b, c, device="cuda")
+    L.call("gldm_gn_swish_chan_sum", L.ptr(y2), L.ptr(c2), b, c, r, L.ptr(cs), st)
+    assert _err(cs / r ** 3, z.mean(dim=(2, 3, 4))) < 2e-5
+    # devoxelize of the activated tensor at random points, gated, plus an addend
+    coords = torch.rand(b, 3, n, generator=g) * (r - 1)
+    gate, add = torch.rand(b, c, generator=g), torch.randn(b, c, n, generator=g)
+    out = torch.empty(b, c, n, device="cuda")
+    dc, dg, da = coords.cuda(), gate.cuda(), add.cuda()
+    L.call("gldm_devoxelize_gn_fused", L.ptr(dc), L.ptr(y2), L.ptr(c2), L.ptr(dg), L.ptr(da), b, c, n, r, L.ptr(out), st)
+    ref = torch.empty(b, c, n, device="cuda")
+    dz = z.contiguous().cuda()
+    L.call("gldm_devoxelize_fused", L.ptr(dc), L.ptr(dz), L.ptr(dg), L.ptr(da), b, c, n, r, L.ptr(ref), st)
+    assert _err(out, ref.cpu()) < 2e-5, _err(out, ref.cpu())
+
+
 def test_ppc_config_z16_latent_against_oracle():
     """Second shipped experiment (configs/generation/partial_pc/ppc_1a_...z16_pc256: grasp latent 16,
     pc latent [3,256], denoiser dim 16 -> the L=16 time-conditioned engine): end-to-end LDM
