@@ -42,14 +42,17 @@ _SIGNATURES = {
     "gldm_conv3d_k3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_conv3d_k3_generic": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_conv3d_k3_bf16x3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
-    "gldm_conv3d_k3_bf16x3_gn": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "gldm_conv3d_k3_bf16x3_gn": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "gldm_groupnorm_coef": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "gldm_gn_swish_chan_sum": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "gldm_gn_swish_chan_sum_cl": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "gldm_se_gate_parts": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "gldm_groupnorm_swish": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "gldm_se_gate": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "gldm_bias_act": [_vp, _vp, _i, _i, ctypes.c_longlong, _i, _vp],
     "gldm_devoxelize_fused": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "gldm_devoxelize_gn_fused": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "gldm_devoxelize_gn_cl_fused": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_pointwise_mlp2": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_pointwise_small": [_vp, _vp, _vp, _i, _i, _i, ctypes.c_longlong, _i, _vp, _vp],
@@ -104,6 +107,8 @@ def lib():
     h.gldm_r1d_tile_columns.restype = _i
     h.gldm_conv3d_partial_floats.argtypes = [_i, _i, _i]
     h.gldm_conv3d_partial_floats.restype = ctypes.c_longlong
+    h.gldm_squeeze_parts.argtypes = []
+    h.gldm_squeeze_parts.restype = _i
     _lib = h
     return h
 

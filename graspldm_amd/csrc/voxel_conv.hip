@@ -378,7 +378,10 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
                                                                                       const float *__restrict__ bias, int cin,
                                                                                       int cout, float *__restrict__ y,
                                                                                       float *__restrict__ partial,
-                                                                                      const float *__restrict__ in_coef) {
+                                                                                      const float *__restrict__ in_coef,
+                                                                                      int out_cl) {
+  // out_cl: y is written channel-LAST, [b][r^3][cout] (one 16-byte store per accumulator instead of four 4-byte ones):
+  // the layout of a PVConv's last conv, whose readers (SE squeeze, devoxelize) then take a voxel's channels as one run
   constexpr int r = R, NTW = ZB / WAVES, kThreads = 64 * WAVES, kZParts = R / ZB;
   static_assert(NTW % 3 == 0 && MT % 3 == 0 && R % ZB == 0, "tiles walked in 3 x 3 groups");
   constexpr int MG = MT / 3, NG = NTW / 3;
@@ -592,14 +595,22 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
       atomicAdd(p + 1, s2);
     }
   }
+  if (out_cl) {
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi)
+    for (int ni = 0; ni < NTW; ++ni)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co = 16 * mi + 4 * kq + q;
+      for (int mi = 0; mi < MT; ++mi)
+        *reinterpret_cast<f32x4 *>(y + (size_t)gvox[ni] * cout + 16 * mi + 4 * kq) = acc[mi][ni];
+  } else {
 #pragma unroll
-      for (int ni = 0; ni < NTW; ++ni) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
-    }
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = 16 * mi + 4 * kq + q;
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
+      }
+  }
   GLDM_C3_STAMP(21);
 }
 
@@ -809,11 +820,16 @@ __global__ __launch_bounds__(512) void groupnorm_swish_kernel(float *__restrict_
 // SE gate: gate = sigmoid(W2 act(W1 mean)), W1 [c/red, c], W2 [c, c/red]; one block per cloud.
 __global__ void se_gate_kernel(const float *__restrict__ chan_sum, const float *__restrict__ w1,
                                const float *__restrict__ w2, int c, int hid, int r3, int use_relu,
-                               float *__restrict__ gate) {
+                               float *__restrict__ gate, int parts) {
   extern __shared__ float s[];  // mean[c], h[hid]
   const int b = blockIdx.x, tid = threadIdx.x;
   float *mean = s, *h = s + c;
-  for (int i = tid; i < c; i += blockDim.x) mean[i] = chan_sum[(size_t)b * c + i] / (float)r3;
+  // chan_sum [b][parts][c]: partial sums of the squeeze, added in index order
+  for (int i = tid; i < c; i += blockDim.x) {
+    float t = chan_sum[(size_t)b * parts * c + i];
+    for (int p = 1; p < parts; ++p) t += chan_sum[((size_t)b * parts + p) * c + i];
+    mean[i] = t / (float)r3;
+  }
   __syncthreads();
   for (int i = tid; i < hid; i += blockDim.x) {
     float a = 0.f;
@@ -881,6 +897,92 @@ __global__ __launch_bounds__(256) void gn_swish_sum_kernel(const float *__restri
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
   __syncthreads();
   if (tid == 0) chan_sum[(size_t)b * c + ch] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// The same squeeze over a channel-LAST tensor [b][r^3][c]: block (part, b) sums its share of the voxels for every channel
+// (thread = (voxel stripe, channel quad), 16-byte loads), parts[b][part][c] leaves; se_gate_kernel adds the parts in order.
+constexpr int kSumParts = 8;
+__global__ __launch_bounds__(256) void gn_swish_sum_cl_kernel(const float *__restrict__ y, const float *__restrict__ coef, int c,
+                                                              int r3, float *__restrict__ parts) {
+  __shared__ f32x4 s_acc[256];
+  const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int quads = c >> 2, stripes = 256 / quads;          // threads beyond stripes * quads idle
+  const int qd = tid % quads, stripe = tid / quads;
+  const int v0 = (int)((long long)r3 * part / kSumParts), v1 = (int)((long long)r3 * (part + 1) / kSumParts);
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (stripe < stripes) {
+    const f32x4 *cf = reinterpret_cast<const f32x4 *>(coef + ((size_t)b * c + 4 * qd) * 2);
+    const f32x4 c01 = cf[0], c23 = cf[1];   // (a0, s0, a1, s1), (a2, s2, a3, s3)
+    const f32x4 *row = reinterpret_cast<const f32x4 *>(y + (size_t)b * r3 * c) + qd;
+    for (int v = v0 + stripe; v < v1; v += stripes) {
+      const f32x4 x = row[(size_t)v * quads];
+      acc[0] += swish_fast(fmaf(x[0], c01[0], c01[1]));
+      acc[1] += swish_fast(fmaf(x[1], c01[2], c01[3]));
+      acc[2] += swish_fast(fmaf(x[2], c23[0], c23[1]));
+      acc[3] += swish_fast(fmaf(x[3], c23[2], c23[3]));
+    }
+  }
+  s_acc[tid] = acc;
+  __syncthreads();
+  if (tid < quads) {
+    f32x4 t = s_acc[tid];
+    for (int st = 1; st < stripes; ++st) {
+      const f32x4 o = s_acc[st * quads + tid];
+      t[0] += o[0]; t[1] += o[1]; t[2] += o[2]; t[3] += o[3];
+    }
+    *reinterpret_cast<f32x4 *>(parts + ((size_t)b * kSumParts + part) * c + 4 * tid) = t;
+  }
+}
+
+// devoxelize_fused_kernel over a channel-LAST raw conv output [b][r^3][c] (coef required): a point's corner is ONE run of
+// c floats, read as 16-byte loads by c / 4 neighbouring lanes, instead of c dword gathers from c cache lines (the
+// channel-major form is bound by the address path: 64 lines per wave instruction, 0.24 ms per 48 x 24^3 x 256 clouds).
+// Block = 64 points; item = (point, channel quad); the results cross LDS so that the stores (and the reads of `add`) run
+// along the points.  c % 4 == 0, c <= 128.
+__global__ __launch_bounds__(256) void devoxelize_cl_kernel(const float *__restrict__ coords, const float *__restrict__ feat,
+                                                            const float *__restrict__ coef, const float *__restrict__ gate,
+                                                            const float *__restrict__ add, int c, int n, int r,
+                                                            float *__restrict__ outs) {
+  extern __shared__ float s_tile[];   // [c][65]
+  const int b = blockIdx.y, p0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int r2 = r * r, r3 = r2 * r, quads = c >> 2;
+  coords += (size_t)b * 3 * n;
+  const f32x4 *f4 = reinterpret_cast<const f32x4 *>(feat + (size_t)b * r3 * c);
+  for (int it = tid; it < 64 * quads; it += 256) {
+    const int pt = it / quads, qd = it - pt * quads;
+    const int i = min(p0 + pt, n - 1);
+    const float x = coords[i], y = coords[i + n], z = coords[i + 2 * n];
+    const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
+    const float xd1 = x - xl, yd1 = y - yl, zd1 = z - zl;
+    const float xd0 = 1.0f - xd1, yd0 = 1.0f - yd1, zd0 = 1.0f - zd1;
+    const float w[8] = {xd0 * yd0 * zd0, xd0 * yd0 * zd1, xd0 * yd1 * zd0, xd0 * yd1 * zd1,
+                        xd1 * yd0 * zd0, xd1 * yd0 * zd1, xd1 * yd1 * zd0, xd1 * yd1 * zd1};
+    const int i000 = (int)xl * r2 + (int)yl * r + (int)zl;
+    const int zh = zd1 > 0 ? 1 : 0, yh = yd1 > 0 ? r : 0, xh = xd1 > 0 ? r2 : 0;
+    const int idx[8] = {i000, i000 + zh, i000 + yh, i000 + yh + zh, i000 + xh, i000 + xh + zh, i000 + xh + yh, i000 + xh + yh + zh};
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = f4[(size_t)idx[k] * quads + qd];
+    const f32x4 *cf = reinterpret_cast<const f32x4 *>(coef + ((size_t)b * c + 4 * qd) * 2);
+    const f32x4 c01 = cf[0], c23 = cf[1];
+    const float ca[4] = {c01[0], c01[2], c23[0], c23[2]}, cs[4] = {c01[1], c01[3], c23[1], c23[3]};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float o = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o += w[k] * swish_fast(fmaf(v[k][q], ca[q], cs[q]));
+      s_tile[(4 * qd + q) * 65 + pt] = o;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < c * 64; e += 256) {
+    const int ch = e >> 6, pt = e & 63;
+    if (p0 + pt < n) {
+      const float gt = gate ? gate[(size_t)b * c + ch] : 1.0f;
+      const size_t o = ((size_t)b * c + ch) * n + p0 + pt;
+      outs[o] = gt * s_tile[ch * 65 + pt] + (add ? add[o] : 0.f);
+    }
+  }
 }
 
 // out[b,c,i] = gate[b,c] * trilinear(V[b,c], coords[b,:,i]) + add[b,c,i]
@@ -1196,7 +1298,7 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
 
 template <int MT, int R, int ZB, int WAVES, bool ACT>
 int launch_conv_pl_act(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
-                       const float *in_coef, hipStream_t s) {
+                       const float *in_coef, int out_cl, hipStream_t s) {
   const size_t lds_bytes = (size_t)3 * 36 * (ZB + 2) * 32 + (ACT ? (size_t)2 * cin * sizeof(float) : 0);
   struct Tag {};
   gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_pl_kernel<MT, R, ZB, WAVES, ACT>), (int)lds_bytes);
@@ -1205,20 +1307,20 @@ int launch_conv_pl_act(const float *x, const float *wp3, const float *bias, int 
     if (hipMemsetAsync(partial, 0, (size_t)b * bpr * bpr * cout * 2 * sizeof(float), s) != hipSuccess) return GLDM_ERR_LAUNCH;
   }
   hipLaunchKernelGGL((conv3d_k3_pl_kernel<MT, R, ZB, WAVES, ACT>), dim3(bpr * bpr * (R / ZB), b), dim3(64 * WAVES), lds_bytes,
-                     s, x, wp3, bias, cin, cout, y, partial, in_coef);
+                     s, x, wp3, bias, cin, cout, y, partial, in_coef, out_cl);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 template <int MT, int R, int ZB, int WAVES>
 int launch_conv_pl(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
-                   const float *in_coef, hipStream_t s) {
-  return in_coef ? launch_conv_pl_act<MT, R, ZB, WAVES, true>(x, wp3, bias, b, cin, cout, y, partial, in_coef, s)
-                 : launch_conv_pl_act<MT, R, ZB, WAVES, false>(x, wp3, bias, b, cin, cout, y, partial, nullptr, s);
+                   const float *in_coef, int out_cl, hipStream_t s) {
+  return in_coef ? launch_conv_pl_act<MT, R, ZB, WAVES, true>(x, wp3, bias, b, cin, cout, y, partial, in_coef, out_cl, s)
+                 : launch_conv_pl_act<MT, R, ZB, WAVES, false>(x, wp3, bias, b, cin, cout, y, partial, nullptr, out_cl, s);
 }
 
 static int conv3d_k3_bf16x3_impl(const float *x, const float *in_coef, const float *w_split, const float *bias, int b, int cin,
-                                 int cout, int r, float *y, float *partial, gldm_stream_t stream) {
+                                 int cout, int r, float *y, float *partial, int out_cl, gldm_stream_t stream) {
   if (!x || !w_split || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
-  if (in_coef && cin % 16) return GLDM_ERR_UNSUPPORTED;   // the folded GroupNorm + Swish lives in the plane-staging kernels
+  if ((in_coef || out_cl) && cin % 16) return GLDM_ERR_UNSUPPORTED;   // both live in the plane-staging kernels
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (cin == 3 && cout == 48 && r == 24) {   // the first voxel conv: K = 81 packed into three k-blocks
     constexpr int kZp = 26, kNvox = 36 * kZp;
@@ -1246,20 +1348,20 @@ static int conv3d_k3_bf16x3_impl(const float *x, const float *in_coef, const flo
   // (4 x 4 x 12 half bricks at 24^3 -- <3, 24, 12, 4>: 48 KiB of planes, two co-resident workgroups of 4 waves -- measured
   // 2.12 ms against 2.05 for the full-z brick: the kernel's 220 registers allow two waves per SIMD either way, and the
   // halves pay a z halo and the weight stream twice.  Kept as an instantiable option, not used.)
-  if (cout == 48 && r == 24) return launch_conv_pl<3, 24, 24, 8>(x, w_split, bias, b, cin, cout, y, partial, in_coef, s);
-  if (cout == 96 && r == 12) return launch_conv_pl<6, 12, 12, 4>(x, w_split, bias, b, cin, cout, y, partial, in_coef, s);
+  if (cout == 48 && r == 24) return launch_conv_pl<3, 24, 24, 8>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
+  if (cout == 96 && r == 12) return launch_conv_pl<6, 12, 12, 4>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
   return GLDM_ERR_UNSUPPORTED;
 }
 
 GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const float *bias, int b, int cin, int cout, int r,
                                    float *y, float *partial, gldm_stream_t stream) {
-  return conv3d_k3_bf16x3_impl(x, nullptr, w_split, bias, b, cin, cout, r, y, partial, stream);
+  return conv3d_k3_bf16x3_impl(x, nullptr, w_split, bias, b, cin, cout, r, y, partial, 0, stream);
 }
 
 GLDM_API int gldm_conv3d_k3_bf16x3_gn(const float *x, const float *in_coef, const float *w_split, const float *bias, int b,
-                                      int cin, int cout, int r, float *y, float *partial, gldm_stream_t stream) {
-  if (!in_coef) return GLDM_ERR_INVALID_ARG;
-  return conv3d_k3_bf16x3_impl(x, in_coef, w_split, bias, b, cin, cout, r, y, partial, stream);
+                                      int cin, int cout, int r, float *y, float *partial, int out_channel_last,
+                                      gldm_stream_t stream) {
+  return conv3d_k3_bf16x3_impl(x, in_coef, w_split, bias, b, cin, cout, r, y, partial, out_channel_last ? 1 : 0, stream);
 }
 
 GLDM_API int gldm_groupnorm_coef(const float *partial, const float *gamma, const float *beta, int b, int c, int r, int groups,
@@ -1294,7 +1396,35 @@ GLDM_API int gldm_se_gate(const float *chan_sum, const float *w1, const float *w
                           int use_relu, float *gate, gldm_stream_t stream) {
   if (!chan_sum || !w1 || !w2 || !gate || b <= 0 || c <= 0 || hidden <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(se_gate_kernel, dim3(b), dim3(128), (size_t)(c + hidden) * sizeof(float),
-                     reinterpret_cast<hipStream_t>(stream), chan_sum, w1, w2, c, hidden, r * r * r, use_relu, gate);
+                     reinterpret_cast<hipStream_t>(stream), chan_sum, w1, w2, c, hidden, r * r * r, use_relu, gate, 1);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_se_gate_parts(const float *chan_parts, int parts, const float *w1, const float *w2, int b, int c, int hidden,
+                                int r, int use_relu, float *gate, gldm_stream_t stream) {
+  if (!chan_parts || !w1 || !w2 || !gate || b <= 0 || c <= 0 || hidden <= 0 || r <= 0 || parts <= 0) return GLDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(se_gate_kernel, dim3(b), dim3(128), (size_t)(c + hidden) * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), chan_parts, w1, w2, c, hidden, r * r * r, use_relu, gate, parts);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_squeeze_parts(void) { return kSumParts; }
+
+GLDM_API int gldm_gn_swish_chan_sum_cl(const float *y, const float *coef, int b, int c, int r, float *chan_parts,
+                                       gldm_stream_t stream) {
+  if (!y || !coef || !chan_parts || b <= 0 || c <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
+  if (c % 4 || c > 1024) return GLDM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gn_swish_sum_cl_kernel, dim3(kSumParts, b), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, coef, c,
+                     r * r * r, chan_parts);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
+GLDM_API int gldm_devoxelize_gn_cl_fused(const float *coords, const float *features_cl, const float *coef, const float *gate,
+                                         const float *add, int b, int c, int n, int r, float *out, gldm_stream_t stream) {
+  if (!coords || !features_cl || !coef || !out || b <= 0 || c <= 0 || n <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
+  if (c % 4 || c > 128) return GLDM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(devoxelize_cl_kernel, dim3((n + 63) / 64, b), dim3(256), (size_t)c * 65 * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), coords, features_cl, coef, gate, add, c, n, r, out);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 

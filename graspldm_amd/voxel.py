@@ -76,7 +76,10 @@ def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
     and its per-brick statistics; gldm_groupnorm_coef folds those with the norm's affine into (a, s) per cloud and channel;
     a following split-bf16 conv applies swish(a x + s) while it stages its bricks (gldm_conv3d_k3_bf16x3_gn), the SE squeeze
     is a read-only pass (gldm_gn_swish_chan_sum) and the devoxelize pass applies it to the eight corners it reads
-    (gldm_devoxelize_gn_fused).  A conv without that staging (f32 / generic kernels) still gets gldm_groupnorm_swish in
+    (gldm_devoxelize_gn_fused).  The last conv of the stack, when it is one of the plane-staging kernels, writes its output
+    channel-last so that both of those readers take a voxel's channels as one run (gldm_gn_swish_chan_sum_cl,
+    gldm_devoxelize_gn_cl_fused: a point's eight corners are eight 16-byte-per-lane runs instead of 8 C scattered dwords).
+    A conv without that staging (f32 / generic kernels) still gets gldm_groupnorm_swish in
     front of it."""
     dev = vox.device
     b = vox.shape[0]
@@ -84,19 +87,25 @@ def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
     x = vox.contiguous()
     coef = None          # (a, s) of the GroupNorm + Swish still to be applied to x, or None
     chan_sum = None
+    x_cl = False         # x is channel-last, [B, r^3, C]
     with torch.cuda.device(dev):
         for i, (conv, gn) in enumerate(zip(convs, norms)):
             cin, cout = conv.in_channels, conv.out_channels
             y = torch.empty((b, cout, r, r, r), dtype=torch.float32, device=dev)
             nf = L.lib().gldm_conv3d_partial_floats(b, cout, r)
             partial = torch.empty(int(nf), dtype=torch.float32, device=dev)
-            if coef is not None:
+            last = i == len(convs) - 1
+            staged = plan.split[i] and cin % 16 == 0          # the plane-staging kernels: folded input, channel-last output
+            # the last conv's readers (squeeze, devoxelize) take a voxel's channels as one run
+            cl = last and staged and cout % 4 == 0 and cout <= 128 and cout // gn.num_groups <= 64
+            if staged and (coef is not None or cl):
                 L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(x), L.ptr(coef), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r,
-                       L.ptr(y), L.ptr(partial), st)
+                       L.ptr(y), L.ptr(partial), 1 if cl else 0, st)
             else:
+                assert coef is None
                 entry = "gldm_conv3d_k3_generic" if plan.generic[i] else ("gldm_conv3d_k3_bf16x3" if plan.split[i] else "gldm_conv3d_k3")
                 L.call(entry, L.ptr(x), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r, L.ptr(y), L.ptr(partial), st)
-            last = i == len(convs) - 1
+            x_cl = cl
             # the consumer of this conv's GroupNorm + Swish: the next conv if it stages planes (cin % 16 == 0 split kernel),
             # else the SE pass + devoxelize (last conv), else a pass of its own
             # (measured per 256 clouds: at 24^3 the pass costs 0.26 ms and the staged form 0.1 ms; at 12^3 the pass is
@@ -118,17 +127,27 @@ def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
         c = x.shape[1]
         gate = None
         if se is not None:
-            if coef is not None:
-                chan_sum = torch.empty((b, c), dtype=torch.float32, device=dev)
-                L.call("gldm_gn_swish_chan_sum", L.ptr(x), L.ptr(coef), b, c, r, L.ptr(chan_sum), st)
             gate = torch.empty((b, c), dtype=torch.float32, device=dev)
             w1, w2 = se.fc[0].weight, se.fc[2].weight
-            L.call("gldm_se_gate", L.ptr(chan_sum), L.ptr(w1), L.ptr(w2), b, c, w1.shape[0], r,
-                   1 if se.use_relu else 0, L.ptr(gate), st)
+            if x_cl:
+                parts = int(L.lib().gldm_squeeze_parts())
+                chan_sum = torch.empty((b, parts, c), dtype=torch.float32, device=dev)
+                L.call("gldm_gn_swish_chan_sum_cl", L.ptr(x), L.ptr(coef), b, c, r, L.ptr(chan_sum), st)
+                L.call("gldm_se_gate_parts", L.ptr(chan_sum), parts, L.ptr(w1), L.ptr(w2), b, c, w1.shape[0], r,
+                       1 if se.use_relu else 0, L.ptr(gate), st)
+            else:
+                if coef is not None:
+                    chan_sum = torch.empty((b, c), dtype=torch.float32, device=dev)
+                    L.call("gldm_gn_swish_chan_sum", L.ptr(x), L.ptr(coef), b, c, r, L.ptr(chan_sum), st)
+                L.call("gldm_se_gate", L.ptr(chan_sum), L.ptr(w1), L.ptr(w2), b, c, w1.shape[0], r,
+                       1 if se.use_relu else 0, L.ptr(gate), st)
         n = norm_coords.shape[2]
         out = torch.empty((b, c, n), dtype=torch.float32, device=dev)
         pf = point_feat.contiguous() if point_feat is not None else None
-        if coef is not None:
+        if x_cl:
+            L.call("gldm_devoxelize_gn_cl_fused", L.ptr(norm_coords), L.ptr(x), L.ptr(coef), L.ptr(gate), L.ptr(pf), b, c, n, r,
+                   L.ptr(out), st)
+        elif coef is not None:
             L.call("gldm_devoxelize_gn_fused", L.ptr(norm_coords), L.ptr(x), L.ptr(coef), L.ptr(gate), L.ptr(pf), b, c, n, r,
                    L.ptr(out), st)
         else:

@@ -383,12 +383,15 @@ int gldm_conv3d_k3_bf16x3(const float *x /*[b,cin,r^3]*/, const float *w_split, 
                           int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/, float *partial,
                           gldm_stream_t stream);
 
-/* ref: pvconv.py:57-66 (Conv3d -> GroupNorm(8) -> Swish -> Conv3d): the SECOND conv reading the first one's RAW output,
- * with x' = swish(a x + s) applied per in-grid element while the bricks are staged; in_coef [b, cin, 2] = (a, s) from
- * gldm_groupnorm_coef.  The activated tensor is never written.  cin % 16 == 0, the cout / r of gldm_conv3d_k3_bf16x3. */
-int gldm_conv3d_k3_bf16x3_gn(const float *x /*[b,cin,r^3] raw*/, const float *in_coef /*[b,cin,2]*/, const float *w_split,
-                             const float *bias /*[cout]*/, int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/,
-                             float *partial, gldm_stream_t stream);
+/* ref: pvconv.py:57-66 (Conv3d -> GroupNorm(8) -> Swish -> Conv3d): a conv of the voxel stack with its neighbours' work
+ * folded in.  in_coef [b, cin, 2] (optional) = (a, s) from gldm_groupnorm_coef: x is the previous conv's RAW output and
+ * x' = swish(a x + s) is applied per in-grid element while the bricks are staged (the activated tensor is never written).
+ * out_channel_last != 0: y is written [b, r^3, cout] (a voxel's channels as one run: the layout the squeeze and
+ * devoxelize passes below read; `partial` is unchanged).  cin % 16 == 0, the cout / r of gldm_conv3d_k3_bf16x3. */
+int gldm_conv3d_k3_bf16x3_gn(const float *x /*[b,cin,r^3] raw*/, const float *in_coef /*[b,cin,2] or NULL*/,
+                             const float *w_split, const float *bias /*[cout]*/, int b, int cin, int cout, int r,
+                             float *y /*[b,cout,r^3] or [b,r^3,cout]*/, float *partial, int out_channel_last,
+                             gldm_stream_t stream);
 
 /* ref: pvconv.py:57-66 (nn.GroupNorm(8, c)) as per-(cloud, channel) coefficients: GN(x) = a x + s, a = gamma rstd,
  * s = beta - mean a, statistics from a conv's `partial` (combined in f64 in a fixed order, as gldm_groupnorm_swish).
@@ -401,6 +404,12 @@ int gldm_groupnorm_coef(const float *partial, const float *gamma, const float *b
 int gldm_gn_swish_chan_sum(const float *y /*[b,c,r^3] raw*/, const float *coef /*[b,c,2]*/, int b, int c, int r,
                            float *chan_sum /*[b,c]*/, gldm_stream_t stream);
 
+/* The same squeeze over a channel-last tensor, as gldm_squeeze_parts() partial sums per cloud (fixed split of the voxels,
+ * added in index order by gldm_se_gate_parts: deterministic, no atomics).  c % 4 == 0. */
+int gldm_squeeze_parts(void);
+int gldm_gn_swish_chan_sum_cl(const float *y /*[b,r^3,c] raw*/, const float *coef /*[b,c,2]*/, int b, int c, int r,
+                              float *chan_parts /*[b,parts,c]*/, gldm_stream_t stream);
+
 /* ref: pvconv.py:57-66 (nn.GroupNorm(8, c) + Swish), in place on y; statistics from `partial`
  * (combined in f64 in a fixed order).  chan_sum [b,c] (optional) receives the per-channel sum of
  * the OUTPUT: the squeeze of the SE block that follows. */
@@ -411,6 +420,8 @@ int gldm_groupnorm_swish(float *y /*[b,c,r^3]*/, const float *partial, const flo
  * act = ReLU (use_relu) or Swish. */
 int gldm_se_gate(const float *chan_sum /*[b,c]*/, const float *w1 /*[hidden,c]*/, const float *w2 /*[c,hidden]*/,
                  int b, int c, int hidden, int r, int use_relu, float *gate /*[b,c]*/, gldm_stream_t stream);
+int gldm_se_gate_parts(const float *chan_parts /*[b,parts,c]*/, int parts, const float *w1, const float *w2, int b, int c,
+                       int hidden, int r, int use_relu, float *gate /*[b,c]*/, gldm_stream_t stream);
 
 /* ref: pvconv.py:79-83: trilinear_devoxelize(SE(v)) + point_features(x) in one pass:
  * out = gate[b,c] * trilinear(V) + add  (gate / add may be NULL). */
@@ -423,6 +434,11 @@ int gldm_devoxelize_fused(const float *coords /*[b,3,n]*/, const float *features
 int gldm_devoxelize_gn_fused(const float *coords /*[b,3,n]*/, const float *features /*[b,c,r^3] raw*/,
                              const float *coef /*[b,c,2]*/, const float *gate /*[b,c]*/, const float *add /*[b,c,n]*/,
                              int b, int c, int n, int r, float *out /*[b,c,n]*/, gldm_stream_t stream);
+/* ... and over a channel-LAST raw conv output: a point's corner is one run of c floats (16-byte loads by neighbouring
+ * lanes) instead of c gathers from c cache lines.  c % 4 == 0, c <= 128. */
+int gldm_devoxelize_gn_cl_fused(const float *coords /*[b,3,n]*/, const float *features_cl /*[b,r^3,c] raw*/,
+                                const float *coef /*[b,c,2]*/, const float *gate /*[b,c]*/, const float *add /*[b,c,n]*/,
+                                int b, int c, int n, int r, float *out /*[b,c,n]*/, gldm_stream_t stream);
 
 /* y[b, c, :] = act(y[b, c, :] + bias[c]) in place (relu != 0: ReLU).  Epilogue of the k = 1 Conv1d /
  * Conv2d + BatchNorm(eval, folded) + ReLU of ext/pvcnn/modules/shared_mlp.py:24-36 when the GEMM itself

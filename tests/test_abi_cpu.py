@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_python_binding_covers_every_declared_symbol():
     from graspldm_amd import _lib
-    bound = set(_lib._SIGNATURES) | {"gldm_abi_version", "gldm_status_string", "gldm_r1d_workspace_bytes", "gldm_r1d_tile_columns", "gldm_conv3d_partial_floats"}
+    bound = set(_lib._SIGNATURES) | {"gldm_abi_version", "gldm_status_string", "gldm_r1d_workspace_bytes", "gldm_r1d_tile_columns", "gldm_conv3d_partial_floats", "gldm_squeeze_parts"}
     assert set(_declared()) <= bound, sorted(set(_declared()) - bound)
 
 

@@ -311,7 +311,7 @@ def test_groupnorm_folded_into_its_consumers():
     d = [t.cuda() for t in (b1, b2, g1, be1, g2, be2)]
     L.call("gldm_conv3d_k3_bf16x3", L.ptr(dx), L.ptr(dw1), L.ptr(d[0]), b, c, c, r, L.ptr(y1), L.ptr(p1), st)
     L.call("gldm_groupnorm_coef", L.ptr(p1), L.ptr(d[2]), L.ptr(d[3]), b, c, r, 8, 1e-5, L.ptr(c1), st)
-    L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(y1), L.ptr(c1), L.ptr(dw2), L.ptr(d[1]), b, c, c, r, L.ptr(y2), L.ptr(p2), st)
+    L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(y1), L.ptr(c1), L.ptr(dw2), L.ptr(d[1]), b, c, c, r, L.ptr(y2), L.ptr(p2), 0, st)
     L.call("gldm_groupnorm_coef", L.ptr(p2), L.ptr(d[4]), L.ptr(d[5]), b, c, r, 8, 1e-5, L.ptr(c2), st)
     cs = torch.empty(b, c, device="cuda")
     L.call("gldm_gn_swish_chan_sum", L.ptr(y2), L.ptr(c2), b, c, r, L.ptr(cs), st)
@@ -326,6 +326,24 @@ def test_groupnorm_folded_into_its_consumers():
     dz = z.contiguous().cuda()
     L.call("gldm_devoxelize_fused", L.ptr(dc), L.ptr(dz), L.ptr(dg), L.ptr(da), b, c, n, r, L.ptr(ref), st)
     assert _err(out, ref.cpu()) < 2e-5, _err(out, ref.cpu())
+    # the same stack with the last conv writing channel-last, its squeeze as partial sums and the run-per-corner devoxelize
+    y2cl, p2cl, c2cl = torch.empty(b, r ** 3, c, device="cuda"), torch.empty(nf, device="cuda"), torch.empty(b, c, 2, device="cuda")
+    L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(y1), L.ptr(c1), L.ptr(dw2), L.ptr(d[1]), b, c, c, r, L.ptr(y2cl), L.ptr(p2cl), 1, st)
+    assert torch.equal(y2cl.view(b, r ** 3, c).permute(0, 2, 1).reshape(b, c, r, r, r), y2) and torch.equal(p2cl, p2)
+    L.call("gldm_groupnorm_coef", L.ptr(p2cl), L.ptr(d[4]), L.ptr(d[5]), b, c, r, 8, 1e-5, L.ptr(c2cl), st)
+    parts = int(L.lib().gldm_squeeze_parts())
+    csp = torch.empty(b, parts, c, device="cuda")
+    L.call("gldm_gn_swish_chan_sum_cl", L.ptr(y2cl), L.ptr(c2cl), b, c, r, L.ptr(csp), st)
+    assert _err(csp.sum(1) / r ** 3, z.mean(dim=(2, 3, 4))) < 2e-5
+    w1, w2 = torch.randn(6, c, generator=g) * 0.2, torch.randn(c, 6, generator=g) * 0.2
+    dw1s, dw2s = w1.cuda(), w2.cuda()
+    ga, gb = torch.empty(b, c, device="cuda"), torch.empty(b, c, device="cuda")
+    L.call("gldm_se_gate_parts", L.ptr(csp), parts, L.ptr(dw1s), L.ptr(dw2s), b, c, 6, r, 0, L.ptr(ga), st)
+    L.call("gldm_se_gate", L.ptr(cs), L.ptr(dw1s), L.ptr(dw2s), b, c, 6, r, 0, L.ptr(gb), st)
+    assert _err(ga, gb.cpu()) < 1e-6
+    out2 = torch.empty(b, c, n, device="cuda")
+    L.call("gldm_devoxelize_gn_cl_fused", L.ptr(dc), L.ptr(y2cl), L.ptr(c2cl), L.ptr(dg), L.ptr(da), b, c, n, r, L.ptr(out2), st)
+    assert _err(out2, ref.cpu()) < 2e-5, _err(out2, ref.cpu())
 
 
 def test_ppc_config_z16_latent_against_oracle():
