@@ -410,7 +410,9 @@ def main():
           t_dec = event_time(lambda: dec(lat, z, samples_per_cond=G), 10, lead=2)
           if N == 1024:
               # executed FLOP per cloud by the pipe they run on (head convs folded: 1536 -> 3 instead of 1536 -> 768 -> 3)
-              f_split = 2 * 1024 * (96 * 768 + 768 * 1536) + 2 * 27 * (48 * 48 * 24 ** 3 + 48 * 96 * 12 ** 3 + 96 * 96 * 12 ** 3)
+              # (the first voxel conv, 3 -> 48 @ 24^3, is counted at its 81 real products per output, not the 96 of its
+              # three k-blocks)
+              f_split = 2 * 1024 * (96 * 768 + 768 * 1536) + 2 * 27 * ((3 * 48 + 48 * 48) * 24 ** 3 + 48 * 96 * 12 ** 3 + 96 * 96 * 12 ** 3)
               f_f32 = ENCODER_FLOP_EXECUTED_PER_CLOUD - f_split
               t_floor = B * (f_split / (PEAK_SPLIT_TFLOPS * 1e12) + f_f32 / (PEAK_F32_MFMA_TFLOPS * 1e12))
               enc_rec = dict(achieved=B * ENCODER_FLOP_EXECUTED_PER_CLOUD / t_enc / 1e12,
@@ -421,7 +423,7 @@ def main():
           kernels = [dict(kernel="PVCNNEncoder.forward (all launches)", bound="mfma (mixed pipes)", avg_ms=t_enc * 1e3, unit="TFLOP/s",
                           note="executed FLOP (head convs folded; the reference graph has %.3f GFLOP per cloud); peak = executed "
                                "FLOP / the time the launches would take with each GEMM at the peak of the pipe it runs on (768 -> "
-                               "1536 layer, 96 -> 768 layer and the 48 / 96-channel voxel convs: split-bf16, 2500 / 6 TFLOP/s; the "
+                               "1536 layer, 96 -> 768 layer and the four voxel convs: split-bf16, 2500 / 6 TFLOP/s; the "
                                "rest: f32 MFMA, 157.3): frac = that time / measured, memory passes counted as zero"
                                % (ENCODER_FLOP_PER_CLOUD / 1e9), **enc_rec),
                      dict(kernel="r1d_kernel<64, 16> (gldm_decode: 64-column tiles = 4 samples x 16 positions, split-bf16 GEMMs)"

@@ -35,3 +35,6 @@ cp gpurun_out/pmck_${tag}_sa.json $out/${tag}_point_ops_pmc_raw.json
 bash tools/prof_kernels.sh ${tag}_enc tools/bench_encoders.py --shipped --only "PVCNNEncoder(fpc)" --batch-sizes 256 --iterations 5 > $out/${tag}_encoder_kernels.txt 2>&1
 bash tools/prof_kernels.sh ${tag}_ssg tools/bench_encoders.py --only PointNet2 --batch-sizes 256 --iterations 5 > $out/${tag}_shootout_ssg_kernels.txt 2>&1
 bash tools/prof_kernels.sh ${tag}_pvcnn2 tools/bench_encoders.py --only PVCNN2 --batch-sizes 256 --iterations 5 > $out/${tag}_shootout_pvcnn2_kernels.txt 2>&1
+# the shipped encoder's kernels under counters (matrix-pipe busy, effective clock, waits, LDS, L2: profiles/<tag>_encoder_pmc.*)
+PMCK_MORE=1 bash tools/pmc_kernels.sh ${tag}_enc tools/run_encoder_once.py 256 3 > $out/${tag}_encoder_pmc.txt 2>&1
+cp gpurun_out/pmck_${tag}_enc.json $out/${tag}_encoder_pmc.json
