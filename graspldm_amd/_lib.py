@@ -40,6 +40,7 @@ _SIGNATURES = {
     "gldm_decode": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "gldm_pose_epilogue": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gldm_conv3d_k3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "gldm_conv3d_k3_cl": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_conv3d_k3_generic": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_conv3d_k3_bf16x3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_conv3d_k3_bf16x3_gn": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],

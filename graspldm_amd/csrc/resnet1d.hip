@@ -4145,6 +4145,7 @@ __device__ __forceinline__ void sa3_gemm(const Ctx &c, const float *wp, int kb, 
     case 4: gemm1_pl<4, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;
     case 5: gemm1_pl<5, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;
     case 6: gemm1_pl<6, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;
+    case 9: gemm1_pl<9, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;   // 259 + 3 -> 288 rows (PVCNN2 SA4)
     default: gemm1_pl<8, 1, NT, NoPre, 1, 4, FIRST>(c, wp, mt, nt0, planes, acc, NoPre(), first); break;
   }
 }
@@ -4655,7 +4656,7 @@ GLDM_API int gldm_sa_mlp_forward_bf16x3(const float *points, const float *center
   int blocks_a = 0, blocks_b = 0;
   for (int l = 0; l < n_layers; ++l) {
     const int kb = cin_pad[l] >> 5, mt = cout[l] >> 4;
-    if (cin_pad[l] <= 0 || (cin_pad[l] & 31) || !(kb <= 6 || kb == 8) || cout[l] <= 0 || (cout[l] & 15)) return GLDM_ERR_UNSUPPORTED;
+    if (cin_pad[l] <= 0 || (cin_pad[l] & 31) || !(kb <= 6 || kb == 8 || kb == 9) || cout[l] <= 0 || (cout[l] & 15)) return GLDM_ERR_UNSUPPORTED;
     if (l > 0 && cin_pad[l] != cout[l - 1]) return GLDM_ERR_INVALID_ARG;
     if (l + 1 < n_layers) {   // hidden layer: its output is the next layer's planes
       if ((cout[l] & 31) || !(mt == 2 || mt == 4 || mt == 8 || mt == 16)) return GLDM_ERR_UNSUPPORTED;
@@ -4673,17 +4674,23 @@ GLDM_API int gldm_sa_mlp_forward_bf16x3(const float *points, const float *center
   // narrow nets (32-row inputs, every K in {32, 64, 128}): the multi-tile kernel -- the layer's weights once per
   // workgroup pass, `sub` tiles' planes side by side in LDS (SSG SA1: three 48 KiB tiles, 2.52 -> 2.07 ms).  Two
   // co-resident workgroups of one tile each (the kernel fits 128 registers) measured slower: 2.40 ms.
-  bool kb_ok = cin_pad[0] == 32;
+  bool kb_ok = cin_pad[0] == 32 || cin_pad[0] == 64;   // one or two row quads per gather thread
   for (int l = 0; l < n_layers; ++l) kb_ok = kb_ok && (cin_pad[l] == 32 || cin_pad[l] == 64 || cin_pad[l] == 128);
   int sub = kb_ok ? (int)((size_t)160 * 1024 / tile_bytes) : 1;
   if (sub > 4) sub = 4;
   while (sub > 1 && (total + sub - 1) / sub < 2 * cu_count()) --sub;
   if (sub > 1) {
-    struct Sa3mTag { int site; };
-    gldm_dev::allow_dynamic_lds<Sa3mTag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<4, 1>), 160 * 1024);
     const int supers = (total + sub - 1) / sub;
     const int grid = supers < cu_count() ? supers : cu_count();
-    hipLaunchKernelGGL((sa_mlp3_kernel<4, 1>), dim3(grid), dim3(512), tile_bytes * sub, s, a, blocks_a, blocks_b, sub, tpc, total);
+    if (cin_pad[0] == 32) {
+      struct Sa3mTag { int site; };
+      gldm_dev::allow_dynamic_lds<Sa3mTag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<4, 1>), 160 * 1024);
+      hipLaunchKernelGGL((sa_mlp3_kernel<4, 1>), dim3(grid), dim3(512), tile_bytes * sub, s, a, blocks_a, blocks_b, sub, tpc, total);
+    } else {
+      struct Sa3m2Tag { int site; };
+      gldm_dev::allow_dynamic_lds<Sa3m2Tag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<4, 2>), 160 * 1024);
+      hipLaunchKernelGGL((sa_mlp3_kernel<4, 2>), dim3(grid), dim3(512), tile_bytes * sub, s, a, blocks_a, blocks_b, sub, tpc, total);
+    }
   } else {
     struct Sa3Tag { int site; };
     gldm_dev::allow_dynamic_lds<Sa3Tag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<1, kSa3Quads>), 160 * 1024);

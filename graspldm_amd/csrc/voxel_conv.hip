@@ -69,7 +69,9 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
                                                                     const float *__restrict__ wp,
                                                                     const float *__restrict__ bias, int cin, int cout,
                                                                     int r_arg, float *__restrict__ y,
-                                                                    float *__restrict__ partial, int cout_total, int co0) {
+                                                                    float *__restrict__ partial, int cout_total, int co0,
+                                                                    int out_cl) {
+  // out_cl: y is written channel-last, [b][r^3][cout_total] (see conv3d_k3_pl_kernel); cout % 4 == 0 then
   // cout output channels starting at channel co0 of a cout_total-channel conv (wp / bias already point at the slice):
   // wide convs (256 ch @ 8^3, 128 ch @ 16^3: PVCNN2's feature propagation) run as two launches of half the m-tiles
   constexpr int r = 4 * NTW;  // the instantiation fixes the resolution: every division below is by a constant (with a
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
   constexpr int r3 = r * r * r, zp = brick_zp(r), bv = 36 * zp, bvp = brick_row_stride(r);
   const int cblocks = (cin + 15) >> 4, kblocks = 27 * cblocks;
   x += (size_t)b * cin * r3;
-  y += ((size_t)b * cout_total + co0) * r3;
+  y += out_cl ? (size_t)b * cout_total * r3 + co0 : ((size_t)b * cout_total + co0) * r3;
   const WStream wv(wp, lane);  // weight fragments: buffer loads, scalar offsets (see wstream.h)
   const lds_f *l3 = (const lds_f *)lds;
 
@@ -295,16 +297,24 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
     p[1] = s2;
   }
   GLDM_C3_STAMP(26);
+  if (out_cl) {
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi)
+    for (int ni = 0; ni < NTW; ++ni)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co = 16 * mi + 4 * kq + q;
-      if (co < cout) {
+      for (int mi = 0; mi < MT; ++mi)
+        if (16 * mi + 4 * kq < cout) *reinterpret_cast<f32x4 *>(y + (size_t)gvox[ni] * cout_total + 16 * mi + 4 * kq) = acc[mi][ni];
+  } else {
 #pragma unroll
-        for (int ni = 0; ni < NTW; ++ni) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = 16 * mi + 4 * kq + q;
+        if (co < cout) {
+#pragma unroll
+          for (int ni = 0; ni < NTW; ++ni) y[(size_t)co * r3 + gvox[ni]] = acc[mi][ni][q];
+        }
       }
-    }
+  }
   GLDM_C3_STAMP(21);
 }
 
@@ -938,7 +948,7 @@ __global__ __launch_bounds__(256) void gn_swish_sum_cl_kernel(const float *__res
 // c floats, read as 16-byte loads by c / 4 neighbouring lanes, instead of c dword gathers from c cache lines (the
 // channel-major form is bound by the address path: 64 lines per wave instruction, 0.24 ms per 48 x 24^3 x 256 clouds).
 // Block = 64 points; item = (point, channel quad); the results cross LDS so that the stores (and the reads of `add`) run
-// along the points.  c % 4 == 0, c <= 128.
+// along the points.  c % 4 == 0, c <= 256.
 __global__ __launch_bounds__(256) void devoxelize_cl_kernel(const float *__restrict__ coords, const float *__restrict__ feat,
                                                             const float *__restrict__ coef, const float *__restrict__ gate,
                                                             const float *__restrict__ add, int c, int n, int r,
@@ -1030,13 +1040,13 @@ __global__ __launch_bounds__(256) void devoxelize_fused_kernel(const float *__re
 
 template <int MT, int NTW, int JN>
 int launch_conv_jn(const float *x, const float *wp, const float *bias, int b, int cin, int cout, int r, float *y,
-                float *partial, hipStream_t s, int cout_total, int co0) {
+                float *partial, hipStream_t s, int cout_total, int co0, int out_cl) {
   const size_t lds_bytes = (size_t)16 * brick_row_stride(r) * sizeof(float);
   struct Tag {};  // one flag array per instantiation
   gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_kernel<MT, NTW, JN>), (int)lds_bytes);
   const int bpr = r / kBrick;
   hipLaunchKernelGGL((conv3d_k3_kernel<MT, NTW, JN>), dim3(bpr * bpr, b), dim3(kConvThreads), lds_bytes, s, x, wp, bias,
-                     cin, cout, r, y, partial, cout_total, co0);
+                     cin, cout, r, y, partial, cout_total, co0, out_cl);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 
@@ -1228,28 +1238,29 @@ GLDM_API long long gldm_conv3d_partial_floats(int b, int cout, int r) {
 
 template <int MT, int NTW>
 int launch_conv(const float *x, const float *wp, const float *bias, int b, int cin, int cout, int r, float *y,
-                float *partial, hipStream_t s, int cout_total = -1, int co0 = 0) {
+                float *partial, hipStream_t s, int out_cl, int cout_total = -1, int co0 = 0) {
   if (cout_total < 0) cout_total = cout;
   // a 3-channel input (the first voxel conv) has one real k-step per tap: skip the three of padding
-  return cin <= 4 ? launch_conv_jn<MT, NTW, 1>(x, wp, bias, b, cin, cout, r, y, partial, s, cout_total, co0)
-                  : launch_conv_jn<MT, NTW, 4>(x, wp, bias, b, cin, cout, r, y, partial, s, cout_total, co0);
+  return cin <= 4 ? launch_conv_jn<MT, NTW, 1>(x, wp, bias, b, cin, cout, r, y, partial, s, cout_total, co0, out_cl)
+                  : launch_conv_jn<MT, NTW, 4>(x, wp, bias, b, cin, cout, r, y, partial, s, cout_total, co0, out_cl);
 }
 
 // a conv of 2 MH m-tiles as two launches of MH (the accumulators of 16 m-tiles do not fit a wave)
 template <int MH, int NTW>
 int launch_conv_halves(const float *x, const float *wp, const float *bias, int b, int cin, int cout, int r, float *y,
-                       float *partial, hipStream_t s) {
+                       float *partial, hipStream_t s, int out_cl) {
   const size_t kblocks = 27 * (size_t)((cin + 15) >> 4);
   const int half = 16 * MH;
-  const int rc = launch_conv<MH, NTW>(x, wp, bias, b, cin, half, r, y, partial, s, cout, 0);
+  const int rc = launch_conv<MH, NTW>(x, wp, bias, b, cin, half, r, y, partial, s, out_cl, cout, 0);
   if (rc != GLDM_OK) return rc;
-  return launch_conv<MH, NTW>(x, wp + (size_t)MH * kblocks * 256, bias + half, b, cin, cout - half, r, y, partial, s, cout, half);
+  return launch_conv<MH, NTW>(x, wp + (size_t)MH * kblocks * 256, bias + half, b, cin, cout - half, r, y, partial, s, out_cl, cout, half);
 }
 
-GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *bias, int b, int cin, int cout, int r,
-                            float *y, float *partial, gldm_stream_t stream) {
+static int conv3d_k3_impl(const float *x, const float *w_packed, const float *bias, int b, int cin, int cout, int r,
+                          float *y, float *partial, int out_cl, gldm_stream_t stream) {
   if (!x || !w_packed || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0)
     return GLDM_ERR_INVALID_ARG;
+  if (out_cl && cout % 4) return GLDM_ERR_UNSUPPORTED;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int mt = (cout + 15) / 16, ntw = r / 4;
   if (r % 4 || (size_t)16 * brick_row_stride(r) * 4 > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
@@ -1276,7 +1287,7 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
   } dump{s, cin, cout, r};
 #endif
 #define GLDM_CONV_CASE(M, N) \
-  if (mt == M && ntw == N) return launch_conv<M, N>(x, w_packed, bias, b, cin, cout, r, y, partial, s)
+  if (mt == M && ntw == N) return launch_conv<M, N>(x, w_packed, bias, b, cin, cout, r, y, partial, s, out_cl)
   GLDM_CONV_CASE(3, 6);   // 48 ch @ 24^3  (shipped fpc/ppc PVCNN encoder)
   GLDM_CONV_CASE(6, 3);   // 96 ch @ 12^3
   GLDM_CONV_CASE(2, 8);   // 32 ch @ 32^3  (PVCNN2)
@@ -1291,9 +1302,19 @@ GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *
   GLDM_CONV_CASE(4, 1);   // 64 ch @ 4^3
   GLDM_CONV_CASE(8, 1);   // 128 ch @ 4^3
 #undef GLDM_CONV_CASE
-  if (mt == 16 && ntw == 2) return launch_conv_halves<8, 2>(x, w_packed, bias, b, cin, cout, r, y, partial, s);  // 256 ch @ 8^3
-  if (mt == 8 && ntw == 4) return launch_conv_halves<4, 4>(x, w_packed, bias, b, cin, cout, r, y, partial, s);   // 128 ch @ 16^3
+  if (mt == 16 && ntw == 2) return launch_conv_halves<8, 2>(x, w_packed, bias, b, cin, cout, r, y, partial, s, out_cl);  // 256 ch @ 8^3
+  if (mt == 8 && ntw == 4) return launch_conv_halves<4, 4>(x, w_packed, bias, b, cin, cout, r, y, partial, s, out_cl);   // 128 ch @ 16^3
   return GLDM_ERR_UNSUPPORTED;
+}
+
+GLDM_API int gldm_conv3d_k3(const float *x, const float *w_packed, const float *bias, int b, int cin, int cout, int r,
+                            float *y, float *partial, gldm_stream_t stream) {
+  return conv3d_k3_impl(x, w_packed, bias, b, cin, cout, r, y, partial, 0, stream);
+}
+
+GLDM_API int gldm_conv3d_k3_cl(const float *x, const float *w_packed, const float *bias, int b, int cin, int cout, int r,
+                               float *y_cl, float *partial, gldm_stream_t stream) {
+  return conv3d_k3_impl(x, w_packed, bias, b, cin, cout, r, y_cl, partial, 1, stream);
 }
 
 template <int MT, int R, int ZB, int WAVES, bool ACT>
@@ -1422,7 +1443,9 @@ GLDM_API int gldm_gn_swish_chan_sum_cl(const float *y, const float *coef, int b,
 GLDM_API int gldm_devoxelize_gn_cl_fused(const float *coords, const float *features_cl, const float *coef, const float *gate,
                                          const float *add, int b, int c, int n, int r, float *out, gldm_stream_t stream) {
   if (!coords || !features_cl || !coef || !out || b <= 0 || c <= 0 || n <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
-  if (c % 4 || c > 128) return GLDM_ERR_UNSUPPORTED;
+  if (c % 4 || c > 256) return GLDM_ERR_UNSUPPORTED;
+  struct DevoxClTag { int site; };
+  gldm_dev::allow_dynamic_lds<DevoxClTag>(reinterpret_cast<const void *>(&devoxelize_cl_kernel), 256 * 65 * (int)sizeof(float));
   hipLaunchKernelGGL(devoxelize_cl_kernel, dim3((n + 63) / 64, b), dim3(256), (size_t)c * 65 * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), coords, features_cl, coef, gate, add, c, n, r, out);
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;

@@ -33,8 +33,11 @@ def split_plan_ok(cins, couts, num_neighbors):
     """Shapes gldm_sa_mlp_forward_bf16x3 takes (csrc/resnet1d.hip: sa_mlp3_kernel): 64-column tiles on split-bf16 planes."""
     if int(num_neighbors) not in (16, 32, 64) or not 1 <= len(couts) <= 4:
         return False
+    # hidden widths are packed padded to the 32-row plane blocks (zero weight rows, zero bias: ReLU leaves zeros, and the
+    # next layer's weights over those rows are zero): a 16-wide hidden layer (half-width PVCNN2) runs as a 32-wide one
+    couts = [(c + 31) // 32 * 32 for c in couts[:-1]] + [couts[-1]]
     kpad = [(cins[0] + 31) // 32 * 32] + list(couts[:-1])
-    if any(k % 32 or not (k // 32 <= 6 or k // 32 == 8) for k in kpad) or any(c % 16 for c in couts):
+    if any(k % 32 or not (k // 32 <= 6 or k // 32 in (8, 9)) for k in kpad) or any(c % 16 for c in couts):
         return False
     if any(c not in (32, 64, 128, 256) for c in couts[:-1]):
         return False
@@ -83,12 +86,15 @@ class SaMlpPlan:
             for i in range(n):
                 w, b = fold_conv_bn(layers[3 * i], layers[3 * i + 1])
                 kpad = (w.shape[1] + 31) // 32 * 32
-                wp = torch.zeros(w.shape[0], kpad)
-                wp[:, : w.shape[1]] = w.cpu()
+                rows = w.shape[0] if i == n - 1 else (w.shape[0] + 31) // 32 * 32   # hidden widths: whole plane blocks
+                wp = torch.zeros(rows, kpad)
+                wp[: w.shape[0], : w.shape[1]] = w.cpu()
+                bp = torch.zeros(rows)
+                bp[: w.shape[0]] = b.cpu()
                 cin_pad.append(kpad)
-                cout.append(w.shape[0])
+                cout.append(rows)
                 w_off.append(buf.add(mfma_a_fragments_bf16x3(wp)))
-                b_off.append(buf.add(b.cpu()))
+                b_off.append(buf.add(bp))
             arr = ctypes.c_int32 * n
             self._split = (buf.tensor().to(self._device), arr(*cin_pad), arr(*cout), arr(*w_off), arr(*b_off))
         return self._split

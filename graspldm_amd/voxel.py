@@ -96,11 +96,15 @@ def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
             partial = torch.empty(int(nf), dtype=torch.float32, device=dev)
             last = i == len(convs) - 1
             staged = plan.split[i] and cin % 16 == 0          # the plane-staging kernels: folded input, channel-last output
+            mfma32 = not plan.split[i] and not plan.generic[i]   # the f32-MFMA kernels: channel-last output
             # the last conv's readers (squeeze, devoxelize) take a voxel's channels as one run
-            cl = last and staged and cout % 4 == 0 and cout <= 128 and cout // gn.num_groups <= 64
+            cl = last and (staged or mfma32) and cout % 4 == 0 and cout <= 256 and cout // gn.num_groups <= 64
             if staged and (coef is not None or cl):
                 L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(x), L.ptr(coef), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r,
                        L.ptr(y), L.ptr(partial), 1 if cl else 0, st)
+            elif cl:
+                assert coef is None
+                L.call("gldm_conv3d_k3_cl", L.ptr(x), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r, L.ptr(y), L.ptr(partial), st)
             else:
                 assert coef is None
                 entry = "gldm_conv3d_k3_generic" if plan.generic[i] else ("gldm_conv3d_k3_bf16x3" if plan.split[i] else "gldm_conv3d_k3")

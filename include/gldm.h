@@ -366,6 +366,11 @@ int gldm_conv3d_k3(const float *x /*[b,cin,r^3]*/, const float *w_packed, const 
                    int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/, float *partial,
                    gldm_stream_t stream);
 
+/* gldm_conv3d_k3 writing its output channel-last, [b, r^3, cout] (the layout gldm_gn_swish_chan_sum_cl and
+ * gldm_devoxelize_gn_cl_fused read: a voxel stack's last conv); cout % 4 == 0. */
+int gldm_conv3d_k3_cl(const float *x /*[b,cin,r^3]*/, const float *w_packed, const float *bias /*[cout]*/, int b, int cin,
+                      int cout, int r, float *y_cl /*[b,r^3,cout]*/, float *partial, gldm_stream_t stream);
+
 /* The same conv for ANY channel counts (r % 4 == 0) with the weight as nn.Conv3d stores it, [cout, cin, 27] f32: a
  * direct VALU kernel for voxel shapes the MFMA kernels are not instantiated for (PVCNN2's 256 ch @ 8^3, 128 ch @ 16^3);
  * same `partial` layout.  A correctness path: no shape of the shipped encoder uses it. */
@@ -435,7 +440,7 @@ int gldm_devoxelize_gn_fused(const float *coords /*[b,3,n]*/, const float *featu
                              const float *coef /*[b,c,2]*/, const float *gate /*[b,c]*/, const float *add /*[b,c,n]*/,
                              int b, int c, int n, int r, float *out /*[b,c,n]*/, gldm_stream_t stream);
 /* ... and over a channel-LAST raw conv output: a point's corner is one run of c floats (16-byte loads by neighbouring
- * lanes) instead of c gathers from c cache lines.  c % 4 == 0, c <= 128. */
+ * lanes) instead of c gathers from c cache lines.  c % 4 == 0, c <= 256. */
 int gldm_devoxelize_gn_cl_fused(const float *coords /*[b,3,n]*/, const float *features_cl /*[b,r^3,c] raw*/,
                                 const float *coef /*[b,c,2]*/, const float *gate /*[b,c]*/, const float *add /*[b,c,n]*/,
                                 int b, int c, int n, int r, float *out /*[b,c,n]*/, gldm_stream_t stream);

@@ -162,20 +162,22 @@ def test_ddpm_sampler_runs_and_is_seed_reproducible(ldm):
 @pytest.mark.parametrize("b,c,n,m,u,chans", [(2, 128, 512, 128, 64, (128, 128, 256)), (3, 0, 1024, 512, 64, (64, 64, 128)),
                                              (2, 32, 1024, 1024, 32, (32, 64)), (1, 5, 300, 37, 16, (16, 32, 32, 64)),
                                              (2, 64, 256, 37, 32, (64, 128)), (300, 16, 128, 5, 16, (32, 64, 128, 256)),
-                                             (1, 160, 200, 9, 64, (128, 128))])
+                                             (1, 160, 200, 9, 64, (128, 128)), (2, 16, 1024, 1024, 32, (16, 32)),
+                                             (2, 256, 64, 16, 32, (128, 256))])
 @pytest.mark.parametrize("split", [True, False])
 def test_fused_sa_mlp_equals_unfused_oracle(b, c, n, m, u, chans, split, monkeypatch):
     """gldm_sa_mlp_forward_bf16x3 / gldm_sa_mlp_forward (gather + grouped MLP + max, fused) vs the oracle's
-    ball_group -> shared_mlp -> max on the same weights.  split=True: every case but the fourth (a 16-row hidden layer) runs
-    on the split-bf16 64-column kernel (sa_mlp3_kernel: 1 / 2 / 4 centres per tile, ragged last tiles, more tiles than
-    persistent workgroups, 2-4 layers, 1-6 input blocks).  split=False forces the f32 kernels: cases 1-3, 5, 6 on the
+    ball_group -> shared_mlp -> max on the same weights.  split=True: every case runs on the split-bf16 64-column kernel
+    (sa_mlp3_kernel: 1 / 2 / 4 centres per tile, ragged last tiles, more tiles than persistent workgroups, 2-4 layers,
+    1-6 and 9 input blocks, 16-wide hidden layers packed as zero-padded 32-wide ones, the narrow-net form with one and
+    with two row quads per gather thread).  split=False forces the f32 kernels: cases 1-3, 5, 6 on the
     128-column one (sa_mlp2_kernel), cases 4 and 7 on the 64-column one (sa_mlp_kernel)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from graspldm_amd import sa_pack
     if not split:
         monkeypatch.setattr(sa_pack, "split_plan_ok", lambda *a, **k: False)
-    elif chans != (16, 32, 32, 64):
+    else:
         cins = [c + 3] + list(chans[:-1])
         assert sa_pack.split_plan_ok(cins, list(chans), u)
     from graspldm_amd.pvcnn import PointNetSAModule
