@@ -398,6 +398,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   // (Measured and kept out: 4 waves x 6 n-tiles on the 24^3 brick -- half the weight-fragment deliveries, but more than
   // 256 registers, hence one wave per SIMD -- 0.74 ms per launch against 0.67 for 8 waves x 3 n-tiles.)
   constexpr int zp = ZB + 2, nvox = 36 * zp, r3 = r * r * r;
+  constexpr int hs = (nvox + 15) & ~15;   // units between the two channel halves of a plane: a multiple of the 16-unit bank row
   constexpr int kItems = 2 * nvox, kRounds = (kItems + kThreads - 1) / kThreads;
   extern __shared__ float lds[];
   GLDM_C3_STAMP(0);
@@ -413,8 +414,9 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   y += (size_t)b * cout * r3;
   const WStream wv(wp3, lane);
   typedef __attribute__((address_space(3))) c3_u32x4 lds_c4;
-  lds_c4 *pl = (lds_c4 *)lds;   // 16-byte units: plane * 2 nvox + half * nvox + voxel: the 16 columns of a fragment row read
-                                // 16 consecutive units (256 B = every bank once); voxel-major pairs (32 B apart) were 2-way conflicts
+  lds_c4 *pl = (lds_c4 *)lds;   // 16-byte units: plane * 2 hs + half * hs + voxel.  A ds_read_b128 is served in 16-lane groups
+                                // that mix columns 0-3, 12-15 of one lane row with columns 4-11 of the next (the other channel
+                                // half): with hs a multiple of 16 units the two sets fall on disjoint banks
 
   // fragment read base of (n-tile, lane column): voxel (0,0,0)-tap of the column, this lane's channel half
   int vb[NTW], gvox[NTW];
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   for (int ni = 0; ni < NTW; ++ni) {
     const int o = 16 * (wave * NTW + ni) + col;
     const int iz = o % ZB, ixy = o / ZB, ix = ixy >> 2, iy = ixy & 3;
-    vb[ni] = (ix * 6 + iy) * zp + iz + (kq & 1) * nvox;
+    vb[ni] = (ix * 6 + iy) * zp + iz + (kq & 1) * hs;
     gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + bz0 + iz;
   }
   f32x4 acc[MT][NTW];
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
       const int h = it / nvox, v = it - h * nvox;       // half-major: a wave's loads run along z
       const int ixy = v / zp, izp = v - ixy * zp;
       const int gx = bx0 + ixy / 6 - 1, gy = by0 + ixy % 6 - 1, gz = bz0 + izp - 1;
-      s_lds[q] = h * nvox + v;
+      s_lds[q] = h * hs + v;
       if ((unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r && (unsigned)gz < (unsigned)r)
         s_glb[q] = (gx * r + gy) * r + gz + 8 * h * r3;
     }
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
     for (int q = 0; q < kRounds; ++q)
       if (s_lds[q] >= 0 && s_glb[q] < 0) {
 #pragma unroll
-        for (int p3 = 0; p3 < 3; ++p3) pl[p3 * 2 * nvox + s_lds[q]] = z4;
+        for (int p3 = 0; p3 < 3; ++p3) pl[p3 * 2 * hs + s_lds[q]] = z4;
       }
   }
   float stg[kRounds][8];
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   };
   // ACT: (a, s) of every input channel of this cloud, behind the planes (the launcher adds the room): read back as
   // wave-wide broadcasts of four 16-byte pairs-of-pairs per staged item
-  float *s_coef = lds + 3 * 2 * nvox * 4;   // [cin][2]
+  float *s_coef = lds + 3 * 2 * hs * 4;   // [cin][2]
   if constexpr (ACT) {
     for (int i = tid; i < 2 * cin; i += kThreads) s_coef[i] = in_coef[(size_t)b * cin * 2 + i];
   }
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
         c3_u32x4 p3[3];
         c3_split(stg[q], p3);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pl[k * 2 * nvox + s_lds[q]] = p3[k];
+        for (int k = 0; k < 3; ++k) pl[k * 2 * hs + s_lds[q]] = p3[k];
       }
   };
   GLDM_C3_STAMP(1);
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
 #pragma unroll
       for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) bs[buf][q][k] = pl[k * 2 * nvox + vb[3 * ng + q] + toff];
+        for (int k = 0; k < 3; ++k) bs[buf][q][k] = pl[k * 2 * hs + vb[3 * ng + q] + toff];
     };
     if (kBPre) load_b(0, 0);
     for (int p0 = 0; p0 < kPairs; p0 += 2) {
@@ -1320,7 +1322,7 @@ GLDM_API int gldm_conv3d_k3_cl(const float *x, const float *w_packed, const floa
 template <int MT, int R, int ZB, int WAVES, bool ACT>
 int launch_conv_pl_act(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
                        const float *in_coef, int out_cl, hipStream_t s) {
-  const size_t lds_bytes = (size_t)3 * 36 * (ZB + 2) * 32 + (ACT ? (size_t)2 * cin * sizeof(float) : 0);
+  const size_t lds_bytes = (size_t)3 * 2 * ((36 * (ZB + 2) + 15) & ~15) * 16 + (ACT ? (size_t)2 * cin * sizeof(float) : 0);
   struct Tag {};
   gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_pl_kernel<MT, R, ZB, WAVES, ACT>), (int)lds_bytes);
   const int bpr = R / kBrick;

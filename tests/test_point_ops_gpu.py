@@ -90,7 +90,8 @@ def test_three_nn_interpolate_exact(hip, cpu, b, c, m, n):
 
 
 @pytest.mark.parametrize("b,c,n,r", [(2, 3, 1024, 24), (2, 48, 1024, 12), (1, 5, 200, 4), (1, 16, 4096, 32),
-                                     (2, 4, 64, 2), (1, 3, 100, 5), (1, 2, 300, 40), (3, 11, 1000, 16)])
+                                     (2, 4, 64, 2), (1, 3, 100, 5), (1, 2, 300, 40), (3, 11, 1000, 16), (1, 7, 333, 8),
+                                     (2, 20, 2048, 16)])
 def test_avg_voxelize_exact_and_deterministic(hip, cpu, b, c, n, r):
     g = torch.Generator().manual_seed(8)
     feat = torch.randn(b, c, n, generator=g)
@@ -101,8 +102,8 @@ def test_avg_voxelize_exact_and_deterministic(hip, cpu, b, c, n, r):
     eo, ei, ek = cpu.avg_voxelize_forward(feat, vc, r)
     assert torch.equal(i.cpu(), ei) and torch.equal(k.cpu(), ek)
     assert torch.equal(o.cpu(), eo)  # same ascending-index summation order -> bitwise
-    # (grids whose rows fit LDS are assembled on chip and written dense; r = 5 (r^3 % 4 != 0) and r = 40 take the
-    # memset + scattered-store form)
+    # (grids whose rows fit LDS are assembled on chip and written dense -- n = 333: scalar feature staging, n = 2048: the
+    # keys sorted through LDS; r = 5 (r^3 % 4 != 0) and r = 40 take the memset + scattered-store form)
     o2, _, _ = hip.avg_voxelize_forward(feat.cuda(), vc.cuda(), r)
     assert torch.equal(o2, o)
 
