@@ -3848,7 +3848,7 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a
     const int dyn_first = a.dyn_first;
     int unit = wave;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load_a(u, 2 * unit, u);
+    for (int u = 0; u < 4; ++u) load_a(u, 2 * (unit < units ? unit : 0), u);   // a wave without a unit requests unit 0's (unused)
     load_b(0, 0);
     while (unit < units) {
       const int mt0 = 2 * unit;
@@ -4547,7 +4547,9 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   if (!x || !w || !bias || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
   if (!y && !head_w) return GLDM_ERR_INVALID_ARG;
   if (head_w && (!z || hout <= 0 || hout > 16)) return GLDM_ERR_INVALID_ARG;
-  if ((cin & 31) || (cout & 255) || (n & 31)) return GLDM_ERR_UNSUPPORTED;  // k-blocks in pairs, 2 m-tiles x 8 waves, 32-point tiles
+  // k-blocks in pairs, 32-point tiles; output rows: 2 m-tiles x 8 waves per round on the f32 kernel, units of two m-tiles on
+  // the split one (fewer than eight units -- 64 .. 224 output rows -- leave waves without a unit idle)
+  if ((cin & 31) || (n & 31) || (split_bf16 ? (cout & 31) : (cout & 255))) return GLDM_ERR_UNSUPPORTED;
   if (w0 && (!b0 || cin0 <= 0 || (cin0 & 31) || (cin & 255))) return GLDM_ERR_UNSUPPORTED;
   size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
   if (split_bf16) {  // `w` and `w0` hold split-bf16 fragments: planes of the tile + the front layer's f32 tile
@@ -4562,7 +4564,7 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
     size_t region = w0 ? (size_t)cin0 * 32 * sizeof(float) : 0;
     if (planes + region > cap) return GLDM_ERR_UNSUPPORTED;
     const int units = cout / 32;
-    int drawn = units - 8;
+    int drawn = units > 8 ? units - 8 : 0;
     if (head_w) {
       const size_t slot = (size_t)hout * 32 * sizeof(float);
       const int room = (int)((cap - planes) / slot);

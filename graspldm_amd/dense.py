@@ -64,6 +64,13 @@ def fused_mlp_supported(x, cin, cout):
             and 4 * (32 * cin + 4096) <= 160 * 1024)
 
 
+def split_mlp_supported(x, cin, cout):
+    """The split-bf16 launch on its own (gldm_pointwise_mlp_bf16x3): output rows in units of 32 (fewer than 256 leave waves
+    idle, still several times the any-shape kernel's rate: the 128-row feature-propagation layers of PointNet++ / PVCNN2)."""
+    return (x.ndim == 3 and x.is_contiguous() and cout % 32 == 0 and cout >= 64 and x.shape[-1] % 32 == 0
+            and split_supported(cin))
+
+
 def fused_mlp2_supported(x, cin0, cin, cout):
     """Two layers in one launch (gldm_pointwise_mlp2): cin0 -> cin -> cout."""
     return (x.ndim == 3 and x.is_contiguous() and cin0 % 32 == 0 and cin % 256 == 0 and cout % 256 == 0
@@ -125,6 +132,8 @@ def folded_conv_bn(conv, bn, device):
             # split fragments: main layers of the split launch (cin % 128 == 0) and its narrow front layers (cin <= 128)
             if split_supported(w.shape[1]) or w.shape[1] <= 128:
                 ws = mfma_a_fragments_bf16x3(w.detach().float().cpu()).to(device)
+        elif w.shape[0] % 32 == 0 and w.shape[0] >= 64 and split_supported(w.shape[1]):
+            ws = mfma_a_fragments_bf16x3(w.detach().float().cpu()).to(device)   # 64 .. 224 output rows: split launch only
         hit = (key, w, b, wp, ws)
         conv.__dict__["_gldm_folded"] = hit
         publish(device)
@@ -142,6 +151,8 @@ def pointwise_conv_bn_relu(x, conv, bn):
         if ws is not None and split_supported(w.shape[1]):   # (narrow layers keep split fragments as FRONT layers only)
             return pointwise_mlp(x, ws, b, w.shape[0], True, split=True)[0]
         return pointwise_mlp(x, wp, b, w.shape[0], True)[0]
+    if wp is None and ws is not None and split_mlp_supported(x, w.shape[1], w.shape[0]):
+        return pointwise_mlp(x, ws, b, w.shape[0], True, split=True)[0]
     return _gemm_bias_act(x, w, b, True)
 
 

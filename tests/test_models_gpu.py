@@ -494,12 +494,15 @@ def test_pointwise_mlp_two_layers_one_launch(b, cin0, cin, cout, n, hout):
 @pytest.mark.parametrize("b,cin0,cin,cout,n,hout", [(2, 96, 768, 1536, 64, 3), (3, 32, 256, 256, 96, 0),
                                                     (1, 64, 512, 768, 32, 16), (5, 96, 256, 512, 2048, 3),
                                                     (2, 0, 128, 256, 64, 0), (1, 0, 768, 1536, 96, 3),
-                                                    (5, 0, 128, 256, 2048, 0), (5, 32, 256, 256, 2048, 0)])
+                                                    (5, 0, 128, 256, 2048, 0), (5, 32, 256, 256, 2048, 0),
+                                                    (3, 0, 128, 128, 1024, 0), (2, 0, 256, 128, 512, 0), (1, 0, 128, 64, 32, 0),
+                                                    (2, 0, 256, 224, 64, 0)])
 def test_pointwise_mlp_split_bf16(b, cin0, cin, cout, n, hout):
     """gldm_pointwise_mlp_bf16x3 / gldm_pointwise_mlp2_bf16x3 (both layers on the bf16 matrix pipe, every f32 operand
     split exactly into three bf16 numbers; units of output rows handed out to the waves at run time) against a torch-CPU
     reference computed in f64: 2e-5 of the output scale, like the f32-pipe form.  (5, ..., 2048): 320 tiles on 256
-    workgroups, i.e. some workgroups take a second tile."""
+    workgroups, i.e. some workgroups take a second tile.  cout 64 / 128 / 224: fewer units of output rows than waves (the
+    128-row feature-propagation layers of the PointNet++-style backbones)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from graspldm_amd import dense

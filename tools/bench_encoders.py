@@ -105,9 +105,17 @@ def main():
     PEAK_SPLIT = 2500.0 / 6           # f32 products as six bf16 partial products on the bf16 matrix pipe
     # Executed FLOP per cloud by the pipe they run on, where part of a model runs as split-bf16 products: the shipped
     # PVCNNEncoder (768 -> 1536 layer + its 96 -> 768 front layer + the 48 / 96-channel voxel convs; head convs folded into
-    # one 1536 -> 3 GEMM: 2.4 GFLOP of the reference graph never executed).  Every other model here runs on the f32 pipe.
-    split_exec = {"PVCNNEncoder(fpc)": (2 * 1024 * (96 * 768 + 768 * 1536) + 2 * 27 * (48 * 48 * 24 ** 3 + 48 * 96 * 12 ** 3 + 96 * 96 * 12 ** 3),
-                                        8.115050112e9 - 2 * 768 * 1536 * 1024 - 2 * 3 * 768 * 1024 + 2 * 3 * 1536 * 1024)}
+    # one 1536 -> 3 GEMM: 2.4 GFLOP of the reference graph never executed).
+    # The set-abstraction MLPs of the two PointNet++-style backbones run on the split kernel too (sa_mlp3_kernel), as do the
+    # feature-propagation layers whose shapes the fused split launch takes (cin % 128 == 0, cout % 256 == 0).
+    def sa(m, u, chans):   # FLOP of a grouped MLP over m centres x u neighbours
+        return 2 * m * u * sum(a * b for a, b in zip(chans[:-1], chans[1:]))
+    ssg_split = sa(512, 64, (3, 64, 64, 128)) + sa(128, 64, (131, 128, 128, 256)) \
+        + 2 * 128 * (256 * 512 + 512 * 1024 + 256 * 256) + 2 * 512 * 384 * 256
+    pv2_split = sa(1024, 32, (19, 16, 32)) + sa(256, 32, (35, 32, 64)) + sa(64, 32, (67, 64, 128))
+    split_exec = {"PVCNNEncoder(fpc)": (2 * 1024 * (96 * 768 + 768 * 1536) + 2 * 27 * ((3 * 48 + 48 * 48) * 24 ** 3 + 48 * 96 * 12 ** 3 + 96 * 96 * 12 ** 3),
+                                        8.115050112e9 - 2 * 768 * 1536 * 1024 - 2 * 3 * 768 * 1024 + 2 * 3 * 1536 * 1024),
+                  "PointNet2": (ssg_split, flops.get("PointNet2", 0)), "PVCNN2": (pv2_split, flops.get("PVCNN2", 0))}
     results = {}
     for name, m in models.items():
         load_synthetic_weights(m, seed=0)
