@@ -203,7 +203,8 @@ __device__ __forceinline__ float half_max(float x) {
 }
 
 #ifdef GLDM_DEBUG_KNOBS
-__device__ long long g_wv_stamp[8][32][4];   // per wave, ring of the last 32 position-major convs: in, k-loop done, out, shape
+__device__ long long g_wv_stamp[8][32][8];   // per wave, ring of the last 32 position-major convs: in, k-loop done, out, shape,
+                                             // statistics published (in front of the exchange barrier), partners merged
 __device__ int g_wv_cnt[8];
 #define GLDM_WV_STAMP(c, k, v) \
   do { if (blockIdx.x == 0 && (c).lane == 0) g_wv_stamp[(c).wave][g_wv_cnt[(c).wave] & 31][k] = (v); } while (0)
@@ -1309,7 +1310,11 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
   }
   // ---- scale / shift rows of this lane's sample (the same for all positions: once per m-tile).  They do not depend
   // on the statistics, so they are issued in front of the exchange barrier: the MFMA chain runs while the wave waits
+#if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_EXP_NO_SS)   // timing experiment only (wrong results): no scale/shift chain
+  if (false) {
+#else
   if (has_ss && !ss_tab) {
+#endif
     const lds_f *Gs = (const lds_f *)(c.lds + GG::kMiscG) + sm * g.E;
     float gb[4];
 #pragma unroll
@@ -1333,7 +1338,9 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
       }
     }
   }
+  GLDM_WV_STAMP(c, 4, (long long)__builtin_readcyclecounter());
   __syncthreads();
+  GLDM_WV_STAMP(c, 5, (long long)__builtin_readcyclecounter());
   float tot = 0.f, ps1[kParts], ps2[kParts];
 #pragma unroll
   for (int q = 0; q < kParts; ++q) {
@@ -3518,7 +3525,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
            host[0] - host[kMaxOps + 1]);
 #ifdef GLDM_DEBUG_KNOBS
     if (pm) {   // per-wave view of the last 32 position-major convs of workgroup 0: k-loop / epilogue, relative to wave 0's entry
-      static long long wv[8][32][4];
+      static long long wv[8][32][8];
       int cnt[8];
       (void)hipMemcpyFromSymbol(wv, HIP_SYMBOL(g_wv_stamp), sizeof(wv));
       (void)hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_wv_cnt), sizeof(cnt));
@@ -3526,8 +3533,9 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
         const int e = (cnt[0] + i) & 31;
         printf("conv %3lld->%3lld:", wv[0][e][3] / 1000, wv[0][e][3] % 1000);
         for (int w = 0; w < 8; ++w)
-          printf("  w%d in %+5lld loop %6lld epi %6lld |", w, wv[w][e][0] - wv[0][e][0], wv[w][e][1] - wv[w][e][0],
-                 wv[w][e][2] - wv[w][e][1]);
+          printf("  w%d in %+5lld loop %6lld epi %6lld (stats %5lld wait %5lld finish %5lld) |", w, wv[w][e][0] - wv[0][e][0],
+                 wv[w][e][1] - wv[w][e][0], wv[w][e][2] - wv[w][e][1], wv[w][e][4] - wv[w][e][1], wv[w][e][5] - wv[w][e][4],
+                 wv[w][e][2] - wv[w][e][5]);
         printf("\n");
       }
     }
