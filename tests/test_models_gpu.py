@@ -348,6 +348,53 @@ def test_groupnorm_folded_into_its_consumers():
     assert _err(out2, ref.cpu()) < 2e-5, _err(out2, ref.cpu())
 
 
+@pytest.mark.parametrize("cin,c,r,n", [(48, 96, 12, 100), (3, 32, 16, 77), (64, 64, 8, 1024), (128, 256, 8, 64)])
+def test_channel_last_voxel_stack_tail(cin, c, r, n):
+    """A voxel stack's last conv written channel-last by the f32 / split kernels (gldm_conv3d_k3_cl,
+    gldm_conv3d_k3_bf16x3_gn(out_channel_last)) is the channel-major output transposed, bit for bit, and the squeeze /
+    devoxelize passes over it agree with the channel-major ones (ragged point counts, 12 / 16 / 24 / 64 channel quads,
+    the two-launch 256-channel conv)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from graspldm_amd import _lib as L
+    from graspldm_amd.voxel import pack_conv3d, pack_conv3d_bf16x3, split_conv_supported
+    g = torch.Generator().manual_seed(c + r)
+    b = 2
+    x = torch.randn(b, cin, r, r, r, generator=g).cuda()
+    w = torch.randn(c, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    bias, gamma, beta = (torch.randn(c, generator=g).cuda() * 0.1 for _ in range(3))
+    gamma = gamma + 1
+    st = L.current_stream()
+    nf = int(L.lib().gldm_conv3d_partial_floats(b, c, r))
+    y, ycl = torch.empty(b, c, r ** 3, device="cuda"), torch.empty(b, r ** 3, c, device="cuda")
+    p, pcl = torch.empty(nf, device="cuda"), torch.empty(nf, device="cuda")
+    if split_conv_supported(cin, c, r):
+        dw = pack_conv3d_bf16x3(w).cuda()
+        L.call("gldm_conv3d_k3_bf16x3", L.ptr(x), L.ptr(dw), L.ptr(bias), b, cin, c, r, L.ptr(y), L.ptr(p), st)
+        L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(x), None, L.ptr(dw), L.ptr(bias), b, cin, c, r, L.ptr(ycl), L.ptr(pcl), 1, st)
+    else:
+        dw = pack_conv3d(w).cuda()
+        L.call("gldm_conv3d_k3", L.ptr(x), L.ptr(dw), L.ptr(bias), b, cin, c, r, L.ptr(y), L.ptr(p), st)
+        L.call("gldm_conv3d_k3_cl", L.ptr(x), L.ptr(dw), L.ptr(bias), b, cin, c, r, L.ptr(ycl), L.ptr(pcl), st)
+    assert torch.equal(ycl.permute(0, 2, 1), y) and torch.equal(pcl, p)
+    coef = torch.empty(b, c, 2, device="cuda")
+    L.call("gldm_groupnorm_coef", L.ptr(p), L.ptr(gamma), L.ptr(beta), b, c, r, 8, 1e-5, L.ptr(coef), st)
+    cs = torch.empty(b, c, device="cuda")
+    L.call("gldm_gn_swish_chan_sum", L.ptr(y), L.ptr(coef), b, c, r, L.ptr(cs), st)
+    parts = int(L.lib().gldm_squeeze_parts())
+    csp = torch.empty(b, parts, c, device="cuda")
+    L.call("gldm_gn_swish_chan_sum_cl", L.ptr(ycl), L.ptr(coef), b, c, r, L.ptr(csp), st)
+    assert _err(csp.sum(1), cs.cpu()) < 2e-5 * max(1.0, cs.abs().max().item())
+    coords = (torch.rand(b, 3, n, generator=g) * (r - 1)).cuda()
+    coords[:, :, 0] = r - 1
+    coords[:, :, 1] = 0
+    gate, add = torch.rand(b, c, generator=g).cuda(), torch.randn(b, c, n, generator=g).cuda()
+    o1, o2 = torch.empty(b, c, n, device="cuda"), torch.empty(b, c, n, device="cuda")
+    L.call("gldm_devoxelize_gn_fused", L.ptr(coords), L.ptr(y), L.ptr(coef), L.ptr(gate), L.ptr(add), b, c, n, r, L.ptr(o1), st)
+    L.call("gldm_devoxelize_gn_cl_fused", L.ptr(coords), L.ptr(ycl), L.ptr(coef), L.ptr(gate), L.ptr(add), b, c, n, r, L.ptr(o2), st)
+    assert _err(o2, o1.cpu()) < 1e-5 * max(1.0, o1.abs().max().item())
+
+
 def test_ppc_config_z16_latent_against_oracle():
     """Second shipped experiment (configs/generation/partial_pc/ppc_1a_...z16_pc256: grasp latent 16,
     pc latent [3,256], denoiser dim 16 -> the L=16 time-conditioned engine): end-to-end LDM
