@@ -88,6 +88,11 @@ def lib():
         raise GldmError(
             f"{LIB_PATH} is missing: the gfx950 HIP library is required (no fallback path). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C graspldm_amd/csrc`.")
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.7, and whichever copy is mapped first
+    # serves both.  Loaded in front of torch, this library would bring /opt/rocm's copy in, and launches then fail once torch
+    # initialises the device on it (seen as GLDM_ERR_LAUNCH from the first kernel of `python __graft_entry__.py smoke`).
+    # The package plumbs torch tensors and streams anyway: import it first.
+    import torch  # noqa: F401
     try:
         h = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
