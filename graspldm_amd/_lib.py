@@ -19,6 +19,7 @@ class GldmError(RuntimeError):
 
 _lib = None
 
+_ll = ctypes.c_longlong
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
 _SIGNATURES = {
@@ -60,6 +61,7 @@ _SIGNATURES = {
     "gldm_pointwise_any": [_vp, _vp, _vp, _i, _i, _i, ctypes.c_longlong, _i, _vp, _vp],
     "gldm_linear_rows": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp_bf16x3": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "gldm_pointwise_mlp_bf16x3_add": [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp2_bf16x3": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_sa_mlp_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "gldm_sa_mlp_forward_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

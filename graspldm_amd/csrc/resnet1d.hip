@@ -3565,6 +3565,10 @@ struct PwArgs {
   int cin0;
   int dyn_first;   // split-bf16 kernel: units (pairs of m-tiles) >= dyn_first are handed out at run time
   int ticket_off;  // ... from a ticket at this float index of the LDS plan
+  // split-bf16 kernel, ADD instantiation: an addend in front of the activation, add[cloud * add_bs + row * add_rs + col * add_cs]
+  // (a per-cloud bias: bs = cout, rs = 1, cs = 0; a [b, cout, n] tensor: bs = cout * n, rs = n, cs = 1)
+  const float *add;
+  long long add_bs, add_rs, add_cs;
 };
 
 __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
@@ -3765,6 +3769,7 @@ __device__ long long g_pw_stamp[64];
 #else
 #define GLDM_PW_STAMP(i) do {} while (0)
 #endif
+template <bool ADD>
 __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a) {
   constexpr int NC = 32;
   extern __shared__ float lds[];
@@ -3892,7 +3897,10 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = acc[mi][ni][r] + bv[mi][r];
+            float v = acc[mi][ni][r] + bv[mi][r];
+            if constexpr (ADD)
+              v += a.add[(long long)b * a.add_bs + (long long)(16 * (mt0 + mi) + 4 * kq + r) * a.add_rs +
+                         (long long)(c0 + 16 * ni + col) * a.add_cs];
             acc[mi][ni][r] = a.relu ? fmaxf(v, 0.f) : v;
           }
         if (a.y) {
@@ -4551,13 +4559,16 @@ GLDM_API int gldm_pose_epilogue(const float *tmrp, const float *logit, const flo
 namespace {
 int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0, const float *w, const float *bias, int b,
                      int cin, int cout, int n, int relu, const float *head_w, const float *head_b, int hout, float *y,
-                     float *z, hipStream_t stream, bool split_bf16 = false) {
+                     float *z, hipStream_t stream, bool split_bf16 = false, const float *add = nullptr, long long add_bs = 0,
+                     long long add_rs = 0, long long add_cs = 0) {
+  if (add && !split_bf16) return GLDM_ERR_UNSUPPORTED;
   if (!x || !w || !bias || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
   if (!y && !head_w) return GLDM_ERR_INVALID_ARG;
   if (head_w && (!z || hout <= 0 || hout > 16)) return GLDM_ERR_INVALID_ARG;
   // k-blocks in pairs, 32-point tiles; output rows: 2 m-tiles x 8 waves per round on the f32 kernel, units of two m-tiles on
   // the split one (fewer than eight units -- 64 .. 224 output rows -- leave waves without a unit idle)
   if ((cin & 31) || (n & 31) || (split_bf16 ? (cout & 31) : (cout & 255))) return GLDM_ERR_UNSUPPORTED;
+  if ((w0 || head_w) && (cout & 255)) return GLDM_ERR_UNSUPPORTED;   // front layer / head: whole rounds of units only
   if (w0 && (!b0 || cin0 <= 0 || (cin0 & 31) || (cin & 255))) return GLDM_ERR_UNSUPPORTED;
   size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
   if (split_bf16) {  // `w` and `w0` hold split-bf16 fragments: planes of the tile + the front layer's f32 tile
@@ -4588,19 +4599,23 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   if (lds_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
   struct PwTag { int site; };
   struct PwBfTag { int site; };
-  if (split_bf16) gldm_dev::allow_dynamic_lds<PwBfTag>(reinterpret_cast<const void *>(&pointwise_mlp_bf_kernel), 160 * 1024);
+  struct PwBfAddTag { int site; };
+  if (split_bf16 && add) gldm_dev::allow_dynamic_lds<PwBfAddTag>(reinterpret_cast<const void *>(&pointwise_mlp_bf_kernel<true>), 160 * 1024);
+  else if (split_bf16) gldm_dev::allow_dynamic_lds<PwBfTag>(reinterpret_cast<const void *>(&pointwise_mlp_bf_kernel<false>), 160 * 1024);
   else gldm_dev::allow_dynamic_lds<PwTag>(reinterpret_cast<const void *>(&pointwise_mlp_kernel), 160 * 1024);
   PwArgs a{};
   a.x = x; a.w = w; a.bias = bias; a.head_w = head_w; a.head_b = head_b; a.y = y; a.z = z;
   a.cin = cin; a.cout = cout; a.n = n; a.relu = relu; a.hout = hout;
   a.w0 = w0; a.bias0 = b0; a.cin0 = cin0;
   a.dyn_first = dyn_first; a.ticket_off = ticket_off;
+  a.add = add; a.add_bs = add_bs; a.add_rs = add_rs; a.add_cs = add_cs;
   a.tiles_per_cloud = n / 32;
   a.total_tiles = b * a.tiles_per_cloud;
   const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
   int grid = cu_count() * per_cu;
   if (grid > a.total_tiles) grid = a.total_tiles;
-  if (split_bf16) hipLaunchKernelGGL(pointwise_mlp_bf_kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
+  if (split_bf16 && add) hipLaunchKernelGGL(pointwise_mlp_bf_kernel<true>, dim3(grid), dim3(512), lds_bytes, stream, a);
+  else if (split_bf16) hipLaunchKernelGGL(pointwise_mlp_bf_kernel<false>, dim3(grid), dim3(512), lds_bytes, stream, a);
   else hipLaunchKernelGGL(pointwise_mlp_kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
 #ifdef GLDM_DEBUG_KNOBS
   if (split_bf16 && getenv("GLDM_PW_STAMP")) {   // diagnostic builds: phase clocks of one steady-state tile (waves 0 and 7)
@@ -4640,6 +4655,14 @@ GLDM_API int gldm_pointwise_mlp_bf16x3(const float *x, const float *w_split, con
                                        float *y, float *z, gldm_stream_t stream) {
   return launch_pointwise(x, nullptr, nullptr, 0, w_split, bias, b, cin, cout, n, relu, head_w_packed, head_bias, hout,
                           y, z, reinterpret_cast<hipStream_t>(stream), true);
+}
+
+GLDM_API int gldm_pointwise_mlp_bf16x3_add(const float *x, const float *w_split, const float *bias, const float *add,
+                                           long long add_cloud_stride, long long add_row_stride, long long add_col_stride, int b,
+                                           int cin, int cout, int n, int relu, float *y, gldm_stream_t stream) {
+  if (!add) return GLDM_ERR_INVALID_ARG;
+  return launch_pointwise(x, nullptr, nullptr, 0, w_split, bias, b, cin, cout, n, relu, nullptr, nullptr, 0, y, nullptr,
+                          reinterpret_cast<hipStream_t>(stream), true, add, add_cloud_stride, add_row_stride, add_col_stride);
 }
 
 GLDM_API int gldm_pointwise_mlp2_bf16x3(const float *x, const float *w0_packed, const float *bias0, int cin0,

@@ -156,6 +156,57 @@ def pointwise_conv_bn_relu(x, conv, bn):
     return _gemm_bias_act(x, w, b, True)
 
 
+def concat_conv_bn_relu(xa, xb, conv, bn):
+    """relu(BN_eval(conv(cat([xa, xb], dim=1)))) of a k = 1 conv WITHOUT building the concatenation:
+    W [xa; xb] = Wa xa + Wb xb.  The wide part runs as the split-bf16 launch with the other part as its addend
+    (gldm_pointwise_mlp_bf16x3_add).  Two shapes of the PointNet++-style backbones (pointnet.py:11-46, 117-135):
+      * xa [B, Ca, N] wide (Ca % 128 == 0), xb [B, Cb, N] a few rows (Cb in SMALL_CIN: coordinates / raw features):
+        addend = Wb xb + b from the lane-per-point kernel, a [B, Cout, N] tensor;
+      * xa [B, Ca, 1] ONE centre's features that nearest-neighbour interpolation would broadcast to every point,
+        xb [B, Cb, N] wide (Cb % 128 == 0): addend = Wa xa, a per-cloud bias [B, Cout].
+    Returns None when neither applies (the caller concatenates and takes the plain path)."""
+    from . import _lib as L
+    if not (xa.is_cuda and xb.is_cuda and xa.ndim == 3 and xb.ndim == 3 and xa.dtype == torch.float32 and xb.dtype == torch.float32):
+        return None
+    bsz, ca, na = xa.shape
+    cb, n = xb.shape[1], xb.shape[2]
+    cout = conv.weight.shape[0]
+    if conv.weight.shape[1] != ca + cb or cout % 32 or cout < 64 or n % 32:
+        return None
+    broadcast = na == 1 and n > 1
+    if not broadcast and na != n:
+        return None
+    wide_c = cb if broadcast else ca
+    if not split_supported(wide_c) or (not broadcast and cb not in SMALL_CIN):
+        return None
+    from ._cache import params_key, publish
+    src = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv.bias] if conv.bias is not None else [])
+    key = (params_key(src, xa.device), ca, broadcast)
+    hit = conv.__dict__.get("_gldm_concat")
+    if hit is None or hit[0] != key:
+        from .r1d_pack import mfma_a_fragments_bf16x3
+        w, b = folded_conv_bn(conv, bn, xa.device)[:2]
+        wa, wb = w[:, :ca].contiguous(), w[:, ca:].contiguous()
+        wide = wb if broadcast else wa
+        hit = (key, mfma_a_fragments_bf16x3(wide.detach().float().cpu()).to(xa.device), wa if broadcast else wb, b,
+               torch.zeros_like(b))
+        conv.__dict__["_gldm_concat"] = hit
+        publish(xa.device)
+    _, w3, w_other, b, zero_b = hit
+    y = torch.empty((bsz, cout, n), dtype=torch.float32, device=xa.device)
+    if broadcast:
+        # Wa xa for every cloud at once: [1, Ca, B] columns = clouds
+        g = _gemm_bias_act(xa[:, :, 0].t().contiguous().unsqueeze(0), w_other, None, False)[0].t().contiguous()   # [B, Cout]
+        xw, add, strides, bias = xb.contiguous(), g, (cout, 1, 0), b
+    else:
+        add = _gemm_bias_act(xb.contiguous(), w_other, b, False)                                                   # [B, Cout, N]
+        xw, strides, bias = xa.contiguous(), (cout * n, n, 1), zero_b
+    with torch.cuda.device(xa.device):
+        L.call("gldm_pointwise_mlp_bf16x3_add", L.ptr(xw), L.ptr(w3), L.ptr(bias), L.ptr(add), *strides, bsz, wide_c, cout, n, 1,
+               L.ptr(y), L.current_stream(xa.device))
+    return y
+
+
 def linear(x, lin):
     """nn.Linear over the last axis of [..., n] (the encoder's out_layer[1] over the POINT axis): hand-written row
     kernel (gldm_linear_rows); n % 4 == 0 and n <= 16384, else the library GEMM."""

@@ -113,6 +113,20 @@ class SharedMLP(nn.Module):
         return self._run(inputs)
 
 
+def _first_layer_of_concat(shared_mlp, parts, training):
+    """First layer of a SharedMLP(dim=1) over cat(parts, dim=1) without the concatenation (dense.concat_conv_bn_relu), or
+    None when the shapes do not fit its two forms."""
+    if training or len(shared_mlp.layers) < 3 or not isinstance(shared_mlp.layers[0], nn.Conv1d):
+        return None
+    return dense.concat_conv_bn_relu(parts[0].float(), parts[1].float(), shared_mlp.layers[0], shared_mlp.layers[1])
+
+
+def _rest_of(shared_mlp, x):
+    for i in range(3, len(shared_mlp.layers), 3):
+        x = dense.pointwise_conv_bn_relu(x, shared_mlp.layers[i], shared_mlp.layers[i + 1])
+    return x
+
+
 class BallQuery(nn.Module):
     """ball_query.py:9-34"""
 
@@ -156,11 +170,21 @@ class PointNetAModule(nn.Module):
 
     def forward(self, inputs):
         features, coords = inputs
+        parts = (features, coords) if self.include_coordinates else None
         if self.include_coordinates:
-            features = torch.cat([features, coords], dim=1)
-        coords = torch.zeros((coords.size(0), 3, 1), device=coords.device)
-        outs = [mlp(features).max(dim=-1, keepdim=True).values for mlp in self.mlps]
-        return (torch.cat(outs, dim=1) if len(outs) > 1 else outs[0]), coords
+            features = None   # concatenated below only by the branches that need the tensor
+        new_coords = torch.zeros((coords.size(0), 3, 1), device=coords.device)
+        outs = []
+        for mlp in self.mlps:
+            x = _first_layer_of_concat(mlp, parts, self.training) if parts is not None else None
+            if x is None:
+                if features is None:
+                    features = torch.cat(parts, dim=1)
+                x = mlp(features)
+            else:
+                x = _rest_of(mlp, x)
+            outs.append(x.max(dim=-1, keepdim=True).values)
+        return (torch.cat(outs, dim=1) if len(outs) > 1 else outs[0]), new_coords
 
 
 class PointNetSAModule(nn.Module):
@@ -231,8 +255,17 @@ class PointNetFPModule(nn.Module):
             points_features = None
         else:
             points_coords, centers_coords, centers_features, points_features = inputs
+        if points_features is not None and centers_coords.shape[2] == 1:
+            # ONE centre: its feature vector is what every point would interpolate to -- no interpolation, no concatenation:
+            # the first layer takes it as a per-cloud bias (dense.concat_conv_bn_relu)
+            x = _first_layer_of_concat(self.mlp, (centers_features, points_features), self.training)
+            if x is not None:
+                return _rest_of(self.mlp, x), points_coords
         interp = nearest_neighbor_interpolate(points_coords, centers_coords, centers_features)
         if points_features is not None:
+            x = _first_layer_of_concat(self.mlp, (interp, points_features), self.training)
+            if x is not None:
+                return _rest_of(self.mlp, x), points_coords
             interp = torch.cat([interp, points_features], dim=1)
         return self.mlp(interp), points_coords
 

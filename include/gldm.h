@@ -343,11 +343,22 @@ int gldm_linear_rows(const float *x /*[rows,n]*/, const float *w /*[nout,n]*/, c
  * product and f32 accumulation (error of the order of one f32 rounding per product, 6/16 of the f32-MFMA time).  The
  * input tile is split once while it is staged.  Since ABI 6 the front layer's weights `w0_split` are split-bf16 fragments
  * too (cin0 % 32 == 0, cin0 <= 96; its f32 input tile is split once per wave into registers); `head_w_packed` stays f32
- * fragments.  cin % 128 == 0, cout % 256 == 0, n % 32 == 0, 4 (48 cin + 32 cin0) + 16 <= 160 KiB. */
+ * fragments.  cin % 128 == 0, cout % 32 == 0 (with a front layer or a head: % 256; fewer than 256 output rows leave waves
+ * idle), n % 32 == 0, 4 (48 cin + 32 cin0) + 16 <= 160 KiB. */
 int gldm_pointwise_mlp_bf16x3(const float *x /*[b,cin,n]*/, const float *w_split, const float *bias /*[cout]*/,
                               int b, int cin, int cout, int n, int relu,
                               const float *head_w_packed, const float *head_bias, int hout,
                               float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
+
+/* The same launch with an addend in front of the activation: y = act(W x + bias + add), add[cloud * add_cloud_stride +
+ * row * add_row_stride + col * add_col_stride] -- a per-cloud bias (strides cout, 1, 0) or a [b, cout, n] tensor
+ * (cout * n, n, 1).  It serves layers whose input is a concatenation (pointnet.py:117-135 PointNetFPModule, :11-46
+ * PointNetAModule): W [x1; x2] = W1 x1 + W2 x2, the wide part here, the other part (three coordinate rows, or one centre's
+ * feature vector broadcast to every point) as the addend, and the concatenated tensor is never built. */
+int gldm_pointwise_mlp_bf16x3_add(const float *x /*[b,cin,n]*/, const float *w_split, const float *bias /*[cout]*/,
+                                  const float *add, long long add_cloud_stride, long long add_row_stride,
+                                  long long add_col_stride, int b, int cin, int cout, int n, int relu,
+                                  float *y /*[b,cout,n]*/, gldm_stream_t stream);
 int gldm_pointwise_mlp2_bf16x3(const float *x /*[b,cin0,n]*/, const float *w0_split, const float *bias0, int cin0,
                                const float *w_split, const float *bias /*[cout]*/, int b, int cin, int cout, int n,
                                const float *head_w_packed, const float *head_bias, int hout,

@@ -583,6 +583,37 @@ def test_pointwise_mlp_split_bf16(b, cin0, cin, cout, n, hout):
             assert torch.equal(z2, z)
 
 
+@pytest.mark.parametrize("b,ca,na,cb,n,cout", [(3, 128, 1024, 3, 1024, 128), (2, 256, 128, 3, 128, 256), (4, 1024, 1, 256, 128, 256),
+                                               (2, 128, 64, 6, 64, 64)])
+def test_first_layer_of_a_concatenation_without_the_concatenation(b, ca, na, cb, n, cout):
+    """dense.concat_conv_bn_relu: relu(BN(conv(cat([xa, xb])))) as the split-bf16 launch over the wide part with the other
+    part as its addend (gldm_pointwise_mlp_bf16x3_add) -- a few coordinate rows as a [B, Cout, N] tensor, or ONE centre's
+    feature vector as a per-cloud bias (what nearest-neighbour interpolation from a single centre broadcasts) -- against
+    torch on the CPU in f64 (2e-5 of the output scale)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.nn as nn
+    from graspldm_amd import dense
+    g = torch.Generator().manual_seed(ca + cb + cout)
+    conv, bn = nn.Conv1d(ca + cb, cout, 1), nn.BatchNorm1d(cout)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(cout, ca + cb, 1, generator=g) / (ca + cb) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        bn.weight.copy_(1 + 0.1 * torch.randn(cout, generator=g)); bn.bias.copy_(0.1 * torch.randn(cout, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(cout, generator=g)); bn.running_var.copy_(1 + 0.2 * torch.rand(cout, generator=g))
+    conv.eval(); bn.eval()
+    xa, xb = torch.randn(b, ca, na, generator=g), torch.randn(b, cb, n, generator=g)
+    cat = torch.cat([xa.expand(b, ca, n) if na == 1 else xa, xb], dim=1).double()
+    ref = bn.double()(conv.double()(cat)).relu().float()
+    conv.float(); bn.float()
+    conv, bn = conv.cuda(), bn.cuda()
+    y = dense.concat_conv_bn_relu(xa.cuda(), xb.cuda(), conv, bn)
+    assert y is not None
+    assert _err(y, ref) < 2e-5 * max(1.0, ref.abs().max().item()), _err(y, ref)
+    # shapes outside the two forms are declined (the caller concatenates)
+    assert dense.concat_conv_bn_relu(xa.cuda()[:, :, : max(1, na // 2)], xb.cuda(), conv, bn) is None or na == 1
+
+
 def test_pointwise_mlp_rejects_unsupported_shapes():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
