@@ -1085,7 +1085,23 @@ __global__ __launch_bounds__(256) void pointwise_small_kernel(const float *__res
 #pragma unroll
   for (int ci = 0; ci < CIN; ++ci) v[ci] = xb[(size_t)ci * n];
   float *yb = y + (size_t)b * cout * n + i;
-  for (int co = 0; co < cout; ++co) {
+  // eight output channels at a time: eight independent fma chains per lane (one chain per pass left the vector pipe waiting
+  // on its own result: 0.106 ms for 48 -> 96 over 256 x 1024 points, three times its instruction count)
+  constexpr int kCh = 8;
+  int co = 0;
+  for (; co + kCh <= cout; co += kCh) {
+    const float *wr = w + (size_t)co * CIN;
+    float acc[kCh];
+#pragma unroll
+    for (int k = 0; k < kCh; ++k) acc[k] = bias ? bias[co + k] : 0.f;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int k = 0; k < kCh; ++k) acc[k] = fmaf(wr[k * CIN + ci], v[ci], acc[k]);
+#pragma unroll
+    for (int k = 0; k < kCh; ++k) yb[(size_t)(co + k) * n] = relu ? fmaxf(acc[k], 0.f) : acc[k];
+  }
+  for (; co < cout; ++co) {
     const float *wr = w + (size_t)co * CIN;
     float acc = bias ? bias[co] : 0.f;
 #pragma unroll
