@@ -72,6 +72,25 @@ ENCODER_FLOP_PER_CLOUD = 8.115e9            # the reference graph (shipped fpc c
 ENCODER_FLOP_EXECUTED_PER_CLOUD = 8.115e9 - 2 * 768 * 1536 * 1024 - 2 * 3 * 768 * 1024 + 2 * 3 * 1536 * 1024
 
 
+def usable_cores():
+    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup's CPU-time quota (cpu.max /
+    cfs_quota), not os.cpu_count() -- a container on a 256-core host is usually granted far fewer."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p_))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -525,29 +544,54 @@ def main():
         # ---- CPU baseline: the torch-CPU oracle on this box's host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.scheduler == "ddim" and not ppc:
-            # separate CPU-only processes on a bounded sample (128 clouds x G grasps, full S steps): once with 16 threads
-            # (the oracle's ~110 small ops per step do not scale past a few cores: the figure of the earlier rounds) and once
-            # with every host core, so that the baseline is not a function of a thread cap; `value` is the better of the two
+            # separate CPU-only processes on a bounded sample (full S steps): once ONE process with 16 threads on 128 clouds
+            # (the oracle's ~110 small ops per step do not scale past a few cores: the figure of the earlier rounds) and, where
+            # this process may use more CPUs than that, once with ALL of them as cores / 16 such processes side by side, 32
+            # clouds each (clouds sharded over processes, the way a CPU deployment would use them); `value` is the better.
+            # "May use": the GPU boxes report 256 host cores, but their cgroup grants this job 16 CPUs of time (cpu.max
+            # 1600000 100000) -- hundreds of threads on that quota is why the all-threads runs of earlier builds never finished
             import subprocess
-            ncores = os.cpu_count() or 1
+            ncores = usable_cores()
             runs = []
-            for threads in sorted({min(ncores, 16), ncores}):
-                # the all-cores run takes a quarter of the sample: with hundreds of threads the oracle's small ops are slower, not faster
-                clouds = CPU_BASELINE_CLOUDS if threads <= 16 else max(CPU_BASELINE_CLOUDS // 4, 1)
-                cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--clouds", str(clouds), "--grasps", str(G), "--points", str(N),
-                       "--ddim-steps", str(S), "--threads", str(threads)]
-                try:
-                    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=120)
-                    rec = json.loads(r.stdout.strip().splitlines()[-1])
-                    runs.append(dict(threads=rec["threads"], clouds=clouds, value=rec["grasps"] / rec["seconds"], seconds=rec["seconds"]))
-                except Exception as e:  # noqa: BLE001
-                    runs.append(dict(threads=threads, value=None, error=f"{e!r}"[:160]))
+
+            def oracle_cmd(clouds, threads):
+                return [sys.executable, "-m", "oracle.cpu_baseline", "--clouds", str(clouds), "--grasps", str(G), "--points", str(N),
+                        "--ddim-steps", str(S), "--threads", str(threads)]
+            t16 = min(ncores, 16)
+            try:
+                r = subprocess.run(oracle_cmd(CPU_BASELINE_CLOUDS, t16), cwd=ROOT, capture_output=True, text=True, timeout=120)
+                rec = json.loads(r.stdout.strip().splitlines()[-1])
+                runs.append(dict(threads=rec["threads"], processes=1, clouds=CPU_BASELINE_CLOUDS, value=rec["grasps"] / rec["seconds"],
+                                 seconds=rec["seconds"]))
+            except Exception as e:  # noqa: BLE001
+                runs.append(dict(threads=t16, processes=1, value=None, error=f"{e!r}"[:160]))
+            nproc = ncores // 16
+            if nproc >= 2:
+                per = max(CPU_BASELINE_CLOUDS // 4, 1)
+                procs = [subprocess.Popen(oracle_cmd(per, 16), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                         for _ in range(nproc)]
+                recs, deadline = [], time.time() + 120
+                for pr in procs:
+                    try:
+                        out_s, _ = pr.communicate(timeout=max(1.0, deadline - time.time()))
+                        recs.append(json.loads(out_s.strip().splitlines()[-1]))
+                    except Exception:  # noqa: BLE001
+                        pr.kill()
+                if len(recs) == nproc:
+                    secs = max(r_["seconds"] for r_ in recs)
+                    runs.append(dict(threads=16 * nproc, processes=nproc, clouds=per * nproc,
+                                     value=sum(r_["grasps"] for r_ in recs) / secs, seconds=secs))
+                else:
+                    runs.append(dict(threads=16 * nproc, processes=nproc, value=None, error=f"{nproc - len(recs)} of {nproc} processes without a result within 120 s"))
             good = [r for r in runs if r.get("value")]
             best = max(good, key=lambda r: r["value"]) if good else None
             cpu = dict(value=best["value"] if best else None, unit="grasps/s", cores=best["threads"] if best else runs[0]["threads"], kind="port",
                        sample=f"{CPU_BASELINE_CLOUDS} clouds x {G} grasps, N={N}, {S} DDIM steps, torch-CPU oracle "
-                              f"(oracle/torch_ref.py + oracle/point_ops.c) on a box with {ncores} host cores; runs: "
-                              + "; ".join(f"{r['threads']} threads: " + (f"{r['value']:.1f} grasps/s ({r['clouds']} clouds in {r['seconds']:.1f} s)" if r.get("value") else "no result within 120 s") for r in runs),
+                              f"(oracle/torch_ref.py + oracle/point_ops.c); this job may use {ncores} of the host's {os.cpu_count()} cores "
+                              f"(affinity mask and cgroup CPU quota); runs: "
+                              + "; ".join(f"{r['processes']} x {r['threads'] // r['processes']} threads: "
+                                          + (f"{r['value']:.1f} grasps/s ({r['clouds']} clouds in {r['seconds']:.1f} s)" if r.get("value") else "no result within 120 s")
+                                          for r in runs),
                        runs=runs)
         out = dict(metric="grasps/sec whole-node (%d-pt cloud, %d %s steps)" % (N, S, args.scheduler.upper()), value=grasps_per_s,
                    unit="grasps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,

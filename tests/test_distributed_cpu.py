@@ -178,3 +178,5 @@ def test_bench_workload_label_follows_arguments():
     assert "ppc_1a" in b.workload_label(256, 20, 1024, 1000, "ddpm", "ppc") and "not a BASELINE.json configuration" in b.workload_label(256, 20, 1024, 1000, "ddpm", "ppc")
     assert b.denoiser_executed_mfma_flop_fpc() == 6193152 and 0.7 < b.denoiser_executed_mfma_flop_fpc() / b.DENOISER_FLOP_PER_LATENT_STEP < 0.9
     assert 0.9 < b.denoiser_executed_mfma_flop_l16() / b.DENOISER_FLOP_PER_LATENT_STEP_PPC < 1.3
+    # the CPU leg sizes itself by the CPUs the job may use (affinity mask, cgroup quota), never more than the host reports
+    assert 1 <= b.usable_cores() <= (os.cpu_count() or 1)
