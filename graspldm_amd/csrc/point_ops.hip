@@ -904,7 +904,7 @@ GLDM_API int gldm_avg_voxelize_forward(const float *features, const int32_t *vox
       const size_t both = row_bytes + (size_t)n * sizeof(float);
       int stage_feat = both <= room ? 1 : 0;
       int g_rows = (int)(room / (stage_feat ? both : row_bytes));
-      if (g_rows > 8) g_rows = 8;
+      if (g_rows > 16) g_rows = 16;
       if (g_rows > c) g_rows = c;
       if (stage_feat && n % 4 == 0 && (size_t)g_rows * n <= (size_t)4 * 4 * kVoxBlock) stage_feat = 2;   // register prefetch form
       // A block sorts its cloud's keys once and then walks `chunk` channels in rounds of g_rows: a cloud is split over
