@@ -264,6 +264,11 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}",
               file=sys.stderr)
+    # Host threads: the ranks of a node share the CPUs this job may use (16 on the GPU boxes, whatever the host reports);
+    # torch's default of one intra-op thread per reported core (256) turns every host-side tensor op of the set-up into
+    # an oversubscribed parallel region -- per rank
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    torch.set_num_threads(max(1, min(16, usable_cores() // max(1, local_world))))
     if args.dry_run:
         return dry_run(args, world, rank)
     if not torch.cuda.is_available():
