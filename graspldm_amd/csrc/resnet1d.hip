@@ -97,31 +97,31 @@ static_assert(Geo<32>::kLdsFloats * 4 * 2 <= 160 * 1024, "LDS budget (2 WG/CU)")
 template <int NC>
 __device__ __forceinline__ int swz(int row, int col) { return row * NC + (col ^ ((row & 1) << 4)); }
 
-// Position-major engine (64 columns, split-bf16 GEMMs): a B fragment of v_mfma_f32_16x16x32_bf16 is rows 8 g + j
+// Position-major engine (64 columns, split-f16 GEMMs): a B fragment of v_mfma_f32_16x16x32_f16 is rows 8 g + j
 // (g = lane >> 4, j = 0..7) of one column per lane, so the four lane groups of a read sit 8 rows apart in the same
 // columns.  XOR-ing the column's position tile with bits 3-4 of the row sends them to four different 16-bank groups:
 // every B read is conflict free, with ONE lane base per tile (the XOR does not depend on j or on the 32-row block).
 __device__ __forceinline__ int pswz(int row, int col) { return row * 64 + (col ^ (((row >> 3) & 3) << 4)); }
 
-// Pre-split activation planes of the position-major engine (levels of up to 128 channels).  A tensor that is only ever
-// read as a GEMM B operand is kept in LDS already split into its three bf16 planes, in B-fragment order:
-//   [32-channel block kb][plane hi|mid|lo][g = 0..3][column 0..63][8 bf16 = channels 32 kb + 8 g + 0..7]
-// (12 KiB per 32 channels).  The producer's epilogue splits each element ONCE (its accumulators hold 4 consecutive
+// Split operands (see "split-f16 GEMM core" below): every f32 value travels as kSplit = 2 f16 numbers, hi + lo.
+constexpr int kSplit = 2;
+constexpr int kFragBytes = kSplit * 1024;        // one weight fragment: [plane][lane 64][8 f16]
+constexpr int kFragFloats = kFragBytes / 4;
+
+// Pre-split activation planes of the 64-column engines.  A tensor that is only ever read as a GEMM B operand is kept
+// in LDS already split into its two f16 planes, in B-fragment order:
+//   [32-channel block kb][plane hi|lo][g = 0..3][column 0..63][8 f16 = channels 32 kb + 8 g + 0..7]
+// (8 KiB per 32 channels).  The producer's epilogue splits each element ONCE (its accumulators hold 4 consecutive
 // channels of a column: one ds_write_b64 per plane); the eight consumer waves read a whole fragment plane with one
-// ds_read_b128 per lane instead of eight ds_read_b32 + 36 VALU instructions of splitting each, and their k-loops are
-// loads + MFMA only.  At 256 channels the planes (96 KiB per tensor) do not fit beside the f32 residual stream: those
-// convs split their B values on the fly (two m-tiles per wave share every split there).
-constexpr int kPlaneH = 128 * 64;                 // H planes: floats [8192, 20480)  (the q|k|v block of the attention
-constexpr int kPlaneX = 128 * 64 + 128 * 96;      // X planes: floats [20480, 32768)  phases overlays both)
+// ds_read_b128 per lane and their k-loops are loads + MFMA only.
+constexpr int kPlaneH = 128 * 64;                 // H planes: floats [8192, 16384): 4 blocks of 32 channels
+constexpr int kPlaneX = kPlaneH + 4 * kSplit * 1024;   // X planes: floats [16384, 24576)
 constexpr int kPlaneMaxC = 128;
-// The 256-channel level (only ever the last one: a down conv into it and one ResnetBlock) keeps ONE tensor in LDS, as planes
-// over both regions (kPlaneW = kPlaneH: 8 blocks x 12 KiB = floats [8192, 32768)): the down conv writes the planes of the new
-// residual stream X there and parks X itself (f32) in global scratch (Ctx::park: every lane stores and later re-loads its own
-// accumulator values, 8 x 16 B, coalesced); conv1 reads the planes and, behind its GroupNorm exchange barrier (every wave
-// is past its k-loop), overwrites them with the planes of H; conv2 reads those and forms X = parked + act(GN(conv)) as f32
-// rows for the final 1x1.  Both convs then run on loads + MFMA only; with X and H as f32 rows (64 KiB each, no room for
-// planes) every wave re-read and re-split all 256 x 64 values per conv: 44 k cycles of k-loop for 30.7 k of MFMAs.
-constexpr int kPlaneW = kPlaneH;
+// The 256-channel level (only ever the last one: a down conv into it and one ResnetBlock) keeps ONE tensor in LDS as
+// planes (8 blocks x 8 KiB = 64 KiB, floats [16384, 32768): behind the level's f32 residual stream X, rows 0..255 =
+// floats [0, 16384)): the down conv writes the planes of the new residual stream X there (and X itself as f32 rows);
+// conv1 reads the planes and, behind its GroupNorm exchange barrier (every wave is past its k-loop), overwrites them with
+// the planes of H; conv2 reads those and adds act(GN(conv)) to the f32 rows for the final 1x1.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 typedef __attribute__((address_space(3))) u32x4 lds_u4;
@@ -135,35 +135,41 @@ struct PG {
   static constexpr int kCols = LL == 16 ? 72 : 64;   // 16-byte entries per row
   static constexpr int kOff = LL == 16 ? 4 : 0;      // entry of column 0
   static constexpr int kPlaneU4 = 4 * kCols;         // entries per plane of a 32-channel block
-  static constexpr int kBlockU4 = 3 * kPlaneU4;      // per block
+  static constexpr int kBlockU4 = kSplit * kPlaneU4; // per block
   static constexpr int kBlockFloats = 4 * kBlockU4;
   static constexpr int kH = 128 * 64;                // H planes (floats), 4 blocks
   static constexpr int kX = kH + 4 * kBlockFloats;   // X planes
-  static constexpr int kW = kH;                      // the 256-channel level's one set, 8 blocks
-  static constexpr int kEnd = kH + 8 * kBlockFloats;
+  // the 256-channel level's one set, 8 blocks.  LL = 4: behind the 256 f32 rows of X; LL = 16: over both regions (its f32
+  // rows 128 .. 255 lie over the first blocks: the residual stream is parked in global scratch, Ctx::park)
+  static constexpr int kW = LL == 16 ? kH : 256 * 64;
+  static constexpr int kEnd = kW + 8 * kBlockFloats;
 };
 static_assert(PG<4>::kH == kPlaneH && PG<4>::kX == kPlaneX, "plane regions");
+static_assert(PG<4>::kEnd <= 512 * 64, "position-major planes end in front of the attention exchange slots");
 static_assert(PG<16>::kEnd <= Geo<64>::kArena, "padded planes fit the arena");
-// rows c0 .. c0 + 3 (c0 % 4 == 0) of column n -> the three planes
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+// (a, b) -> packed f16 hi parts and packed f16 lo parts: x = hi + lo up to 2^-22 |x| (f16 subnormals are kept by the
+// matrix pipe -- tools/micro/mfma_f16_split -- so small lo parts lose nothing but bits below 2^-25).
+// v_cvt_pk_f16_f32 (round to nearest even), the remainders from the packed halves by v_fma_mix_f32, v_cvt_pk_f16_f32.
+__device__ __forceinline__ void split_f16x2(float a, float b, unsigned &hi, unsigned &lo) {
+  const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+  const float ra = __builtin_fmaf((float)h[0], -1.0f, a), rb = __builtin_fmaf((float)h[1], -1.0f, b);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, f16x2));
+}
+// rows c0 .. c0 + 3 (c0 % 4 == 0) of column n -> the two planes
 template <int LL = 4>
 __device__ __forceinline__ void store_planes4(float *planes, int c0, int n, float v0, float v1, float v2, float v3) {
-  const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){v0, v1}, __attribute__((ext_vector_type(2))) __bf16));
-  const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){v2, v3}, __attribute__((ext_vector_type(2))) __bf16));
-  const float r0 = v0 - __uint_as_float(h0 << 16), r1 = v1 - __uint_as_float(h0 & 0xffff0000u);
-  const float r2 = v2 - __uint_as_float(h1 << 16), r3 = v3 - __uint_as_float(h1 & 0xffff0000u);
-  const unsigned m0 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){r0, r1}, __attribute__((ext_vector_type(2))) __bf16));
-  const unsigned m1 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){r2, r3}, __attribute__((ext_vector_type(2))) __bf16));
-  const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xffff0000u);
-  const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xffff0000u);
-  const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){s0, s1}, __attribute__((ext_vector_type(2))) __bf16));
-  const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){s2, s3}, __attribute__((ext_vector_type(2))) __bf16));
-  // dword address: (((kb * 3 + plane) * 4 + g) * kCols + kOff + n) * 4 + 2 * (half of the 8-group)
+  unsigned h0, h1, l0, l1;
+  split_f16x2(v0, v1, h0, l0);
+  split_f16x2(v2, v3, h1, l1);
+  // dword address: (((kb * kSplit + plane) * 4 + g) * kCols + kOff + n) * 4 + 2 * (half of the 8-group)
   using G = PG<LL>;
-  const int a = ((((c0 >> 5) * 3) * 4 + ((c0 >> 3) & 3)) * G::kCols + G::kOff + n) * 4 + ((c0 >> 2) & 1) * 2;
+  const int a = ((((c0 >> 5) * kSplit) * 4 + ((c0 >> 3) & 3)) * G::kCols + G::kOff + n) * 4 + ((c0 >> 2) & 1) * 2;
   lds_u2 *d = (lds_u2 *)(planes + a);
   d[0] = u32x2_t{h0, h1};
-  d[2 * G::kPlaneU4] = u32x2_t{m0, m1};    // next plane: kPlaneU4 entries of 16 bytes = 2 kPlaneU4 u2
-  d[4 * G::kPlaneU4] = u32x2_t{l0, l1};
+  d[2 * G::kPlaneU4] = u32x2_t{l0, l1};    // next plane: kPlaneU4 entries of 16 bytes = 2 kPlaneU4 u2
 }
 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
@@ -461,50 +467,41 @@ __device__ __forceinline__ void gemm_fast_tap3(const Ctx &c, const float *__rest
 }
 
 
-// ---- split-bf16 GEMM core of the position-major engine -------------------------------------------------------
-// f32 matrix products on the bf16 matrix pipe.  v_mfma_f32_16x16x32_bf16 delivers 16x the FLOP/cycle of
-// v_mfma_f32_16x16x4_f32, so an f32 product computed EXACTLY ENOUGH from bf16 pieces still wins: every f32 operand
-// is written as hi + mid + lo, three bf16 numbers (8 significant bits each cover the 24 of an f32: the split is
-// exact), and a product a b is the sum of the partial products of weight >= 2^-16,
-//   a b ~ a_hi b_lo + a_lo b_hi + a_mid b_mid + a_hi b_mid + a_mid b_hi + a_hi b_hi      (six MFMAs, f32 accumulation),
-// the dropped ones (mid lo, lo mid, lo lo) being <= 2^-23 |a b|: the size of one f32 rounding.  6/16 of the f32-MFMA
-// time.  Weights are split once on the host (r1d_pack.py: mfma_a_fragments_bf16x3, layout in gldm.h); activations
-// are split as they are read from LDS (f32 there, like everywhere in the engine): 44 VALU instructions per 8
-// values, which issue in the shadow of the MFMAs they feed (a B fragment of a k = 3 conv serves 3 taps x MT m-tiles).
-// Measured against the reference's vectors: single forwards 5e-7 from the f32 graph, 100 DDIM steps 1.2e-6
-// (tools/study/bf16x3_error.py), well inside the 2e-5 / 1e-4 parity bars.
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
+// ---- split-f16 GEMM core of the 64-column engines ------------------------------------------------------------
+// f32 matrix products on the f16 matrix pipe.  v_mfma_f32_16x16x32_f16 delivers 16x the FLOP/cycle of
+// v_mfma_f32_16x16x4_f32, so an f32 product computed EXACTLY ENOUGH from f16 pieces still wins: every f32 operand is
+// written as hi + lo, two f16 numbers (11 + 11 significant bits; the matrix pipe keeps f16 subnormals, so a small lo
+// part loses only bits below 2^-25), and a product a b is the sum of three partial products,
+//   a b ~ a_hi b_lo + a_lo b_hi + a_hi b_hi      (three MFMAs, f32 accumulation),
+// the dropped one (lo lo) being <= 2^-22 |a b|.  3/16 of the f32-MFMA time -- and half of what the three-piece bf16
+// split of rounds 3-4 took (six products) at the same measured accuracy: on a 16 x 16 x 768 product the error relative
+// to sum |a b| is 1.3e-7 (f32 fma chain: 1.3e-7; bf16 x 3: 1.5e-7), on operands spread over 15 binades 3.5e-7 (5.6e-7;
+// 3.4e-7) -- tools/micro/mfma_f16_split, profiles/r05_mfma_f16_split.txt.  Weights are split once on the host
+// (r1d_pack.py: mfma_a_fragments_f16x2, layout in gldm.h); activations are split by the producing epilogue
+// (store_planes4) or as they are read from LDS (split_planes8).  Range: |x| < 65504 (f16); the packers refuse weights
+// beyond it, activations of these nets are O(10) behind their norms.
+// Measured against the reference's vectors: single forwards 1.7e-6 from the f32 graph, 100 DDIM steps 1.8e-6
+// (tools/study/f16x2_error.py), well inside the 2e-5 / 1e-4 parity bars.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: element 0 in the low half
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-// x[0..7] (consecutive k of one column) -> the three planes of a B fragment
-__device__ __forceinline__ void split_bf16x3(const float (&x)[8], u32x4 (&pl)[3]) {
+// x[0..7] (consecutive k of one column) -> the planes of a B fragment
+__device__ __forceinline__ void split_planes8(const float (&x)[8], u32x4 (&pl)[kSplit]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float a = x[2 * q], b = x[2 * q + 1];
-    const unsigned h = cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-    const unsigned m = cvt_pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    unsigned h, l;
+    split_f16x2(x[2 * q], x[2 * q + 1], h, l);
     pl[0][q] = h;
-    pl[1][q] = m;
-    pl[2][q] = cvt_pk_bf16(sa, sb);
+    pl[1][q] = l;
   }
 }
-__device__ __forceinline__ f32x4 mfma_bf(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma_h(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 // acc += A B with both operands split: small terms first
-__device__ __forceinline__ f32x4 mfma_split6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 acc) {
-  acc = mfma_bf(a[0], b[2], acc);
-  acc = mfma_bf(a[2], b[0], acc);
-  acc = mfma_bf(a[1], b[1], acc);
-  acc = mfma_bf(a[0], b[1], acc);
-  acc = mfma_bf(a[1], b[0], acc);
-  return mfma_bf(a[0], b[0], acc);
+__device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[kSplit], const u32x4 (&b)[kSplit], f32x4 acc) {
+  acc = mfma_h(a[0], b[1], acc);
+  acc = mfma_h(a[1], b[0], acc);
+  return mfma_h(a[0], b[0], acc);
 }
 
 // Position-major k = 3 conv (see gemm_pm3 below for the tile algebra) on split-bf16 operands.  wp3: split fragments
@@ -530,7 +527,7 @@ template <int MT>
 struct PreA {
   static constexpr bool on = true;
   static constexpr int kSets = MT == 1 ? 3 : 1;
-  u32x4 a[kSets][MT][3];
+  u32x4 a[kSets][MT][kSplit];
   __device__ __forceinline__ void request(const WStream &wv, int mt0, int cin) {
     const int kb32 = cin >> 5, kblocks = 3 * kb32;
 #pragma unroll
@@ -538,7 +535,7 @@ struct PreA {
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[t][mi][pl] = wv.raw_at(((mt0 + mi) * kblocks + t * kb32) * 3072, pl * 1024);
+        for (int pl = 0; pl < kSplit; ++pl) a[t][mi][pl] = wv.raw_at(((mt0 + mi) * kblocks + t * kb32) * kFragBytes, pl * 1024);
   }
 };
 
@@ -551,29 +548,29 @@ __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restric
   const int col = c.lane & 15, g = c.lane >> 4;
   const int kb32 = cin >> 5, kblocks = 3 * kb32;
   const WStream wv(wp3, c.lane);
-  const lds_u4 *pl3 = (const lds_u4 *)planes + g * 64 + 16 * PB0 + col;   // + (kb * 3 + plane) * 256 + 16 q
+  const lds_u4 *pl3 = (const lds_u4 *)planes + g * 64 + 16 * PB0 + col;   // + (kb * kSplit + plane) * 256 + 16 q
   // A registers.  One m-tile per wave: a set per tap, refilled with the next block's fragments right after the tap's
   // MFMAs (a whole block to arrive).  Two m-tiles: 72 registers that way, so two sets alternate over the tap steps
   // instead (the next step's fragments are requested in front of the current step's MFMAs: 36-48 of them, and the
   // partner wave's, to arrive); the trip covers two blocks so that the alternation is static.
   constexpr int NA = MT == 1 ? 3 : 2;
   constexpr int NBUF = (MT == 1 && NB <= 3) ? 2 : 1;   // 4 tiles x 2 sets = 96 registers: spills
-  u32x4 a[NA][MT][3];
-  u32x4 bs[NBUF][NB][3];
+  u32x4 a[NA][MT][kSplit];
+  u32x4 bs[NBUF][NB][kSplit];
   auto load_a = [&](int buf, int t, int kb) {
     if (kExpNoA && kb > 0) return;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        a[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kblocks + t * kb32 + kb) * 3072, pl * 1024);
+      for (int pl = 0; pl < kSplit; ++pl)
+        a[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kblocks + t * kb32 + kb) * kFragBytes, pl * 1024);
   };
   auto load_b = [&](int buf, int kb) {
     if (kExpNoB && kb > 0) return;
 #pragma unroll
     for (int q = 0; q < NB; ++q)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bs[buf][q][pl] = pl3[(kb * 3 + pl) * 256 + 16 * q];
+      for (int pl = 0; pl < kSplit; ++pl) bs[buf][q][pl] = pl3[(kb * kSplit + pl) * 256 + 16 * q];
   };
   auto tap_mfmas = [&](int abuf, int bbuf, int t) {
 #pragma unroll
@@ -583,7 +580,7 @@ __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restric
         const int sp = P0 + p + t - 1;
         if (sp >= 0 && sp <= 3) {
           const int qi = sp - PB0 < 0 ? 0 : (sp - PB0 >= NB ? NB - 1 : sp - PB0);
-          acc[mi][p] = mfma_split6(a[abuf][mi], bs[bbuf][qi], acc[mi][p]);
+          acc[mi][p] = mfma_split(a[abuf][mi], bs[bbuf][qi], acc[mi][p]);
         }
       }
   };
@@ -596,7 +593,7 @@ __device__ __forceinline__ void gemm_pm3_pl(const Ctx &c, const float *__restric
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) a[t][mi][pl] = pre.a[t][mi][pl];
+          for (int pl = 0; pl < kSplit; ++pl) a[t][mi][pl] = pre.a[t][mi][pl];
       } else {
         load_a(t, t, 0);
       }
@@ -667,15 +664,15 @@ __device__ __forceinline__ void gemm_sm3_pl(const Ctx &c, const float *__restric
   const int col = c.lane & 15, g = c.lane >> 4;
   const int kb32 = (cin + 31) >> 5, kblocks = 3 * kb32;
   const WStream wv(wp3, c.lane);
-  const lds_u4 *pl3 = (const lds_u4 *)planes + g * G::kCols + 16 * T0 + col;   // + (kb * 3 + plane) * kPlaneU4 + 16 q + 4 t
+  const lds_u4 *pl3 = (const lds_u4 *)planes + g * G::kCols + 16 * T0 + col;   // + (kb * kSplit + plane) * kPlaneU4 + 16 q + 4 t
   constexpr int NA = MT == 1 ? 3 : 2;
-  u32x4 a[NA][MT][3];
+  u32x4 a[NA][MT][kSplit];
   auto load_a = [&](int buf, int t, int kb) {
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        a[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kblocks + t * kb32 + kb) * 3072, pl * 1024);
+      for (int pl = 0; pl < kSplit; ++pl)
+        a[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kblocks + t * kb32 + kb) * kFragBytes, pl * 1024);
   };
   auto first_a = [&]() {   // block 0's fragments (three tap sets, or tap 0's with two m-tiles): the caller's, or requested here
 #pragma unroll
@@ -684,7 +681,7 @@ __device__ __forceinline__ void gemm_sm3_pl(const Ctx &c, const float *__restric
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) a[t][mi][pl] = pre.a[t][mi][pl];
+          for (int pl = 0; pl < kSplit; ++pl) a[t][mi][pl] = pre.a[t][mi][pl];
       } else {
         load_a(t, t, 0);
       }
@@ -695,10 +692,10 @@ __device__ __forceinline__ void gemm_sm3_pl(const Ctx &c, const float *__restric
     // ONE rolling set of B fragments: the moment a tile's six MFMAs of a tap step have issued, its registers are refilled
     // with the same tile's planes of the NEXT tap step, which then have the other tiles' MFMAs to arrive (two full sets
     // were 96 registers at four tiles: spills inside the loop)
-    u32x4 bs[NT][3];
+    u32x4 bs[NT][kSplit];
     auto load_b1 = [&](int q, int kb, int t) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bs[q][pl] = pl3[(kb * 3 + pl) * G::kPlaneU4 + 16 * q + 4 * t];
+      for (int pl = 0; pl < kSplit; ++pl) bs[q][pl] = pl3[(kb * kSplit + pl) * G::kPlaneU4 + 16 * q + 4 * t];
     };
 #pragma unroll
     for (int q = 0; q < NT; ++q) load_b1(q, 0, 0);
@@ -710,7 +707,7 @@ __device__ __forceinline__ void gemm_sm3_pl(const Ctx &c, const float *__restric
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
         __builtin_amdgcn_sched_barrier(0);
-        acc[0][q] = mfma_split6(a[t][0], bs[q], acc[0][q]);
+        acc[0][q] = mfma_split(a[t][0], bs[q], acc[0][q]);
         __builtin_amdgcn_sched_barrier(0);
         load_b1(q, nkb, nt);
       }
@@ -726,10 +723,10 @@ __device__ __forceinline__ void gemm_sm3_pl(const Ctx &c, const float *__restric
     }
   } else {
     static_assert(MT == 1 || NT == 4, "two m-tiles per wave: all four tiles");
-    u32x4 bs[2][3];
+    u32x4 bs[2][kSplit];
     auto load_b1 = [&](int buf, int kb, int t, int q) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bs[buf][pl] = pl3[(kb * 3 + pl) * G::kPlaneU4 + 16 * q + 4 * t];
+      for (int pl = 0; pl < kSplit; ++pl) bs[buf][pl] = pl3[(kb * kSplit + pl) * G::kPlaneU4 + 16 * q + 4 * t];
     };
     first_a();
     load_b1(0, 0, 0, 0);
@@ -743,7 +740,7 @@ __device__ __forceinline__ void gemm_sm3_pl(const Ctx &c, const float *__restric
         else load_b1(0, nkb, nt, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) acc[mi][q] = mfma_split6(a[st & 1][mi], bs[q & 1], acc[mi][q]);
+        for (int mi = 0; mi < MT; ++mi) acc[mi][q] = mfma_split(a[st & 1][mi], bs[q & 1], acc[mi][q]);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -759,7 +756,7 @@ __device__ __forceinline__ void gemm_sm3_pl(const Ctx &c, const float *__restric
 // FIRST: NoFirst, or Frag3 = block 0's fragments of the first m-tile, requested by the caller ahead of the call (by value in
 // registers: a pointer to them would put the array on the stack).
 struct NoFirst { static constexpr bool on = false; };
-struct Frag3 { static constexpr bool on = true; u32x4 p[3]; };
+struct Frag3 { static constexpr bool on = true; u32x4 p[kSplit]; };
 template <int KB32, int MT, int NT, class PRE = NoPre, int MS = 1, int LL = 4, class FIRST = NoFirst>
 __device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__ wp3, int mt0, int nt0, const float *planes,
                                          f32x4 (&acc)[MT][NT], const PRE &pre = PRE(), const FIRST &first = FIRST()) {
@@ -767,29 +764,29 @@ __device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__
   const WStream wv(wp3, c.lane);
   using PGx = PG<LL>;
   const lds_u4 *pl3 = (const lds_u4 *)planes + g * PGx::kCols + PGx::kOff + 16 * nt0 + col;
-  u32x4 a[2][MT][3];
-  u32x4 bs[2][3];
+  u32x4 a[2][MT][kSplit];
+  u32x4 bs[2][kSplit];
   auto load_a = [&](int buf, int kb) {
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
-      const int sb = ((mt0 + mi * MS) * KB32 + kb) * 3072;   // one scalar offset per (m-tile, block), the planes by immediates
+      const int sb = ((mt0 + mi * MS) * KB32 + kb) * kFragBytes;   // one scalar offset per (m-tile, block), the planes by immediates
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[buf][mi][pl] = wv.raw_at(sb, pl * 1024);
+      for (int pl = 0; pl < kSplit; ++pl) a[buf][mi][pl] = wv.raw_at(sb, pl * 1024);
     }
   };
   auto load_b = [&](int buf, int kb, int ni) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) bs[buf][pl] = pl3[(kb * 3 + pl) * PGx::kPlaneU4 + 16 * ni];
+    for (int pl = 0; pl < kSplit; ++pl) bs[buf][pl] = pl3[(kb * kSplit + pl) * PGx::kPlaneU4 + 16 * ni];
   };
   if constexpr (FIRST::on) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) a[0][0][pl] = first.p[pl];
+    for (int pl = 0; pl < kSplit; ++pl) a[0][0][pl] = first.p[pl];
     if constexpr (MT > 1) {
 #pragma unroll
       for (int mi = 1; mi < MT; ++mi) {
-        const int sb = ((mt0 + mi * MS) * KB32) * 3072;
+        const int sb = ((mt0 + mi * MS) * KB32) * kFragBytes;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[0][mi][pl] = wv.raw_at(sb, pl * 1024);
+        for (int pl = 0; pl < kSplit; ++pl) a[0][mi][pl] = wv.raw_at(sb, pl * 1024);
       }
     }
   } else {
@@ -812,7 +809,7 @@ __device__ __forceinline__ void gemm1_pl(const Ctx &c, const float *__restrict__
       if (nxt < KB32 * NT) load_b(nxt & 1, nxt / NT, nxt % NT);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = mfma_split6(a[kb & 1][mi], bs[step & 1], acc[mi][ni]);
+      for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = mfma_split(a[kb & 1][mi], bs[step & 1], acc[mi][ni]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -1233,11 +1230,14 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
   else gemm_pm3_pl<MT, P0, NP, PRE>(c, wp, cin, mt0, bplanes, acc, pre);
   GLDM_WV_STAMP(c, 1, (long long)__builtin_readcyclecounter());
   if (FIN != 0) load_params();
-  // 256-channel level (two m-tiles per wave): this lane's slice of the parked residual stream, one f32x4 per (m-tile, position)
+  // 256-channel level (two m-tiles per wave).  16-position engine: this lane's slice of the parked residual stream, one
+  // f32x4 per (m-tile, position) (its 256 f32 rows do not fit beside the padded planes); the 4-position engine keeps the
+  // f32 rows in LDS (PG<4>::kW lies behind them)
   constexpr bool kWide = MT == 2;
+  constexpr bool kPark = kWide && LL == 16;
   f32x4 *pk = reinterpret_cast<f32x4 *>(c.park) + (size_t)(c.wave * MT * NP) * 64 + c.lane;
-  f32x4 parked[FIN == 2 && kWide ? MT : 1][FIN == 2 && kWide ? NP : 1];
-  if constexpr (FIN == 2 && kWide) {   // requested here, in flight under the statistics and the exchange barrier
+  f32x4 parked[FIN == 2 && kPark ? MT : 1][FIN == 2 && kPark ? NP : 1];
+  if constexpr (FIN == 2 && kPark) {   // requested here, in flight under the statistics and the exchange barrier
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -1253,7 +1253,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          if constexpr (kWide) {
+          if constexpr (kPark) {
             pk[(mi * NP + p) * 64] = acc[mi][p];
           } else {
 #pragma unroll
@@ -1406,7 +1406,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
           }
           const int a = pswz(16 * (mt0 + mi) + 4 * kq + r, 16 * (P0 + p) + cl);
           if constexpr (kMode == 2) {
-            if constexpr (kWide) t = parked[mi][p][r] + t;
+            if constexpr (kPark) t = parked[mi][p][r] + t;
             else t = d3[a] + t;
             d3[a] = t;
           }
@@ -2916,7 +2916,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   auto col_of = [](int sm, int l) { return PM ? (L == 4 ? 16 * l + sm : 4 * l + sm) : sm * L + l; };
   Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
         a.skip, GG::kNT};
-  if constexpr (PM) c.park = a.park + (size_t)blockIdx.x * (kParkBytes / 4);
+  if constexpr (PM && L == 16) c.park = a.park + (size_t)blockIdx.x * (kParkBytes / 4);
   const int E = d.emb_dim, R = d.cond_rows;
   float *lat = lds + GG::kMiscLat, *epsr = lds + GG::kMiscEps, *G = lds + GG::kMiscG;
   float *X = lds + GG::kBufX;
@@ -3385,8 +3385,8 @@ bool wide_engine(const gldm_r1d_desc *d) { return pm_supported(d) || pm16_suppor
 
 using gldm_dev::cu_count;
 
-// Scratch behind the hand-off granules where the position-major engine parks the residual stream of a 256-channel last
-// level (kPlaneW): 64 KiB per workgroup of the launch (at most one per CU), 256-byte aligned.  *base is rounded up to the
+// Scratch behind the hand-off granules where the 16-position 64-column engine parks the residual stream of a 256-channel
+// last level (PG<16>::kW): 64 KiB per workgroup of the launch (at most one per CU), 256-byte aligned.  *base is rounded up to the
 // alignment; returns the bytes to add behind it (0: this descriptor never parks).
 struct WsLayout { long long tiles, ss_off, park_off, total; int nc; };
 long long park_bytes(const gldm_r1d_desc *d, long long tiles, long long *base);
@@ -3409,7 +3409,7 @@ WsLayout ws_layout(const gldm_r1d_desc *d, int n_samples) {
   return w;
 }
 long long park_bytes(const gldm_r1d_desc *d, long long tiles, long long *base) {
-  if (!wide_engine(d) || d->dims[d->n_levels] != 256) return 0;
+  if (pm_supported(d) || !pm16_supported(d) || d->dims[d->n_levels] != 256) return 0;   // the 4-position engine keeps it in LDS
   *base = (*base + 255) & ~255LL;
   const long long wgs = tiles < cu_count() ? tiles : cu_count();
   return wgs * kParkBytes;
@@ -3694,14 +3694,13 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
 // per tile on the f32 pipe before) and writes its ReLU output straight into those planes; the head product is taken on the
 // accumulators exactly as in the f32 kernel (the C layout of the two MFMA shapes is the same).
 __device__ __forceinline__ void store_planes4_32(float *planes, int c0, int n, float v0, float v1, float v2, float v3) {
-  float x[8] = {v0, v1, v2, v3, 0.f, 0.f, 0.f, 0.f};
-  u32x4 pl[3];
-  split_bf16x3(x, pl);
-  const int a = ((((c0 >> 5) * 3) * 4 + ((c0 >> 3) & 3)) * 32 + n) * 4 + ((c0 >> 2) & 1) * 2;   // dwords
+  unsigned h0, h1, l0, l1;
+  split_f16x2(v0, v1, h0, l0);
+  split_f16x2(v2, v3, h1, l1);
+  const int a = ((((c0 >> 5) * kSplit) * 4 + ((c0 >> 3) & 3)) * 32 + n) * 4 + ((c0 >> 2) & 1) * 2;   // dwords
   lds_u2 *d = (lds_u2 *)(planes + a);
-  d[0] = u32x2_t{pl[0][0], pl[0][1]};
-  d[256] = u32x2_t{pl[1][0], pl[1][1]};   // next plane: 4 * 32 * 4 dwords
-  d[512] = u32x2_t{pl[2][0], pl[2][1]};
+  d[0] = u32x2_t{h0, h1};
+  d[256] = u32x2_t{l0, l1};   // next plane: 4 * 32 * 4 dwords
 }
 
 // The layer in front of the split-bf16 main layer, on the same pipe: x0 = the f32 [cin0][32] tile (swizzled), w0s =
@@ -3713,7 +3712,7 @@ __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *
                                                int wave, int lane, int mt_per_wave0) {
   constexpr int NC = 32;
   const int col = lane & 15, kq = lane >> 4;
-  u32x4 bp[KB0][2][3];
+  u32x4 bp[KB0][2][kSplit];
 #pragma unroll
   for (int kb = 0; kb < KB0; ++kb)
 #pragma unroll
@@ -3721,13 +3720,13 @@ __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = x0[swz<NC>(32 * kb + 8 * kq + j, 16 * ni + col)];
-      split_bf16x3(v, bp[kb][ni]);
+      split_planes8(v, bp[kb][ni]);
     }
-  u32x4 af[2][KB0][3];
+  u32x4 af[2][KB0][kSplit];
   const int mt_first = wave * mt_per_wave0, mt_last = mt_first + mt_per_wave0 - 2;
   auto load_a = [&](int mi, int kb, int mt0) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) af[mi][kb][pl] = w0s.raw_at(((mt0 + mi) * KB0 + kb) * 3072, pl * 1024);
+    for (int pl = 0; pl < kSplit; ++pl) af[mi][kb][pl] = w0s.raw_at(((mt0 + mi) * KB0 + kb) * kFragBytes, pl * 1024);
   };
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -3747,7 +3746,7 @@ __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *
 #pragma unroll
       for (int kb = 0; kb < KB0; ++kb) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_split6(af[mi][kb], bp[kb][ni], acc[mi][ni]);
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_split(af[mi][kb], bp[kb][ni], acc[mi][ni]);
         __builtin_amdgcn_sched_barrier(0);
         load_a(mi, kb, mtn);   // pinned here: the scheduler sinks such requests to their first use otherwise
         __builtin_amdgcn_sched_barrier(0);
@@ -3777,14 +3776,14 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kq = lane >> 4;
   const int kb32 = a.cin >> 5, mtiles = a.cout >> 4, mt_per_wave = mtiles >> 3;
-  float *planes = lds;                       // [kb32][3][4][32][4 dwords]
+  float *planes = lds;                       // [kb32][kSplit][4][32][4 dwords]
   float *zpart = lds;                        // [8 waves][16 rows][32 cols], over the planes once they are dead
-  float *x0 = lds + a.cin * 48;              // front layer's f32 input tile [cin0][32]
+  float *x0 = lds + a.cin * 16 * kSplit;     // front layer's f32 input tile [cin0][32] behind the planes (cin / 32 blocks x kSplit x 512 floats)
   float *zdyn = x0;                          // head products of the drawn units [unit - dyn_first][hout][32] (x0 is dead then)
   int *ticket = (int *)(lds + a.ticket_off); // next unit of output rows to hand out (main layer)
   const WStream hw(a.head_w ? a.head_w : a.w, lane);
   const WStream wv(a.w, lane);
-  const lds_u4 *pl3 = (const lds_u4 *)planes + kq * 32 + col;   // + ((kb * 3 + plane) * 4) * 32 + 16 ni
+  const lds_u4 *pl3 = (const lds_u4 *)planes + kq * 32 + col;   // + ((kb * kSplit + plane) * 4) * 32 + 16 ni
   for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_cloud, c0 = (tile - b * a.tiles_per_cloud) * NC;
     __syncthreads();  // the previous tile's readers are done
@@ -3815,12 +3814,11 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a
           float v[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = xb[(size_t)(row + j) * a.n + scol];
-          u32x4 pl[3];
-          split_bf16x3(v, pl);
-          lds_u4 *d = (lds_u4 *)planes + (((row >> 5) * 3) * 4 + ((row >> 3) & 3)) * 32 + scol;
+          u32x4 pl[kSplit];
+          split_planes8(v, pl);
+          lds_u4 *d = (lds_u4 *)planes + (((row >> 5) * kSplit) * 4 + ((row >> 3) & 3)) * 32 + scol;
           d[0] = pl[0];
           d[128] = pl[1];
-          d[256] = pl[2];
         }
       }
     }
@@ -3836,19 +3834,19 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a
     // first weight fragments are requested from inside that loop (the ring of four A sets never drains), and the B
     // planes of block k + 1 are read in front of the MFMAs of block k.
     const int units = mtiles >> 1;
-    u32x4 af[4][2][3];
+    u32x4 af[4][2][kSplit];
     auto load_a = [&](int buf, int mt0, int kb) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kb32 + kb) * 3072, pl * 1024);
+        for (int pl = 0; pl < kSplit; ++pl) af[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kb32 + kb) * kFragBytes, pl * 1024);
     };
-    u32x4 bs[2][2][3];
+    u32x4 bs[2][2][kSplit];
     auto load_b = [&](int buf, int kb) {
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bs[buf][ni][pl] = pl3[(kb * 3 + pl) * 128 + 16 * ni];
+        for (int pl = 0; pl < kSplit; ++pl) bs[buf][ni][pl] = pl3[(kb * kSplit + pl) * 128 + 16 * ni];
     };
     auto draw = [&]() {
       int t = 0;
@@ -3886,7 +3884,7 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_split6(af[u][mi], bs[u & 1][ni], acc[mi][ni]);
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_split(af[u][mi], bs[u & 1][ni], acc[mi][ni]);
           __builtin_amdgcn_sched_barrier(0);
           load_a(u, tail ? mtn : mt0, tail ? u : kb + 4);
         }
@@ -4150,6 +4148,7 @@ __global__ __launch_bounds__(512, 1) void sa_mlp2_kernel(const SaArgs a, int row
 // Persistent workgroups; the next tile's gather is requested in front of the last layer and stored behind it.
 // Shapes: cin_pad a multiple of 32 (zero weights beyond the real rows), hidden widths multiples of 32 up to 256, U in
 // {16, 32, 64}; anything else runs on the f32 kernels above.
+constexpr int kSaBlockFloats = PG<4>::kBlockFloats;   // one 32-channel block of a 64-column tile's planes
 constexpr int kSa3Quads = 9;   // row quads per gather thread: 8 threads per column x 9 x 4 rows >= 259 + padding
 template <int NT, class FIRST>
 __device__ __forceinline__ void sa3_gemm(const Ctx &c, const float *wp, int kb, int mt, int nt0, const float *planes,
@@ -4178,7 +4177,7 @@ __device__ __forceinline__ Frag3 sa3_request(const Ctx &c, const SaArgs &a, int 
   const int mtc = mt < (a.cout[l] >> 4) ? mt : 0;   // waves beyond a narrow last layer: any valid fragment
   Frag3 f;
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) f.p[pl] = wv.raw_at(mtc * kb * 3072, pl * 1024);
+  for (int pl = 0; pl < kSplit; ++pl) f.p[pl] = wv.raw_at(mtc * kb * kFragBytes, pl * 1024);
   return f;
 }
 // REQ: request the next layer's first fragments right behind this k-loop (in flight under the epilogue and the barrier)
@@ -4237,11 +4236,11 @@ __device__ __forceinline__ void sa3_layer_multi(const Ctx &c, const SaArgs &a, i
                                                 int src_off, int dst_off, int T, int tiles_per_cloud, int total_tiles) {
   const int col = c.lane & 15, kq = c.lane >> 4, g = kq;
   const WStream wv(a.weights + a.w_off[l], c.lane);
-  u32x4 af[KB][3];
+  u32x4 af[KB][kSplit];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) af[kb][pl] = wv.raw_at((mt * KB + kb) * 3072, pl * 1024);
+    for (int pl = 0; pl < kSplit; ++pl) af[kb][pl] = wv.raw_at((mt * KB + kb) * kFragBytes, pl * 1024);
   const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq);
   const int cpt = 64 / a.u, tpc = a.u >> 4;
   for (int st = 0; st < sub; ++st) {
@@ -4251,13 +4250,13 @@ __device__ __forceinline__ void sa3_layer_multi(const Ctx &c, const SaArgs &a, i
     for (int ni = 0; ni < NT; ++ni) acc[ni] = bv;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      u32x4 bs[NT][3];
+      u32x4 bs[NT][kSplit];
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bs[ni][pl] = pl3[(kb * 3 + pl) * 256 + 16 * ni];
+        for (int pl = 0; pl < kSplit; ++pl) bs[ni][pl] = pl3[(kb * kSplit + pl) * 256 + 16 * ni];
 #pragma unroll
-      for (int ni = 0; ni < NT; ++ni) acc[ni] = mfma_split6(af[kb], bs[ni], acc[ni]);
+      for (int ni = 0; ni < NT; ++ni) acc[ni] = mfma_split(af[kb], bs[ni], acc[ni]);
     }
     if constexpr (!LAST) {
 #pragma unroll
@@ -4311,7 +4310,7 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
   Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
         0, 4};
   const int cpt = 64 / a.u;  // centres per tile
-  const int per = (blocks_a + blocks_b) * 3072;   // floats of one tile's two plane regions
+  const int per = (blocks_a + blocks_b) * kSaBlockFloats;   // floats of one tile's two plane regions
   const int w = c.wave, col = c.lane, qg = c.wave;   // gather: thread = (column, row-quad group)
   const int nquads = a.cin_pad[0] >> 2;
   const int supers = (total_tiles + sub - 1) / sub;
@@ -4362,7 +4361,7 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
     Ctx cl = c;
     asm volatile("" : "+v"(cl.tid), "+v"(cl.lane));
     if constexpr (SUBMAX > 1) {   // weights once per layer, the tiles stream through (sa3_layer_multi)
-      const int so = a_to_b ? 0 : blocks_a * 3072, dof = a_to_b ? blocks_a * 3072 : 0;
+      const int so = a_to_b ? 0 : blocks_a * kSaBlockFloats, dof = a_to_b ? blocks_a * kSaBlockFloats : 0;
       if (mtiles >= 8) {
         for (int p = 0; p < (mtiles >> 3); ++p) sa3_layer_multi_kb<4, false>(cl, a, l, w + 8 * p, 0, sub, per, so, dof, 0, 1, 0);
       } else if (mtiles == 4) sa3_layer_multi_kb<2, false>(cl, a, l, w & 3, 2 * (w >> 2), sub, per, so, dof, 0, 1, 0);
@@ -4371,8 +4370,8 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
     }
     const Frag3 cur = frag;
     for (int st = 0; st < sub; ++st) {
-      const float *src = lds + st * per + (a_to_b ? 0 : blocks_a * 3072);
-      float *dst = lds + st * per + (a_to_b ? blocks_a * 3072 : 0);
+      const float *src = lds + st * per + (a_to_b ? 0 : blocks_a * kSaBlockFloats);
+      float *dst = lds + st * per + (a_to_b ? blocks_a * kSaBlockFloats : 0);
       if (st == 0) {
         if (mtiles == 8) frag = sa3_hidden<4, Frag3, true>(cl, a, l, w, 0, src, dst, cur);
         else if (mtiles == 16) {
@@ -4409,7 +4408,7 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
       Ctx cl = c;
       asm volatile("" : "+v"(cl.tid), "+v"(cl.lane));
       if constexpr (SUBMAX > 1) {
-        const int so = a_to_b ? 0 : blocks_a * 3072;
+        const int so = a_to_b ? 0 : blocks_a * kSaBlockFloats;
         for (int mt = w; mt < mtiles; mt += 8) sa3_layer_multi_kb<4, true>(cl, a, l, mt, 0, sub, per, so, 0, T, tiles_per_cloud, total_tiles);
       }
       const Frag3 cur = frag;
@@ -4418,7 +4417,7 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
         if (t >= total_tiles) break;   // wave uniform
         const int b = t / tiles_per_cloud, j0 = (t - b * tiles_per_cloud) * cpt;
         float *outb = a.out + (size_t)b * a.cout[l] * a.m;
-        const float *src = lds + st * per + (a_to_b ? 0 : blocks_a * 3072);
+        const float *src = lds + st * per + (a_to_b ? 0 : blocks_a * kSaBlockFloats);
         if (st == 0) {
           if (w < mtiles) sa3_last<Frag3>(cl, a, l, w, src, j0, outb, cur);
         } else {
@@ -4579,7 +4578,7 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   if (split_bf16) {
     // LDS plan: planes | front tile, later the head products of the drawn units | ticket.  As many units are drawn as
     // have room for their head slot (all but the first round when there is no head).
-    const size_t planes = (size_t)cin * 48 * sizeof(float), cap = (size_t)160 * 1024 - 16;
+    const size_t planes = (size_t)cin * 16 * kSplit * sizeof(float), cap = (size_t)160 * 1024 - 16;
     size_t region = w0 ? (size_t)cin0 * 32 * sizeof(float) : 0;
     if (planes + region > cap) return GLDM_ERR_UNSUPPORTED;
     const int units = cout / 32;
@@ -4700,7 +4699,7 @@ GLDM_API int gldm_sa_mlp_forward_bf16x3(const float *points, const float *center
   }
   if (cin_pad[0] < 3 + c || cin_pad[0] > 32 * kSa3Quads) return GLDM_ERR_UNSUPPORTED;
   blocks_a = blocks_a > (cin_pad[0] >> 5) ? blocks_a : (cin_pad[0] >> 5);
-  const size_t tile_bytes = (size_t)(blocks_a + blocks_b) * 3072 * sizeof(float);
+  const size_t tile_bytes = (size_t)(blocks_a + blocks_b) * kSaBlockFloats * sizeof(float);
   if (tile_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
   const int cpt = 64 / u, tpc = (m + cpt - 1) / cpt, total = tpc * b;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

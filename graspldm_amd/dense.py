@@ -121,7 +121,7 @@ def folded_conv_bn(conv, bn, device):
     key = params_key(src, device)
     hit = conv.__dict__.get("_gldm_folded")  # lives and dies with the module
     if hit is None or hit[0] != key:
-        from .r1d_pack import mfma_a_fragments, mfma_a_fragments_bf16x3
+        from .r1d_pack import mfma_a_fragments, mfma_a_fragments_f16x2
         s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
         w = (conv.weight.reshape(conv.weight.shape[0], -1) * s.view(-1, 1)).contiguous()
         cb = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
@@ -131,9 +131,9 @@ def folded_conv_bn(conv, bn, device):
             wp = mfma_a_fragments(w.detach().float().cpu()).to(device)
             # split fragments: main layers of the split launch (cin % 128 == 0) and its narrow front layers (cin <= 128)
             if split_supported(w.shape[1]) or w.shape[1] <= 128:
-                ws = mfma_a_fragments_bf16x3(w.detach().float().cpu()).to(device)
+                ws = mfma_a_fragments_f16x2(w.detach().float().cpu()).to(device)
         elif w.shape[0] % 32 == 0 and w.shape[0] >= 64 and split_supported(w.shape[1]):
-            ws = mfma_a_fragments_bf16x3(w.detach().float().cpu()).to(device)   # 64 .. 224 output rows: split launch only
+            ws = mfma_a_fragments_f16x2(w.detach().float().cpu()).to(device)   # 64 .. 224 output rows: split launch only
         hit = (key, w, b, wp, ws)
         conv.__dict__["_gldm_folded"] = hit
         publish(device)
@@ -184,11 +184,11 @@ def concat_conv_bn_relu(xa, xb, conv, bn):
     key = (params_key(src, xa.device), ca, broadcast)
     hit = conv.__dict__.get("_gldm_concat")
     if hit is None or hit[0] != key:
-        from .r1d_pack import mfma_a_fragments_bf16x3
+        from .r1d_pack import mfma_a_fragments_f16x2
         w, b = folded_conv_bn(conv, bn, xa.device)[:2]
         wa, wb = w[:, :ca].contiguous(), w[:, ca:].contiguous()
         wide = wb if broadcast else wa
-        hit = (key, mfma_a_fragments_bf16x3(wide.detach().float().cpu()).to(xa.device), wa if broadcast else wb, b,
+        hit = (key, mfma_a_fragments_f16x2(wide.detach().float().cpu()).to(xa.device), wa if broadcast else wb, b,
                torch.zeros_like(b))
         conv.__dict__["_gldm_concat"] = hit
         publish(xa.device)

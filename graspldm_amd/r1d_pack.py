@@ -82,6 +82,33 @@ def mfma_a_fragments_bf16x3(w2d):
     return frag.reshape(-1, 8).view(torch.float32).reshape(-1)     # bit pattern kept: 8 bf16 = 4 floats
 
 
+def split_f16x2(w):
+    """f32 -> (hi, lo) f16 with hi + lo == w up to 2^-22 |w| (round to nearest at each stage; lo may be an f16
+    subnormal: the matrix pipe keeps those).  Values beyond the f16 range (|w| >= 65520) are refused."""
+    w = w.detach().float()
+    if w.numel() and float(w.abs().max()) >= 65504.0:
+        raise ValueError("split-f16 operands must stay below 65504 in magnitude (got %g)" % float(w.abs().max()))
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return hi, lo
+
+
+def mfma_a_fragments_f16x2(w2d):
+    """[M, K] (K % 32 == 0) -> f32-typed bit container of the split-f16 A fragments of v_mfma_f32_16x16x32_f16:
+    [M/16][K/32][plane hi|lo][lane 64][8 f16], lane l = W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + j]
+    (include/gldm.h).  512 floats per (m-tile, 32-deep k-block)."""
+    m, k = w2d.shape
+    if k % 32:
+        raise ValueError("split-f16 fragments need K % 32 == 0")
+    mt = (m + 15) // 16
+    wp = torch.zeros(mt * 16, k, dtype=torch.float32)
+    wp[:m] = w2d
+    planes = torch.stack(split_f16x2(wp))                          # [2, M, K] f16
+    planes = planes.view(2, mt, 16, k // 32, 4, 8)                 # (plane, mt, i, kb, g, j): k = 32 kb + 8 g + j
+    frag = planes.permute(1, 3, 0, 4, 2, 5).contiguous()           # (mt, kb, plane, g, i, j): lane = 16 g + i
+    return frag.reshape(-1, 8).view(torch.float32).reshape(-1)     # bit pattern kept: 8 f16 = 4 floats
+
+
 def conv_as_gemm(w):
     """Conv1d weight [Cout, Cin, taps] -> [Cout, taps*Cin] with k = tap*Cin + ci."""
     return w.permute(0, 2, 1).reshape(w.shape[0], -1)
@@ -166,8 +193,8 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
         rb.ss_b = buf.add(comb)
         w1, w2 = (conv_as_gemm(weight_standardize(sd[q + f"block{i}.proj.weight"])) for i in (1, 2))
         if c % 16 == 0:   # split-bf16 copies for the 64-column engines (per tap a multiple of 32 channels: 16 is padded)
-            rb.c1_w3 = buf.add(mfma_a_fragments_bf16x3(pad_cin32(w1, c, 3)))
-            rb.c2_w3 = buf.add(mfma_a_fragments_bf16x3(pad_cin32(w2, c, 3)))
+            rb.c1_w3 = buf.add(mfma_a_fragments_f16x2(pad_cin32(w1, c, 3)))
+            rb.c2_w3 = buf.add(mfma_a_fragments_f16x2(pad_cin32(w2, c, 3)))
         rb.c1_w = buf.add(mfma_a_fragments(conv_as_gemm(weight_standardize(sd[q + "block1.proj.weight"]))))
         rb.c1_b = buf.add(sd[q + "block1.proj.bias"])
         rb.n1_w = buf.add(sd[q + "block1.norm.weight"])
@@ -205,9 +232,9 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
         lv.ln2_g = buf.add(sd[q + "2.fn.fn.to_out.1.g"])
         lv.down_w = buf.add(mfma_a_fragments(conv_as_gemm(sd[q + "3.weight"])))
         if c % 16 == 0:
-            lv.qkvn_w3 = buf.add(mfma_a_fragments_bf16x3(pad_cin32(wn, c, 1)))
-            lv.down_w3 = buf.add(mfma_a_fragments_bf16x3(pad_cin32(conv_as_gemm(sd[q + "3.weight"]), c, 3)))
-        lv.out_w3 = buf.add(mfma_a_fragments_bf16x3(sd[q + "2.fn.fn.to_out.0.weight"][:, :, 0]))
+            lv.qkvn_w3 = buf.add(mfma_a_fragments_f16x2(pad_cin32(wn, c, 1)))
+            lv.down_w3 = buf.add(mfma_a_fragments_f16x2(pad_cin32(conv_as_gemm(sd[q + "3.weight"]), c, 3)))
+        lv.out_w3 = buf.add(mfma_a_fragments_f16x2(sd[q + "2.fn.fn.to_out.0.weight"][:, :, 0]))
         lv.down_b = buf.add(sd[q + "3.bias"])
     resblock(p + "final_res_block.", dims[-1], slot)
     fw = sd[p + "final_conv.weight"]

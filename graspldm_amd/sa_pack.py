@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .r1d_pack import _Buf, mfma_a_fragments, mfma_a_fragments_bf16x3
+from .r1d_pack import _Buf, mfma_a_fragments, mfma_a_fragments_f16x2
 
 _OK_MTILES = (1, 2, 4, 8, 12, 16)
 
@@ -93,7 +93,7 @@ class SaMlpPlan:
                 bp[: w.shape[0]] = b.cpu()
                 cin_pad.append(kpad)
                 cout.append(rows)
-                w_off.append(buf.add(mfma_a_fragments_bf16x3(wp)))
+                w_off.append(buf.add(mfma_a_fragments_f16x2(wp)))
                 b_off.append(buf.add(bp))
             arr = ctypes.c_int32 * n
             self._split = (buf.tensor().to(self._device), arr(*cin_pad), arr(*cout), arr(*w_off), arr(*b_off))

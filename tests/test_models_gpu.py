@@ -553,7 +553,7 @@ def test_pointwise_mlp_split_bf16(b, cin0, cin, cout, n, hout):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from graspldm_amd import dense
-    from graspldm_amd.r1d_pack import mfma_a_fragments_bf16x3
+    from graspldm_amd.r1d_pack import mfma_a_fragments_f16x2
     g = torch.Generator().manual_seed(7 + cin0 + cin + cout)
     c_in = cin0 if cin0 else cin
     x = torch.randn(b, c_in, n, generator=g)
@@ -563,7 +563,7 @@ def test_pointwise_mlp_split_bf16(b, cin0, cin, cout, n, hout):
     if cin0:
         w0, b0 = torch.randn(cin, cin0, generator=g) / cin0 ** 0.5, torch.randn(cin, generator=g)
         h_ref = (torch.einsum("oc,bcn->bon", w0.double(), h_ref) + b0.double().view(1, -1, 1)).relu().float().double()
-        front = (mfma_a_fragments_bf16x3(w0).cuda(), b0.cuda(), cin)
+        front = (mfma_a_fragments_f16x2(w0).cuda(), b0.cuda(), cin)
     y_ref = (torch.einsum("oc,bcn->bon", w1.double(), h_ref) + b1.double().view(1, -1, 1)).relu()
     head = None
     if hout:
@@ -571,14 +571,14 @@ def test_pointwise_mlp_split_bf16(b, cin0, cin, cout, n, hout):
         z_ref = (torch.einsum("oc,bcn->bon", wh.double(), y_ref) + bh.double().view(1, -1, 1)).float()
         head = (dense.pack_head(wh).cuda(), bh.cuda(), hout)
     assert dense.split_supported(cin, cin0)
-    y, z = dense.pointwise_mlp(x.cuda(), mfma_a_fragments_bf16x3(w1).cuda(), b1.cuda(), cout, True, head=head, keep_y=True,
+    y, z = dense.pointwise_mlp(x.cuda(), mfma_a_fragments_f16x2(w1).cuda(), b1.cuda(), cout, True, head=head, keep_y=True,
                                front=front, split=True)
     assert _err(y, y_ref.float()) < 2e-5 * max(1.0, y_ref.abs().max().item())
     if hout:
         assert _err(z, z_ref) < 2e-5 * max(1.0, z_ref.abs().max().item())
         # the head sum does not depend on which wave drew which unit of output rows: bitwise repeatable
         for _ in range(3):
-            _, z2 = dense.pointwise_mlp(x.cuda(), mfma_a_fragments_bf16x3(w1).cuda(), b1.cuda(), cout, True, head=head,
+            _, z2 = dense.pointwise_mlp(x.cuda(), mfma_a_fragments_f16x2(w1).cuda(), b1.cuda(), cout, True, head=head,
                                         keep_y=False, front=front, split=True)
             assert torch.equal(z2, z)
 
