@@ -26,12 +26,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix), spec
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: Peak BF16 MFMA, dense (the headline 5 PF is with 2:1 sparsity)
-# The GEMMs of the denoiser run on the bf16 matrix pipe with every f32 operand split into three bf16 numbers (exact)
-# and SIX partial products per f32 product (f32 accumulation): the ceiling for algorithmic f32 FLOP through that
-# scheme is the bf16 dense peak / 6.
-SPLIT_PRODUCTS = 6
-PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: Peak BF16/FP16 MFMA, dense (the headline 5 PF is with 2:1 sparsity)
+# The GEMMs run on the f16 matrix pipe with every f32 operand split into two f16 numbers (hi + lo: 22 significant bits)
+# and THREE partial products per f32 product (hi hi, hi lo, lo hi; f32 accumulation): the ceiling for algorithmic f32
+# FLOP through that scheme is the f16 dense peak / 3.  (Rounds 3-4 split into three bf16 numbers and issued six.)
+SPLIT_PRODUCTS = 3
+PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
 PEAK_HBM_GBS = 8000.0          # HBM3E peak, spec
 DENOISER_FLOP_PER_LATENT_STEP = 7_589_120   # SURVEY.md Appendix B (matches torch flop counter, tests/golden/r1d_flops.json)
 DENOISER_FLOP_PER_LATENT_STEP_PPC = 30_783_104   # the ppc experiment's 16-position denoiser (tests/golden/r1d_flops.json)
@@ -55,7 +55,7 @@ def denoiser_executed_mfma_flop_l16():
 
 def denoiser_executed_mfma_flop_fpc():
     """FLOP the position-major engine really issues on the matrix pipes per latent and step (f32-equivalent: one per
-    algorithmic multiply-add pair, before the x6 of the split): the k = 3 convs multiply 10 of their 12 (tap, position)
+    algorithmic multiply-add pair, before the x3 of the split): the k = 3 convs multiply 10 of their 12 (tap, position)
     pairs (the zero-padding taps are never issued), the 1x1 convs all of theirs, the to_out conv of the 4-channel level a
     padded 16-row m-tile; the scale/shift Linears (f32 MFMA, per sample); the conditioning Linear and the time MLP are
     hoisted out of the step loop and the attention cores / 4-channel ResnetBlocks run on the VALU."""
@@ -304,7 +304,7 @@ def main():
     den = ldm.diffusion_model.model
     eng = den.engine(dev)
     from graspldm_amd import _lib as L
-    pm_engine = L.lib().gldm_r1d_tile_columns(eng._desc_ptr()) == 64   # position-major split-bf16 engine (else: sample-major, f32 pipe)
+    pm_engine = L.lib().gldm_r1d_tile_columns(eng._desc_ptr()) == 64   # position-major split-f16 engine (else: sample-major, f32 pipe)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
     counter = [0]
@@ -392,35 +392,35 @@ def main():
                 break
         if pm_engine:
             exec_flop = B * G * S * (denoiser_executed_mfma_flop_fpc() if D == 4 else denoiser_executed_mfma_flop_l16())
-            roof = dict(kernel="r1d_kernel<64, %d> (gldm_denoise: %d %s steps fused, 64-column tiles = %s, split-bf16 GEMMs)"
+            roof = dict(kernel="r1d_kernel<64, %d> (gldm_denoise: %d %s steps fused, 64-column tiles = %s, split-f16 GEMMs)"
                                % (D, S, args.scheduler.upper(), "16 samples x 4 positions" if D == 4 else "4 samples x 16 positions"),
                         bound="mfma",
                         achieved=flop / t_den / 1e12, peak=PEAK_SPLIT_TFLOPS, unit="TFLOP/s",
                         frac=flop / t_den / 1e12 / PEAK_SPLIT_TFLOPS, traffic=traffic, traffic_source=traffic_source,
                         algorithmic_flop_per_launch=flop, avg_launch_ms=t_den * 1e3,
-                        executed=dict(f32_equivalent_flop_per_launch=exec_flop, bf16_flop_per_launch=SPLIT_PRODUCTS * exec_flop,
-                                      achieved_bf16_tflops=SPLIT_PRODUCTS * exec_flop / t_den / 1e12, peak_bf16_tflops=PEAK_BF16_MFMA_TFLOPS,
-                                      frac=SPLIT_PRODUCTS * exec_flop / t_den / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                        executed=dict(f32_equivalent_flop_per_launch=exec_flop, f16_flop_per_launch=SPLIT_PRODUCTS * exec_flop,
+                                      achieved_f16_tflops=SPLIT_PRODUCTS * exec_flop / t_den / 1e12, peak_f16_tflops=PEAK_F16_MFMA_TFLOPS,
+                                      frac=SPLIT_PRODUCTS * exec_flop / t_den / 1e12 / PEAK_F16_MFMA_TFLOPS,
                                       note="what the matrix pipe really executes (zero-padding taps of the k = 3 convs never "
                                            "issued, conditioning Linear / time MLP hoisted out of the loop, attention cores on "
-                                           "the VALU) x 6 bf16 products, against the bf16 dense peak"),
-                        peak_note="peak = bf16 dense MFMA peak (2500 TFLOP/s) / 6: the kernel computes every f32 product as six "
-                                  "bf16 partial products (operands split exactly into hi + mid + lo) with f32 accumulation, "
-                                  "so 6 executed bf16 FLOP per algorithmic FLOP",
+                                           "the VALU) x 3 f16 products, against the f16 dense peak"),
+                        peak_note="peak = f16 dense MFMA peak (2500 TFLOP/s) / 3: the kernel computes every f32 product as three "
+                                  "f16 partial products (operands split into hi + lo, 22 significant bits) with f32 accumulation, "
+                                  "so 3 executed f16 FLOP per algorithmic FLOP (rounds 3-4: six bf16 products, peak 2500 / 6)",
                         timing="HIP events around 3 launches on their own (no other stream active); in the pipelined "
                                "steps the other stream's encoder kernels share the GPU with the launch",
                         flop_note=f"algorithmic FLOP = the reference graph's count ({flop_ls:,} per latent and step, = torch's "
                                   "flop counter over the reference module, which counts a k=3 conv's zero-padding taps: "
                                   "tests/golden/r1d_flops.json).  "
-                                  "Arithmetic: f32 in, f32 out, f32 accumulation; products formed from bf16 pieces whose dropped "
-                                  "cross terms are <= 2^-23 relative (parity bars unchanged: 2e-5 single forward, 1e-4 poses)")
+                                  "Arithmetic: f32 in, f32 out, f32 accumulation; products formed from f16 pieces whose dropped "
+                                  "cross term is <= 2^-22 relative (parity bars unchanged: 2e-5 single forward, 1e-4 poses)")
         else:
             roof = dict(kernel="r1d_kernel<32, %d> (gldm_denoise: %d %s steps fused, sample-major 32-column tiles, f32 MFMA)" % (D, S, args.scheduler.upper()),
                         bound="mfma", achieved=flop / t_den / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=flop / t_den / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=None, traffic_source=None,
                         algorithmic_flop_per_launch=flop, avg_launch_ms=t_den * 1e3,
                         peak_note="the 16-position latent denoiser runs on the sample-major engine: exact f32 products on "
-                                  "v_mfma_f32_16x16x4_f32 (157.3 TFLOP/s dense); the split-bf16 position-major engine is built "
+                                  "v_mfma_f32_16x16x4_f32 (157.3 TFLOP/s dense); the split-f16 position-major engine is built "
                                   "for 4-position latents only",
                         flop_note="algorithmic FLOP = torch's flop counter over the reference's TimeConditionedResNet1D "
                                   "(dim 16, cond 256): tests/golden/r1d_flops.json")
@@ -441,22 +441,22 @@ def main():
               t_floor = B * (f_split / (PEAK_SPLIT_TFLOPS * 1e12) + f_f32 / (PEAK_F32_MFMA_TFLOPS * 1e12))
               enc_rec = dict(achieved=B * ENCODER_FLOP_EXECUTED_PER_CLOUD / t_enc / 1e12,
                              peak=B * ENCODER_FLOP_EXECUTED_PER_CLOUD / t_floor / 1e12, frac=t_floor / t_enc,
-                             executed_flop_per_cloud=dict(split_bf16_pipe=f_split, f32_pipe=f_f32))
+                             executed_flop_per_cloud=dict(split_f16_pipe=f_split, f32_pipe=f_f32))
           else:
               enc_rec = dict(achieved=None, peak=None, frac=None)
           kernels = [dict(kernel="PVCNNEncoder.forward (all launches)", bound="mfma (mixed pipes)", avg_ms=t_enc * 1e3, unit="TFLOP/s",
                           note="executed FLOP (head convs folded; the reference graph has %.3f GFLOP per cloud); peak = executed "
                                "FLOP / the time the launches would take with each GEMM at the peak of the pipe it runs on (768 -> "
-                               "1536 layer, 96 -> 768 layer and the four voxel convs: split-bf16, 2500 / 6 TFLOP/s; the "
+                               "1536 layer, 96 -> 768 layer and the four voxel convs: split-f16, 2500 / 3 TFLOP/s; the "
                                "rest: f32 MFMA, 157.3): frac = that time / measured, memory passes counted as zero"
                                % (ENCODER_FLOP_PER_CLOUD / 1e9), **enc_rec),
-                     dict(kernel="r1d_kernel<64, 16> (gldm_decode: 64-column tiles = 4 samples x 16 positions, split-bf16 GEMMs)"
+                     dict(kernel="r1d_kernel<64, 16> (gldm_decode: 64-column tiles = 4 samples x 16 positions, split-f16 GEMMs)"
                                  if dec_cols == 64 else "r1d_kernel<32, 16> (gldm_decode, f32 matrix pipe)", bound="mfma",
                           avg_ms=t_dec * 1e3, achieved=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12,
                           peak=PEAK_SPLIT_TFLOPS if dec_cols == 64 else PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                           frac=B * G * DECODER_FLOP_PER_GRASP / t_dec / 1e12 / (PEAK_SPLIT_TFLOPS if dec_cols == 64 else PEAK_F32_MFMA_TFLOPS),
                           note="algorithmic FLOP = torch's flop counter over the reference decoder trunk (tests/golden/r1d_flops.json)")]
-          # ---- the same launch on the f32 matrix pipe only: a descriptor without the split-bf16 weight copies (what an
+          # ---- the same launch on the f32 matrix pipe only: a descriptor without the split-f16 weight copies (what an
           # ABI-4 packer produces) runs the sample-major engine, exact f32 fma chains -- for comparison with the split
           # arithmetic of the headline path
           if args.scheduler == "ddim" and pm_engine:
@@ -521,12 +521,12 @@ def main():
           t_fsa = event_time(fsa, 10)
           sa_flop = B * 2 * Ms * Us * (131 * 128 + 128 * 128 + 128 * 256)
           sa_exec = B * 2 * Ms * Us * (160 * 128 + 128 * 128 + 128 * 256)   # input rows padded 131 -> 160 (five 32-channel blocks)
-          kernels.append(dict(kernel="sa_mlp3_kernel (SSG SA2 fused gather + MLP 131-128-128-256 + max, 64-column tiles on split-bf16 planes)",
+          kernels.append(dict(kernel="sa_mlp3_kernel (SSG SA2 fused gather + MLP 131-128-128-256 + max, 64-column tiles on split-f16 planes)",
                               bound="mfma", avg_ms=t_fsa * 1e3, achieved=sa_flop / t_fsa / 1e12, peak=PEAK_SPLIT_TFLOPS,
                               unit="TFLOP/s", frac=sa_flop / t_fsa / 1e12 / PEAK_SPLIT_TFLOPS,
-                              executed_frac=SPLIT_PRODUCTS * sa_exec / t_fsa / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                              executed_frac=SPLIT_PRODUCTS * sa_exec / t_fsa / 1e12 / PEAK_F16_MFMA_TFLOPS,
                               hbm_bytes_avoided=B * 4 * (Cs + 3) * Ms * Us,
-                              note="gldm_sa_mlp_forward_bf16x3: GEMMs as six bf16 partial products per f32 product (round 3: "
+                              note="gldm_sa_mlp_forward_f16x2: GEMMs as three f16 partial products per f32 product (round 3: "
                                    "sa_mlp2_kernel on the f32 matrix pipe, 2.79 ms = 0.63 of its peak)"))
           # ---- BASELINE.json configs[1]: ONE object (B = 1, G grasps), latency per stage and end to end
           if args.scheduler == "ddim":
@@ -601,9 +601,9 @@ def main():
         out = dict(metric="grasps/sec whole-node (%d-pt cloud, %d %s steps)" % (N, S, args.scheduler.upper()), value=grasps_per_s,
                    unit="grasps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
                    higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype=("f32 (GEMMs as split-bf16 x6 partial products on the bf16 matrix pipe, f32 accumulation; GroupNorm / "
+                   dtype=("f32 (GEMMs as split-f16 x3 partial products on the f16 matrix pipe, f32 accumulation; GroupNorm / "
                           "LayerNorm / attention / scheduler in f32)") if pm_engine else
-                         "f32 (denoiser / decoder GEMMs on the f32 matrix pipe; the encoder's wide GEMMs as split-bf16 x6 partial products)",
+                         "f32 (denoiser / decoder GEMMs on the f32 matrix pipe; the encoder's wide GEMMs as split-f16 x3 partial products)",
                    data="synthetic",
                    config=dict(workload=f"LDM mode, {B} synthetic {'partial ' if partial else ''}{N}-pt clouds per GPU x {G} grasps, "
                                         f"{S} {args.scheduler.upper()} steps: " + workload_label(B, G, N, S, args.scheduler, args.experiment),

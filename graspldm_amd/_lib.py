@@ -43,8 +43,8 @@ _SIGNATURES = {
     "gldm_conv3d_k3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_conv3d_k3_cl": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gldm_conv3d_k3_generic": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
-    "gldm_conv3d_k3_bf16x3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
-    "gldm_conv3d_k3_bf16x3_gn": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "gldm_conv3d_k3_f16x2": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "gldm_conv3d_k3_f16x2_gn": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "gldm_groupnorm_coef": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "gldm_gn_swish_chan_sum": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "gldm_gn_swish_chan_sum_cl": [_vp, _vp, _i, _i, _i, _vp, _vp],
@@ -60,11 +60,11 @@ _SIGNATURES = {
     "gldm_pointwise_small": [_vp, _vp, _vp, _i, _i, _i, ctypes.c_longlong, _i, _vp, _vp],
     "gldm_pointwise_any": [_vp, _vp, _vp, _i, _i, _i, ctypes.c_longlong, _i, _vp, _vp],
     "gldm_linear_rows": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
-    "gldm_pointwise_mlp_bf16x3": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
-    "gldm_pointwise_mlp_bf16x3_add": [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _vp],
-    "gldm_pointwise_mlp2_bf16x3": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "gldm_pointwise_mlp_f16x2": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "gldm_pointwise_mlp_f16x2_add": [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _vp],
+    "gldm_pointwise_mlp2_f16x2": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_sa_mlp_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "gldm_sa_mlp_forward_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gldm_sa_mlp_forward_f16x2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 
 

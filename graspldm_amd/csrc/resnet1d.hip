@@ -86,7 +86,10 @@ struct Geo {
   static constexpr int kMiscTape = kMiscRed2 + kWaves * NC;  // [kMaxOps][12] ints: the step program (+ its length)
   static constexpr int kMiscSegs = kMiscTape + 1024;         // [kMaxSegs][4] ints: this workgroup's (tile, s0, s1) list
   static constexpr int kMiscOld = kMiscSegs + 256;           // [NC] previous step's denoised row (DPM++ 2M)
-  static constexpr int kLdsFloats = kMiscOld + NC;
+  // 64-column engines: per-sample range of a ResnetBlock's H (conv_pm3_wave): [8 waves][16] published bounds, [16] scales
+  static constexpr int kMiscHb = kMiscOld + NC;
+  static constexpr int kMiscHs = kMiscHb + (NC == 64 ? 8 * 16 : 0);
+  static constexpr int kLdsFloats = kMiscHs + (NC == 64 ? 16 : 0);
 };
 static_assert(Geo<64>::kLdsFloats * 4 <= 160 * 1024, "LDS budget (1 WG/CU)");
 static_assert(Geo<32>::kLdsFloats * 4 * 2 <= 160 * 1024, "LDS budget (2 WG/CU)");
@@ -106,7 +109,6 @@ __device__ __forceinline__ int pswz(int row, int col) { return row * 64 + (col ^
 // Split operands (see "split-f16 GEMM core" below): every f32 value travels as kSplit = 2 f16 numbers, hi + lo.
 constexpr int kSplit = 2;
 constexpr int kFragBytes = kSplit * 1024;        // one weight fragment: [plane][lane 64][8 f16]
-constexpr int kFragFloats = kFragBytes / 4;
 
 // Pre-split activation planes of the 64-column engines.  A tensor that is only ever read as a GEMM B operand is kept
 // in LDS already split into its two f16 planes, in B-fragment order:
@@ -504,7 +506,7 @@ __device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[kSplit], const u32x
   return mfma_h(a[0], b[0], acc);
 }
 
-// Position-major k = 3 conv (see gemm_pm3 below for the tile algebra) on split-bf16 operands.  wp3: split fragments
+// Position-major k = 3 conv (see gemm_pm3 below for the tile algebra) on split-f16 operands.  wp3: split fragments
 // of [Cout x 3 Cin], k = tap * Cin + ci, 32-deep k-blocks (Cin % 32 == 0).  One set of A registers per tap: the
 // moment a tap's MFMAs have issued, its registers are refilled with the next channel block's fragments of that tap,
 // which then have the two other taps' MFMAs (and the partner wave's) to arrive.  The raw f32 B values of the next
@@ -1169,6 +1171,11 @@ constexpr int kPmMaxOps = 8 * GLDM_R1D_MAX_LEVELS + 2;   // 64-column engines: a
 //   GK 1: partner = wave ^ 4 (C = 64: one m-tile = one group, positions split in two halves)
 //   GK 2: four waves (one per position) x two groups per m-tile (C = 32: 8 channels per group)
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
+constexpr float sqrt_up(int n) {   // >= sqrt(n), n a power of two
+  float r = 1.f;
+  while (n >= 4) { r *= 2.f; n /= 4; }
+  return n >= 2 ? r * 1.41422f : r;
+}
 // FIN: which epilogues this instance carries (code size: the kernel's straight-line phases must stay inside the instruction
 // cache): 0 = none (the level's down conv, mode 0), 1 = block1 (H = act(GN(conv)), scale/shift at run time), 2 = block2
 // (X += act(GN(conv)), no scale/shift).  Modes 1 and 2 only ever run inside the fused ResnetBlock op.
@@ -1213,10 +1220,25 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
       }
     }
   };
+  // Range of H.  A ResnetBlock's H = act((scale + 1) GN(conv1) + shift) is the one operand whose size is set by the DATA
+  // (the conditioning embedding through scale / shift: 5e5 with wild conditioning rows, tests/test_cli.py), and f16
+  // planes end at 65504.  block1 therefore writes H / hs, hs a power of two per SAMPLE chosen from a bound it already has
+  // in registers (1 for anything ordinary: every operation below is then bit for bit what it was); block2 computes
+  // conv(H) / hs (bias / hs in the accumulator) and folds hs back into its GroupNorm coefficients (per-sample
+  // statistics: mean and M2 scale with hs and hs^2).  Everything else these engines feed the f16 pipe is bounded by the
+  // weights alone (norm outputs, residual sums of them, softmax-weighted values).
+  lds_f *hsc = (lds_f *)(c.lds + GG::kMiscHs);
+  float hs = 1.0f;
+  if constexpr (FIN == 2) hs = hsc[sm];
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + 16 * (mt0 + mi) + 4 * kq);
+    if constexpr (FIN == 2) {
+      const float hinv = __builtin_amdgcn_rcpf(hs);   // a power of two: exact
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] *= hinv;
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) acc[mi][p] = bv;
   }
@@ -1338,9 +1360,38 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
       }
     }
   }
+  if constexpr (FIN == 1) {
+    // |H| <= |gamma (scale + 1)| R + |beta (scale + 1) + shift| over this lane's rows, R = sqrt(group size) >= any
+    // normalised value of the group; max over the lanes of the sample, then over the eight waves behind the barrier
+    constexpr float kR = sqrt_up(kNloc * kParts);
+    float hb = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        hb = fmaxf(hb, fmaf(__builtin_fabsf(ga[mi][r] * sc[mi][r]), kR, __builtin_fabsf(fmaf(be[mi][r], sc[mi][r], sh[mi][r]))));
+    if constexpr (LL == 16) {
+      hb = fmaxf(hb, dpp_mov<0x124>(hb));
+      hb = fmaxf(hb, dpp_mov<0x128>(hb));
+    }
+    hb = half_max(row_pair_max(hb));
+    if (kq == 0 && (LL != 16 || (cl >> 2) == 0)) ((lds_f *)(c.lds + GG::kMiscHb))[c.wave * 16 + sm] = hb;   // shadow waves too
+  }
   GLDM_WV_STAMP(c, 4, (long long)__builtin_readcyclecounter());
   __syncthreads();
   GLDM_WV_STAMP(c, 5, (long long)__builtin_readcyclecounter());
+  float hinv = 1.0f;   // block1: 1 / hs of this lane's sample
+  if constexpr (FIN == 1) {
+    const lds_f *hbp = (const lds_f *)(c.lds + GG::kMiscHb) + sm;
+    float hb = hbp[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) hb = fmaxf(hb, hbp[16 * q]);
+    // hb in [2^k, 2^(k+1)): hs = 2^max(0, k - 14) puts H / hs below 2^15
+    int e = (int)((__float_as_uint(hb) >> 23) & 0xffu) - 127 - 14;
+    e = e < 0 ? 0 : e;
+    hinv = __uint_as_float((unsigned)(127 - e) << 23);
+    if (c.wave == 0 && kq == 0 && (LL != 16 || (cl >> 2) == 0)) hsc[sm] = __uint_as_float((unsigned)(127 + e) << 23);
+  }
   float tot = 0.f, ps1[kParts], ps2[kParts];
 #pragma unroll
   for (int q = 0; q < kParts; ++q) {
@@ -1358,7 +1409,9 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
     const float dm = ps1[q] * (1.0f / (float)kNloc) - mean;
     m2 += ps2[q] + (float)kNloc * dm * dm;
   }
-  const float rstd = __builtin_amdgcn_rsqf(m2 * (1.0f / (float)(kNloc * kParts)) + 1e-5f);
+  // block2: the accumulators hold conv / hs: the true variance is hs^2 times theirs, and (acc - mean') hs rstd is the
+  // normalised value (hs = 1: the same bits as without it)
+  const float rstd = __builtin_amdgcn_rsqf((m2 * hs) * hs * (1.0f / (float)(kNloc * kParts)) + 1e-5f) * hs;
   // mode 1 (block1): H = y, as planes only (H is only ever a conv input);
   // mode 2 (block2): X += y in f32 (the residual stream), plus the planes of the new X up to 128 channels; at 256
   // channels X = parked + y as f32 rows only (what follows is the final 1x1 conv).
@@ -1410,7 +1463,7 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
             else t = d3[a] + t;
             d3[a] = t;
           }
-          y[r] = t;
+          y[r] = kMode == 1 ? t * hinv : t;
         }
         if constexpr (!(kMode == 2 && kWide))
           store_planes4<LL>(c.lds + (kMode == 2 ? PGx::kX : (kWide ? PGx::kW : PGx::kH)), 16 * (mt0 + mi) + 4 * kq,
@@ -1780,7 +1833,7 @@ __device__ __forceinline__ void column_stats8(const Ctx &c, const float *src, fl
 //     are in-lane; the sums over d (32 channels of the head) are in-lane over the lane's 4 channels, permlane swaps over
 //     the four row quarters, and ONE exchange through LDS between the two waves of the head: each publishes
 //     (max, sum, A) taken over its own 16 channels and merges the partner's like two blocks of an online softmax.
-//   * The output leaves as split-bf16 planes (it is only ever the B operand of to_out), into the H-plane region.
+//   * The output leaves as split-f16 planes (it is only ever the B operand of to_out), into the H-plane region.
 // Barriers: statistics, exchange, end (the two phases this replaces had five).
 constexpr int kAttExch = 512 * 64;   // floats [32768, 35840): 8 waves x 24 rows x 16 samples, behind the X planes
 static_assert(kAttExch + 8 * 24 * 16 <= Geo<64>::kArena, "attention exchange slots");
@@ -2716,7 +2769,7 @@ __host__ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *
            last_of_pair ? 1 : 0);
       return;
     }
-    // the position-major engine reads the split-bf16 copies of the conv weights (gemm_pm3_bf)
+    // the position-major engine reads the split-f16 copies of the conv weights (gemm_pm3_bf)
     emit(OP_CONV, NC == 64 ? rb.c1_w3 : rb.c1_w, rb.c1_b, X, H, C, C,
          3 | (1 << 9) | (NC == 64 ? kFlagFused : 0) | ((toff >> 2) << kFlagTabShift), rb.n1_w, rb.n1_b, rb.ss_w, rb.ss_b);
     emit(OP_CONV, NC == 64 ? rb.c2_w3 : rb.c2_w, rb.c2_b, H, X, C, C, 3 | (2 << 9), rb.n2_w, rb.n2_b, -1, 0);  // X += act(GN(conv(H)))
@@ -3350,7 +3403,7 @@ bool pm_supported(const gldm_r1d_desc *d) {
   if (d->dims[0] != 4) return false;
   for (int i = 0; i < d->n_levels; ++i)  // to_qkv with the PreNorm gain folded in (ABI 4 packers provide it)
     if (d->lv[i].qkvn_w <= 0 || d->lv[i].qkvn_s <= 0) return false;
-  for (int i = 1; i < d->n_levels; ++i)  // split-bf16 conv weights (ABI 5 packers provide them)
+  for (int i = 1; i < d->n_levels; ++i)  // split-f16 conv weights (ABI 5 packers provide them)
     if (d->lv[i].down_w3 <= 0 || d->lv[i].qkvn_w3 <= 0 || d->lv[i].out_w3 <= 0 || d->rb[2 * i].c1_w3 <= 0 || d->rb[2 * i].c2_w3 <= 0 || d->rb[2 * i + 1].c1_w3 <= 0 ||
         d->rb[2 * i + 1].c2_w3 <= 0)
       return false;
@@ -3364,9 +3417,9 @@ bool pm_supported(const gldm_r1d_desc *d) {
 }
 
 // The 16-position 64-column engine (r1d_kernel<64, 16>: tiles of 4 samples x 16 positions, column = 4 * position +
-// sample, split-bf16 GEMMs on pre-split planes) serves the nets both shipped experiments run at 16 positions: the pose
+// sample, split-f16 GEMMs on pre-split planes) serves the nets both shipped experiments run at 16 positions: the pose
 // decoder (latent_dim > 0, heads) and the ppc experiment's latent denoiser.  emb_dim 64, a 16-channel first level
-// and 32..256-channel ones after it, every split-bf16 weight copy present (ABI 5 packers; 16-channel levels zero-padded
+// and 32..256-channel ones after it, every split-f16 weight copy present (ABI 5 packers; 16-channel levels zero-padded
 // to one 32-channel block: r1d_pack.pad_cin32).
 bool pm16_supported(const gldm_r1d_desc *d) {
   if (d->seq_len != 16 || d->emb_dim != 64 || d->groups != 4 || d->dims[0] != 16 || d->cond_rows > 4) return false;
@@ -3563,9 +3616,9 @@ struct PwArgs {
   // optional layer in front (x [b, cin0, n] -> relu(W0 x + b0) = the [cin][32] tile of the main layer, never in HBM)
   const float *w0, *bias0;
   int cin0;
-  int dyn_first;   // split-bf16 kernel: units (pairs of m-tiles) >= dyn_first are handed out at run time
+  int dyn_first;   // split-f16 kernel: units (pairs of m-tiles) >= dyn_first are handed out at run time
   int ticket_off;  // ... from a ticket at this float index of the LDS plan
-  // split-bf16 kernel, ADD instantiation: an addend in front of the activation, add[cloud * add_bs + row * add_rs + col * add_cs]
+  // split-f16 kernel, ADD instantiation: an addend in front of the activation, add[cloud * add_bs + row * add_rs + col * add_cs]
   // (a per-cloud bias: bs = cout, rs = 1, cs = 0; a [b, cout, n] tensor: bs = cout * n, rs = n, cs = 1)
   const float *add;
   long long add_bs, add_rs, add_cs;
@@ -3677,9 +3730,9 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
   }
 }
 
-// ---- the same layer(s) on split-bf16 operands -------------------------------------------------------------------------
+// ---- the same layer(s) on split-f16 operands -------------------------------------------------------------------------
 // pointwise_mlp_kernel with the main GEMM on v_mfma_f32_16x16x32_bf16 (6 partial products per f32 product, see the
-// split-bf16 core of the position-major engine): weights pre-split on the host (mfma_a_fragments_bf16x3), the [cin][32]
+// split-f16 core of the position-major engine): weights pre-split on the host (mfma_a_fragments_f16x2), the [cin][32]
 // input tile split ONCE while it is staged and kept in LDS as B-fragment planes
 //   [32-channel block][plane hi|mid|lo][g][32 columns][8 bf16]      (6 KiB per block; cin = 768: 144 KiB)
 // so the eight waves' k-loops are ds_read_b128 + buffer loads + MFMA.  A 32-column tile re-uses a weight fragment
@@ -3703,7 +3756,7 @@ __device__ __forceinline__ void store_planes4_32(float *planes, int c0, int n, f
   d[256] = u32x2_t{l0, l1};   // next plane: 4 * 32 * 4 dwords
 }
 
-// The layer in front of the split-bf16 main layer, on the same pipe: x0 = the f32 [cin0][32] tile (swizzled), w0s =
+// The layer in front of the split-f16 main layer, on the same pipe: x0 = the f32 [cin0][32] tile (swizzled), w0s =
 // split fragments of W0 [cin x cin0], KB0 = cin0 / 32.  A wave splits the whole tile ONCE into registers (its B planes
 // serve all of the wave's m-tiles) and walks its m-tiles in pairs; the A registers of a (m-tile, block) are refilled
 // with the next pair's fragments as soon as its MFMAs have issued.  Output: ReLU, split, into the main layer's planes.
@@ -3769,13 +3822,13 @@ __device__ long long g_pw_stamp[64];
 #define GLDM_PW_STAMP(i) do {} while (0)
 #endif
 template <bool ADD>
-__global__ __launch_bounds__(512, 2) void pointwise_mlp_bf_kernel(const PwArgs a) {
+__global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a) {
   constexpr int NC = 32;
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kq = lane >> 4;
-  const int kb32 = a.cin >> 5, mtiles = a.cout >> 4, mt_per_wave = mtiles >> 3;
+  const int kb32 = a.cin >> 5, mtiles = a.cout >> 4;
   float *planes = lds;                       // [kb32][kSplit][4][32][4 dwords]
   float *zpart = lds;                        // [8 waves][16 rows][32 cols], over the planes once they are dead
   float *x0 = lds + a.cin * 16 * kSplit;     // front layer's f32 input tile [cin0][32] behind the planes (cin / 32 blocks x kSplit x 512 floats)
@@ -4136,10 +4189,10 @@ __global__ __launch_bounds__(512, 1) void sa_mlp2_kernel(const SaArgs a, int row
 }
 
 
-// ======================================================== fused set abstraction on split-bf16 planes ==
+// ======================================================== fused set abstraction on split-f16 planes ==
 // The same module core (gather + grouped MLP + max over the neighbours, ext/pvcnn/modules/pointnet.py:100-111) with the
 // GEMMs on the bf16 matrix pipe: every f32 product as six bf16 partial products (hi / mid / lo splits of both operands,
-// f32 accumulation: see the split-bf16 core above), 6/16 of the f32-MFMA time.  A tile is 64 columns = 64 / U centres x U
+// f32 accumulation: see the split-f16 core above), 6/16 of the f32-MFMA time.  A tile is 64 columns = 64 / U centres x U
 // neighbours; the gathered tile and every hidden layer's output live in LDS as pre-split planes in B-fragment order
 // (the position-major engine's geometry: 12 KiB per 32 channels), written once by their producer (the gather threads hold
 // four consecutive channels of a column; a layer's epilogue its accumulators' four consecutive rows), so the k-loops are
@@ -4558,24 +4611,24 @@ GLDM_API int gldm_pose_epilogue(const float *tmrp, const float *logit, const flo
 namespace {
 int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0, const float *w, const float *bias, int b,
                      int cin, int cout, int n, int relu, const float *head_w, const float *head_b, int hout, float *y,
-                     float *z, hipStream_t stream, bool split_bf16 = false, const float *add = nullptr, long long add_bs = 0,
+                     float *z, hipStream_t stream, bool split_f16 = false, const float *add = nullptr, long long add_bs = 0,
                      long long add_rs = 0, long long add_cs = 0) {
-  if (add && !split_bf16) return GLDM_ERR_UNSUPPORTED;
+  if (add && !split_f16) return GLDM_ERR_UNSUPPORTED;
   if (!x || !w || !bias || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
   if (!y && !head_w) return GLDM_ERR_INVALID_ARG;
   if (head_w && (!z || hout <= 0 || hout > 16)) return GLDM_ERR_INVALID_ARG;
   // k-blocks in pairs, 32-point tiles; output rows: 2 m-tiles x 8 waves per round on the f32 kernel, units of two m-tiles on
   // the split one (fewer than eight units -- 64 .. 224 output rows -- leave waves without a unit idle)
-  if ((cin & 31) || (n & 31) || (split_bf16 ? (cout & 31) : (cout & 255))) return GLDM_ERR_UNSUPPORTED;
+  if ((cin & 31) || (n & 31) || (split_f16 ? (cout & 31) : (cout & 255))) return GLDM_ERR_UNSUPPORTED;
   if ((w0 || head_w) && (cout & 255)) return GLDM_ERR_UNSUPPORTED;   // front layer / head: whole rounds of units only
   if (w0 && (!b0 || cin0 <= 0 || (cin0 & 31) || (cin & 255))) return GLDM_ERR_UNSUPPORTED;
   size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
-  if (split_bf16) {  // `w` and `w0` hold split-bf16 fragments: planes of the tile + the front layer's f32 tile
+  if (split_f16) {  // `w` and `w0` hold split-f16 fragments: planes of the tile + the front layer's f32 tile
     if (cin & 127) return GLDM_ERR_UNSUPPORTED;  // the A ring walks four 32-deep blocks per trip
     if (w0 && cin0 > 96) return GLDM_ERR_UNSUPPORTED;  // the front layer keeps its whole split tile in registers (72)
   }
   int dyn_first = 0, ticket_off = 0;
-  if (split_bf16) {
+  if (split_f16) {
     // LDS plan: planes | front tile, later the head products of the drawn units | ticket.  As many units are drawn as
     // have room for their head slot (all but the first round when there is no head).
     const size_t planes = (size_t)cin * 16 * kSplit * sizeof(float), cap = (size_t)160 * 1024 - 16;
@@ -4599,8 +4652,8 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   struct PwTag { int site; };
   struct PwBfTag { int site; };
   struct PwBfAddTag { int site; };
-  if (split_bf16 && add) gldm_dev::allow_dynamic_lds<PwBfAddTag>(reinterpret_cast<const void *>(&pointwise_mlp_bf_kernel<true>), 160 * 1024);
-  else if (split_bf16) gldm_dev::allow_dynamic_lds<PwBfTag>(reinterpret_cast<const void *>(&pointwise_mlp_bf_kernel<false>), 160 * 1024);
+  if (split_f16 && add) gldm_dev::allow_dynamic_lds<PwBfAddTag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<true>), 160 * 1024);
+  else if (split_f16) gldm_dev::allow_dynamic_lds<PwBfTag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<false>), 160 * 1024);
   else gldm_dev::allow_dynamic_lds<PwTag>(reinterpret_cast<const void *>(&pointwise_mlp_kernel), 160 * 1024);
   PwArgs a{};
   a.x = x; a.w = w; a.bias = bias; a.head_w = head_w; a.head_b = head_b; a.y = y; a.z = z;
@@ -4613,11 +4666,11 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
   int grid = cu_count() * per_cu;
   if (grid > a.total_tiles) grid = a.total_tiles;
-  if (split_bf16 && add) hipLaunchKernelGGL(pointwise_mlp_bf_kernel<true>, dim3(grid), dim3(512), lds_bytes, stream, a);
-  else if (split_bf16) hipLaunchKernelGGL(pointwise_mlp_bf_kernel<false>, dim3(grid), dim3(512), lds_bytes, stream, a);
+  if (split_f16 && add) hipLaunchKernelGGL(pointwise_mlp_sp_kernel<true>, dim3(grid), dim3(512), lds_bytes, stream, a);
+  else if (split_f16) hipLaunchKernelGGL(pointwise_mlp_sp_kernel<false>, dim3(grid), dim3(512), lds_bytes, stream, a);
   else hipLaunchKernelGGL(pointwise_mlp_kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
 #ifdef GLDM_DEBUG_KNOBS
-  if (split_bf16 && getenv("GLDM_PW_STAMP")) {   // diagnostic builds: phase clocks of one steady-state tile (waves 0 and 7)
+  if (split_f16 && getenv("GLDM_PW_STAMP")) {   // diagnostic builds: phase clocks of one steady-state tile (waves 0 and 7)
     long long h[64];
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pw_stamp), sizeof(h));
@@ -4649,14 +4702,14 @@ GLDM_API int gldm_pointwise_mlp2(const float *x, const float *w0_packed, const f
                           hout, y, z, reinterpret_cast<hipStream_t>(stream));
 }
 
-GLDM_API int gldm_pointwise_mlp_bf16x3(const float *x, const float *w_split, const float *bias, int b, int cin, int cout,
+GLDM_API int gldm_pointwise_mlp_f16x2(const float *x, const float *w_split, const float *bias, int b, int cin, int cout,
                                        int n, int relu, const float *head_w_packed, const float *head_bias, int hout,
                                        float *y, float *z, gldm_stream_t stream) {
   return launch_pointwise(x, nullptr, nullptr, 0, w_split, bias, b, cin, cout, n, relu, head_w_packed, head_bias, hout,
                           y, z, reinterpret_cast<hipStream_t>(stream), true);
 }
 
-GLDM_API int gldm_pointwise_mlp_bf16x3_add(const float *x, const float *w_split, const float *bias, const float *add,
+GLDM_API int gldm_pointwise_mlp_f16x2_add(const float *x, const float *w_split, const float *bias, const float *add,
                                            long long add_cloud_stride, long long add_row_stride, long long add_col_stride, int b,
                                            int cin, int cout, int n, int relu, float *y, gldm_stream_t stream) {
   if (!add) return GLDM_ERR_INVALID_ARG;
@@ -4664,7 +4717,7 @@ GLDM_API int gldm_pointwise_mlp_bf16x3_add(const float *x, const float *w_split,
                           reinterpret_cast<hipStream_t>(stream), true, add, add_cloud_stride, add_row_stride, add_col_stride);
 }
 
-GLDM_API int gldm_pointwise_mlp2_bf16x3(const float *x, const float *w0_packed, const float *bias0, int cin0,
+GLDM_API int gldm_pointwise_mlp2_f16x2(const float *x, const float *w0_packed, const float *bias0, int cin0,
                                         const float *w_split, const float *bias, int b, int cin, int cout, int n,
                                         const float *head_w_packed, const float *head_bias, int hout, float *y, float *z,
                                         gldm_stream_t stream) {
@@ -4673,7 +4726,7 @@ GLDM_API int gldm_pointwise_mlp2_bf16x3(const float *x, const float *w0_packed, 
                           hout, y, z, reinterpret_cast<hipStream_t>(stream), true);
 }
 
-GLDM_API int gldm_sa_mlp_forward_bf16x3(const float *points, const float *centers, const float *features,
+GLDM_API int gldm_sa_mlp_forward_f16x2(const float *points, const float *centers, const float *features,
                                         const int32_t *idx, const float *weights, int b, int c, int n, int m, int u,
                                         int n_layers, const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off,
                                         const int32_t *b_off, float *out, gldm_stream_t stream) {

@@ -318,44 +318,38 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3d_k3_kernel(const float 
   GLDM_C3_STAMP(21);
 }
 
-// ---- the same conv on split-bf16 operands (the shipped encoder's two shapes: 48 ch @ 24^3 and 96 ch @ 12^3) ------------
+// ---- the same conv on split-f16 operands (the shipped encoder's two shapes: 48 ch @ 24^3 and 96 ch @ 12^3) ------------
 // v_mfma_f32_16x16x32_bf16 with every f32 operand written as hi + mid + lo (three bf16 numbers, exact) and the six
 // partial products of weight >= 2^-16 accumulated in f32: the error of an f32 rounding per product at 6/16 of the
-// f32-MFMA time (see csrc/resnet1d.hip, "split-bf16 GEMM core").  K is walked as (16-channel block, PAIR of taps):
+// f32-MFMA time (see csrc/resnet1d.hip, "split-f16 GEMM core").  K is walked as (16-channel block, PAIR of taps):
 // lane group g of a fragment = (tap 2 p + (g >> 1), channels 8 (g & 1) .. + 7); 27 taps = 13 pairs + one half-empty
 // (zero weights).  Work is walked in groups of 3 m-tiles x 3 n-tiles so that the A sets (double buffered), the B planes
-// and the accumulators fit 256 registers.  Weights: graspldm_amd/voxel.py: pack_conv3d_bf16x3.
+// and the accumulators fit 256 registers.  Weights: graspldm_amd/voxel.py: pack_conv3d_f16x2.
 // (First form, measured and replaced: the brick kept f32 in LDS, every lane splitting its 8 channels of a voxel again
 // for each (tap pair, n-tile): 2.4 / 0.9 ms per launch at 256 clouds against 2.1 / 0.8 with the pre-split planes below,
 // 3.55 / 1.25 on the f32 pipe.)
-typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 c3_bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 c3_f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 c3_f16x2;
 typedef __attribute__((ext_vector_type(2))) float c3_f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned c3_u32x4;
+constexpr int kC3Split = 2;   // planes per operand: hi | lo (f16)
 
-__device__ __forceinline__ unsigned c3_cvt_pk(float a, float b) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(c3_f32x2{a, b}, c3_bf16x2));
-}
-__device__ __forceinline__ void c3_split(const float (&x)[8], c3_u32x4 (&pl)[3]) {
+// x[0..7] -> the hi and lo planes of a fragment: x = hi + lo up to 2^-22 |x| (the matrix pipe keeps f16 subnormals)
+__device__ __forceinline__ void c3_split(const float (&x)[8], c3_u32x4 (&pl)[kC3Split]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float a = x[2 * q], b = x[2 * q + 1];
-    const unsigned h = c3_cvt_pk(a, b);
-    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-    const unsigned m = c3_cvt_pk(ra, rb);
-    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
-    pl[0][q] = h;
-    pl[1][q] = m;
-    pl[2][q] = c3_cvt_pk(sa, sb);
+    const c3_f16x2 h = __builtin_convertvector(c3_f32x2{a, b}, c3_f16x2);
+    const float ra = __builtin_fmaf((float)h[0], -1.0f, a), rb = __builtin_fmaf((float)h[1], -1.0f, b);
+    pl[0][q] = __builtin_bit_cast(unsigned, h);
+    pl[1][q] = __builtin_bit_cast(unsigned, __builtin_convertvector(c3_f32x2{ra, rb}, c3_f16x2));
   }
 }
 __device__ __forceinline__ f32x4 c3_mfma(const c3_u32x4 &a, const c3_u32x4 &b, const f32x4 &c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(c3_bf16x8, a), __builtin_bit_cast(c3_bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(c3_f16x8, a), __builtin_bit_cast(c3_f16x8, b), c, 0, 0, 0);
 }
-__device__ __forceinline__ f32x4 c3_mfma6(const c3_u32x4 (&a)[3], const c3_u32x4 (&b)[3], f32x4 acc) {
-  acc = c3_mfma(a[0], b[2], acc);
-  acc = c3_mfma(a[2], b[0], acc);
-  acc = c3_mfma(a[1], b[1], acc);
+// acc += A B, both operands split: the three partial products, small terms first
+__device__ __forceinline__ f32x4 c3_mfma3(const c3_u32x4 (&a)[kC3Split], const c3_u32x4 (&b)[kC3Split], f32x4 acc) {
   acc = c3_mfma(a[0], b[1], acc);
   acc = c3_mfma(a[1], b[0], acc);
   return c3_mfma(a[0], b[0], acc);
@@ -363,7 +357,7 @@ __device__ __forceinline__ f32x4 c3_mfma6(const c3_u32x4 (&a)[3], const c3_u32x4
 
 constexpr int kPairs = 14;  // tap pairs per 16-channel block (the last one holds tap 26 and zeros)
 
-// ---- split-bf16 conv with the brick PRE-SPLIT in LDS --------------------------------------------------------------------
+// ---- split-f16 conv with the brick PRE-SPLIT in LDS --------------------------------------------------------------------
 // Splitting a lane's 8 channels of a voxel for every (tap pair, n-tile) that touches it means ~27 splits per element
 // and wave, 36 VALU instructions per 18-36 MFMAs, with the two waves of a SIMD doing it in lock step.  Here the
 // staging threads split each brick element ONCE and keep the three bf16 planes in LDS, channel-minor:
@@ -459,7 +453,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
     for (int q = 0; q < kRounds; ++q)
       if (s_lds[q] >= 0 && s_glb[q] < 0) {
 #pragma unroll
-        for (int p3 = 0; p3 < 3; ++p3) pl[p3 * 2 * hs + s_lds[q]] = z4;
+        for (int p3 = 0; p3 < kC3Split; ++p3) pl[p3 * 2 * hs + s_lds[q]] = z4;
       }
   }
   float stg[kRounds][8];
@@ -474,7 +468,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   };
   // ACT: (a, s) of every input channel of this cloud, behind the planes (the launcher adds the room): read back as
   // wave-wide broadcasts of four 16-byte pairs-of-pairs per staged item
-  float *s_coef = lds + 3 * 2 * hs * 4;   // [cin][2]
+  float *s_coef = lds + kC3Split * 2 * hs * 4;   // [cin][2]
   if constexpr (ACT) {
     for (int i = tid; i < 2 * cin; i += kThreads) s_coef[i] = in_coef[(size_t)b * cin * 2 + i];
   }
@@ -493,10 +487,10 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
             stg[q][2 * j2 + 1] = t1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * t1));
           }
         }
-        c3_u32x4 p3[3];
+        c3_u32x4 p3[kC3Split];
         c3_split(stg[q], p3);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pl[k * 2 * hs + s_lds[q]] = p3[k];
+        for (int k = 0; k < kC3Split; ++k) pl[k * 2 * hs + s_lds[q]] = p3[k];
       }
   };
   GLDM_C3_STAMP(1);
@@ -511,21 +505,21 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
     if (cb < 3) GLDM_C3_STAMP(4 + 4 * cb);
     __syncthreads();
     if (cb < 3) GLDM_C3_STAMP(5 + 4 * cb);
-    c3_u32x4 a[2][3][3];
+    c3_u32x4 a[2][3][kC3Split];
     auto load_a = [&](int buf, int step) {   // step = pair * MG + mg
       const int p = step / MG, mg = step - p * MG;
 #pragma unroll
       for (int mi = 0; mi < 3; ++mi)
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-          a[buf][mi][k] = wv.raw_at((((3 * mg + mi) * kblocks + cb * kPairs + p) * 3) * 1024, k * 1024);
+        for (int k = 0; k < kC3Split; ++k)
+          a[buf][mi][k] = wv.raw_at((((3 * mg + mi) * kblocks + cb * kPairs + p) * kC3Split) * 1024, k * 1024);
     };
     load_a(0, 0);
     __builtin_amdgcn_s_setprio(0);
     constexpr int kSteps = kPairs * MG;
     constexpr int kUnits = kPairs * NG;   // (pair, n-group) units: the B planes of unit u + 1 are requested during unit u
     constexpr bool kBPre = NG > 1;   // a second B set costs 36 registers: only where a wave has two n-groups
-    c3_u32x4 bs[kBPre ? 2 : 1][3][3];
+    c3_u32x4 bs[kBPre ? 2 : 1][3][kC3Split];
     auto load_b = [&](int buf, int unit) {
       const int p = unit / NG, ng = unit - p * NG;
       const int ta = 2 * p, tb = 2 * p + 1 < 27 ? 2 * p + 1 : 26;
@@ -534,7 +528,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
 #pragma unroll
       for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) bs[buf][q][k] = pl[k * 2 * hs + vb[3 * ng + q] + toff];
+        for (int k = 0; k < kC3Split; ++k) bs[buf][q][k] = pl[k * 2 * hs + vb[3 * ng + q] + toff];
     };
     if (kBPre) load_b(0, 0);
     for (int p0 = 0; p0 < kPairs; p0 += 2) {
@@ -558,7 +552,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
             for (int mi = 0; mi < 3; ++mi)
 #pragma unroll
               for (int q = 0; q < 3; ++q)
-                acc[3 * mg + mi][3 * ng + q] = c3_mfma6(a[cur][mi], bs[bcur][q], acc[3 * mg + mi][3 * ng + q]);
+                acc[3 * mg + mi][3 * ng + q] = c3_mfma3(a[cur][mi], bs[bcur][q], acc[3 * mg + mi][3 * ng + q]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -626,7 +620,7 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   GLDM_C3_STAMP(21);
 }
 
-// ---- split-bf16 conv of a FEW input channels (the encoder's first voxel conv: 3 -> 48 at 24^3) ------------------------
+// ---- split-f16 conv of a FEW input channels (the encoder's first voxel conv: 3 -> 48 at 24^3) ------------------------
 // With k = tap * 16 + ci (conv3d_k3_kernel, JN = 1) a 3-channel input pays 27 k-steps of 4 on the f32 pipe for 81 real
 // products per output: 0.49 ms per 256 clouds at 0.55 matrix-pipe occupancy, for a tensor whose store takes 0.1 ms.  Here
 // K is packed tap-major, channel-minor without padding between taps: k = tap * CIN + ci < 27 CIN, rounded up ONCE to a
@@ -637,9 +631,9 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
 // brick, R / 8 n-tiles per wave, 117 registers: two workgroups per CU; the haloed input brick is CIN x 6 x 6 x (R + 2)
 // floats (11 KiB at R = 24).  0.32 ms.  (Measured and dropped: persistent workgroups with the weight planes in LDS and the
 // next brick's input requested under the current k-loop -- 216 registers, one workgroup per CU: 0.41 ms; the same with
-// two 4-wave workgroups per CU spills: 0.59 ms.)  Weights: graspldm_amd/voxel.py: pack_conv3d_fewch_bf16x3.
+// two 4-wave workgroups per CU spills: 0.59 ms.)  Weights: graspldm_amd/voxel.py: pack_conv3d_fewch_f16x2.
 template <int MT, int R, int CIN, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 4) void conv3d_k3_fewch_bf_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(64 * WAVES, 4) void conv3d_k3_fewch_sp_kernel(const float *__restrict__ x,
                                                                            const float *__restrict__ wp3,
                                                                            const float *__restrict__ bias,
                                                                            float *__restrict__ y,
@@ -686,11 +680,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv3d_k3_fewch_bf_kernel(const
   __syncthreads();
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
-    c3_u32x4 a[MT][3];
+    c3_u32x4 a[MT][kC3Split];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[mi][pl] = wv.raw_at(((mi * KB + kb) * 3) * 1024, pl * 1024);
+      for (int pl = 0; pl < kC3Split; ++pl) a[mi][pl] = wv.raw_at(((mi * KB + kb) * kC3Split) * 1024, pl * 1024);
     int off[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -709,10 +703,10 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv3d_k3_fewch_bf_kernel(const
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[(ni + 1) & 1][j] = l3[vb[ni + 1] + off[j]];
       }
-      c3_u32x4 b3[3];
+      c3_u32x4 b3[kC3Split];
       c3_split(v[ni & 1], b3);
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = c3_mfma6(a[mi], b3, acc[mi][ni]);
+      for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = c3_mfma3(a[mi], b3, acc[mi][ni]);
     }
   }
   // ---- epilogue: per-channel partial statistics of this brick, then the stores (as in conv3d_k3_pl_kernel)
@@ -1338,7 +1332,7 @@ GLDM_API int gldm_conv3d_k3_cl(const float *x, const float *w_packed, const floa
 template <int MT, int R, int ZB, int WAVES, bool ACT>
 int launch_conv_pl_act(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
                        const float *in_coef, int out_cl, hipStream_t s) {
-  const size_t lds_bytes = (size_t)3 * 2 * ((36 * (ZB + 2) + 15) & ~15) * 16 + (ACT ? (size_t)2 * cin * sizeof(float) : 0);
+  const size_t lds_bytes = (size_t)kC3Split * 2 * ((36 * (ZB + 2) + 15) & ~15) * 16 + (ACT ? (size_t)2 * cin * sizeof(float) : 0);
   struct Tag {};
   gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_pl_kernel<MT, R, ZB, WAVES, ACT>), (int)lds_bytes);
   const int bpr = R / kBrick;
@@ -1356,7 +1350,7 @@ int launch_conv_pl(const float *x, const float *wp3, const float *bias, int b, i
                  : launch_conv_pl_act<MT, R, ZB, WAVES, false>(x, wp3, bias, b, cin, cout, y, partial, nullptr, out_cl, s);
 }
 
-static int conv3d_k3_bf16x3_impl(const float *x, const float *in_coef, const float *w_split, const float *bias, int b, int cin,
+static int conv3d_k3_f16x2_impl(const float *x, const float *in_coef, const float *w_split, const float *bias, int b, int cin,
                                  int cout, int r, float *y, float *partial, int out_cl, gldm_stream_t stream) {
   if (!x || !w_split || !bias || !y || !partial || b <= 0 || cin <= 0 || cout <= 0 || r <= 0) return GLDM_ERR_INVALID_ARG;
   if ((in_coef || out_cl) && cin % 16) return GLDM_ERR_UNSUPPORTED;   // both live in the plane-staging kernels
@@ -1364,7 +1358,7 @@ static int conv3d_k3_bf16x3_impl(const float *x, const float *in_coef, const flo
   if (cin == 3 && cout == 48 && r == 24) {   // the first voxel conv: K = 81 packed into three k-blocks
     constexpr int kZp = 26, kNvox = 36 * kZp;
     const size_t lds_bytes = (size_t)3 * (kNvox + ((kNvox & 31) == 0 ? 8 : 0)) * sizeof(float);
-    hipLaunchKernelGGL((conv3d_k3_fewch_bf_kernel<3, 24, 3, 8>), dim3(36, b), dim3(512), lds_bytes, s, x, w_split, bias, y, partial);
+    hipLaunchKernelGGL((conv3d_k3_fewch_sp_kernel<3, 24, 3, 8>), dim3(36, b), dim3(512), lds_bytes, s, x, w_split, bias, y, partial);
     return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
   }
   if (cin % 16 || cout % 48) return GLDM_ERR_UNSUPPORTED;   // the kernels below: cout == 16 MT exactly, no row guards
@@ -1392,15 +1386,15 @@ static int conv3d_k3_bf16x3_impl(const float *x, const float *in_coef, const flo
   return GLDM_ERR_UNSUPPORTED;
 }
 
-GLDM_API int gldm_conv3d_k3_bf16x3(const float *x, const float *w_split, const float *bias, int b, int cin, int cout, int r,
+GLDM_API int gldm_conv3d_k3_f16x2(const float *x, const float *w_split, const float *bias, int b, int cin, int cout, int r,
                                    float *y, float *partial, gldm_stream_t stream) {
-  return conv3d_k3_bf16x3_impl(x, nullptr, w_split, bias, b, cin, cout, r, y, partial, 0, stream);
+  return conv3d_k3_f16x2_impl(x, nullptr, w_split, bias, b, cin, cout, r, y, partial, 0, stream);
 }
 
-GLDM_API int gldm_conv3d_k3_bf16x3_gn(const float *x, const float *in_coef, const float *w_split, const float *bias, int b,
+GLDM_API int gldm_conv3d_k3_f16x2_gn(const float *x, const float *in_coef, const float *w_split, const float *bias, int b,
                                       int cin, int cout, int r, float *y, float *partial, int out_channel_last,
                                       gldm_stream_t stream) {
-  return conv3d_k3_bf16x3_impl(x, in_coef, w_split, bias, b, cin, cout, r, y, partial, out_channel_last ? 1 : 0, stream);
+  return conv3d_k3_f16x2_impl(x, in_coef, w_split, bias, b, cin, cout, r, y, partial, out_channel_last ? 1 : 0, stream);
 }
 
 GLDM_API int gldm_groupnorm_coef(const float *partial, const float *gamma, const float *beta, int b, int c, int r, int groups,

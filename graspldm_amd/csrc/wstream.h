@@ -23,7 +23,7 @@ struct WStream {
     r = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7FFFFFFF, 0x00020000);
     v = lane * 16;
   }
-  // the same fragment as raw bits (split-bf16 planes: 8 bf16 per lane)
+  // the same fragment as raw bits (split-f16 planes: 8 bf16 per lane)
   __device__ __forceinline__ wstream_u32x4 raw(size_t i) const {
     return __builtin_bit_cast(wstream_u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v, (int)(i * 16), 0));
   }

@@ -1,5 +1,5 @@
 """Dense k = 1 layers of the point-cloud encoders: every one of them a hand-written launch, on every encoder.  Shipped
-PVCNN encoder: the wide SharedMLP layers + head (gldm_pointwise_mlp*: MFMA GEMMs, the 768 -> 1536 one on split-bf16
+PVCNN encoder: the wide SharedMLP layers + head (gldm_pointwise_mlp*: MFMA GEMMs, the 768 -> 1536 one on split-f16
 operands), the narrow point-branch convs (gldm_pointwise_small) and the Linear over the point axis (gldm_linear_rows).
 Layer shapes outside those kernels' sets (PVCNN2 / PointNet++ widths such as 384 -> 256 over 128 centres) run in the
 any-shape f32-MFMA kernel (gldm_pointwise_any); since round 4 nothing here reaches rocBLAS / MIOpen, and the package no
@@ -54,7 +54,7 @@ def pack_head(wh):
 
 
 def split_supported(cin, cin0=0):
-    """The split-bf16 form of the fused launch (gldm_pointwise_mlp*_bf16x3): A ring of four 32-deep blocks, the tile
+    """The split-f16 form of the fused launch (gldm_pointwise_mlp*_f16x2): A ring of four 32-deep blocks, the tile
     as planes (48 floats per channel) + the front layer's f32 tile (split once per wave into registers: cin0 <= 96)."""
     return cin % 128 == 0 and cin0 % 32 == 0 and cin0 <= 96 and 4 * (48 * cin + 32 * cin0) + 16 <= 160 * 1024
 
@@ -65,7 +65,7 @@ def fused_mlp_supported(x, cin, cout):
 
 
 def split_mlp_supported(x, cin, cout):
-    """The split-bf16 launch on its own (gldm_pointwise_mlp_bf16x3): output rows in units of 32 (fewer than 256 leave waves
+    """The split-f16 launch on its own (gldm_pointwise_mlp_f16x2): output rows in units of 32 (fewer than 256 leave waves
     idle, still several times the any-shape kernel's rate: the 128-row feature-propagation layers of PointNet++ / PVCNN2)."""
     return (x.ndim == 3 and x.is_contiguous() and cout % 32 == 0 and cout >= 64 and x.shape[-1] % 32 == 0
             and split_supported(cin))
@@ -79,9 +79,9 @@ def fused_mlp2_supported(x, cin0, cin, cout):
 
 def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True, front=None, split=False):
     """One fused launch: y = act(W x + b) over [B, Cin, N] (hand-written MFMA GEMM, csrc/resnet1d.hip:
-    pointwise_mlp_kernel / pointwise_mlp_bf_kernel) and optionally z = Wh y + bh on the accumulators.
+    pointwise_mlp_kernel / pointwise_mlp_sp_kernel) and optionally z = Wh y + bh on the accumulators.
     head = (packed Wh, bh, hout).  front = (packed W0, b0, cin): a ReLU layer x -> relu(W0 x + b0) in front, its output
-    kept in LDS only.  split=True: `w_packed` (and the front layer's W0) hold split-bf16 fragments (the GEMMs run on the
+    kept in LDS only.  split=True: `w_packed` (and the front layer's W0) hold split-f16 fragments (the GEMMs run on the
     bf16 matrix pipe with six partial products per f32 product)."""
     from . import _lib as L
     b, cin, n = x.shape
@@ -92,11 +92,11 @@ def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True, front=N
         if front is not None:
             if not relu:
                 raise ValueError("the two-layer launch applies ReLU after both layers")
-            L.call("gldm_pointwise_mlp2_bf16x3" if split else "gldm_pointwise_mlp2", L.ptr(x), L.ptr(front[0]),
+            L.call("gldm_pointwise_mlp2_f16x2" if split else "gldm_pointwise_mlp2", L.ptr(x), L.ptr(front[0]),
                    L.ptr(front[1]), cin, L.ptr(w_packed), L.ptr(bias), b, front[2], cout, n, *hp, L.ptr(y), L.ptr(z),
                    L.current_stream(x.device))
         else:
-            L.call("gldm_pointwise_mlp_bf16x3" if split else "gldm_pointwise_mlp", L.ptr(x), L.ptr(w_packed), L.ptr(bias),
+            L.call("gldm_pointwise_mlp_f16x2" if split else "gldm_pointwise_mlp", L.ptr(x), L.ptr(w_packed), L.ptr(bias),
                    b, cin, cout, n, int(relu), *hp, L.ptr(y), L.ptr(z), L.current_stream(x.device))
     return y, z
 
@@ -114,7 +114,7 @@ def pointwise_conv(x, conv):
 
 
 def folded_conv_bn(conv, bn, device):
-    """BatchNorm(eval) folded into the k = 1 conv: (W', b', W' packed for gldm_pointwise_mlp or None, W' as split-bf16
+    """BatchNorm(eval) folded into the k = 1 conv: (W', b', W' packed for gldm_pointwise_mlp or None, W' as split-f16
     fragments or None), on `device`, computed once per (weights, statistics) version and kept on the conv module."""
     from ._cache import params_key, publish
     src = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv.bias] if conv.bias is not None else [])
@@ -158,8 +158,8 @@ def pointwise_conv_bn_relu(x, conv, bn):
 
 def concat_conv_bn_relu(xa, xb, conv, bn):
     """relu(BN_eval(conv(cat([xa, xb], dim=1)))) of a k = 1 conv WITHOUT building the concatenation:
-    W [xa; xb] = Wa xa + Wb xb.  The wide part runs as the split-bf16 launch with the other part as its addend
-    (gldm_pointwise_mlp_bf16x3_add).  Two shapes of the PointNet++-style backbones (pointnet.py:11-46, 117-135):
+    W [xa; xb] = Wa xa + Wb xb.  The wide part runs as the split-f16 launch with the other part as its addend
+    (gldm_pointwise_mlp_f16x2_add).  Two shapes of the PointNet++-style backbones (pointnet.py:11-46, 117-135):
       * xa [B, Ca, N] wide (Ca % 128 == 0), xb [B, Cb, N] a few rows (Cb in SMALL_CIN: coordinates / raw features):
         addend = Wb xb + b from the lane-per-point kernel, a [B, Cout, N] tensor;
       * xa [B, Ca, 1] ONE centre's features that nearest-neighbour interpolation would broadcast to every point,
@@ -202,7 +202,7 @@ def concat_conv_bn_relu(xa, xb, conv, bn):
         add = _gemm_bias_act(xb.contiguous(), w_other, b, False)                                                   # [B, Cout, N]
         xw, strides, bias = xa.contiguous(), (cout * n, n, 1), zero_b
     with torch.cuda.device(xa.device):
-        L.call("gldm_pointwise_mlp_bf16x3_add", L.ptr(xw), L.ptr(w3), L.ptr(bias), L.ptr(add), *strides, bsz, wide_c, cout, n, 1,
+        L.call("gldm_pointwise_mlp_f16x2_add", L.ptr(xw), L.ptr(w3), L.ptr(bias), L.ptr(add), *strides, bsz, wide_c, cout, n, 1,
                L.ptr(y), L.current_stream(xa.device))
     return y
 

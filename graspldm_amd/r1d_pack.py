@@ -56,32 +56,6 @@ def mfma_a_fragments(w2d):
     return wp.permute(0, 2, 4, 1, 3).contiguous().reshape(-1)   # (mt, kb, kq, i, j): lane = 16 kq + i
 
 
-def split_bf16x3(w):
-    """f32 -> (hi, mid, lo) bf16 with hi + mid + lo == w exactly (round to nearest at each stage)."""
-    w = w.detach().float()
-    hi = w.to(torch.bfloat16)
-    r = w - hi.float()
-    mid = r.to(torch.bfloat16)
-    lo = (r - mid.float()).to(torch.bfloat16)
-    return hi, mid, lo
-
-
-def mfma_a_fragments_bf16x3(w2d):
-    """[M, K] (K % 32 == 0) -> f32-typed bit container of the split-bf16 A fragments of v_mfma_f32_16x16x32_bf16:
-    [M/16][K/32][plane hi|mid|lo][lane 64][8 bf16], lane l = W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + j]
-    (include/gldm.h).  768 floats per (m-tile, 32-deep k-block)."""
-    m, k = w2d.shape
-    if k % 32:
-        raise ValueError("split-bf16 fragments need K % 32 == 0")
-    mt = (m + 15) // 16
-    wp = torch.zeros(mt * 16, k, dtype=torch.float32)
-    wp[:m] = w2d
-    planes = torch.stack(split_bf16x3(wp))                         # [3, M, K] bf16
-    planes = planes.view(3, mt, 16, k // 32, 4, 8)                 # (plane, mt, i, kb, g, j): k = 32 kb + 8 g + j
-    frag = planes.permute(1, 3, 0, 4, 2, 5).contiguous()           # (mt, kb, plane, g, i, j): lane = 16 g + i
-    return frag.reshape(-1, 8).view(torch.float32).reshape(-1)     # bit pattern kept: 8 bf16 = 4 floats
-
-
 def split_f16x2(w):
     """f32 -> (hi, lo) f16 with hi + lo == w up to 2^-22 |w| (round to nearest at each stage; lo may be an f16
     subnormal: the matrix pipe keeps those).  Values beyond the f16 range (|w| >= 65520) are refused."""
@@ -192,7 +166,7 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
         rb.ss_w = buf.add(mfma_a_fragments(mw))
         rb.ss_b = buf.add(comb)
         w1, w2 = (conv_as_gemm(weight_standardize(sd[q + f"block{i}.proj.weight"])) for i in (1, 2))
-        if c % 16 == 0:   # split-bf16 copies for the 64-column engines (per tap a multiple of 32 channels: 16 is padded)
+        if c % 16 == 0:   # split-f16 copies for the 64-column engines (per tap a multiple of 32 channels: 16 is padded)
             rb.c1_w3 = buf.add(mfma_a_fragments_f16x2(pad_cin32(w1, c, 3)))
             rb.c2_w3 = buf.add(mfma_a_fragments_f16x2(pad_cin32(w2, c, 3)))
         rb.c1_w = buf.add(mfma_a_fragments(conv_as_gemm(weight_standardize(sd[q + "block1.proj.weight"]))))

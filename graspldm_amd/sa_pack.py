@@ -30,7 +30,7 @@ def fusable(shared_mlp, num_neighbors):
 
 
 def split_plan_ok(cins, couts, num_neighbors):
-    """Shapes gldm_sa_mlp_forward_bf16x3 takes (csrc/resnet1d.hip: sa_mlp3_kernel): 64-column tiles on split-bf16 planes."""
+    """Shapes gldm_sa_mlp_forward_f16x2 takes (csrc/resnet1d.hip: sa_mlp3_kernel): 64-column tiles on split-f16 planes."""
     if int(num_neighbors) not in (16, 32, 64) or not 1 <= len(couts) <= 4:
         return False
     # hidden widths are packed padded to the 32-row plane blocks (zero weight rows, zero bias: ReLU leaves zeros, and the
@@ -47,7 +47,7 @@ def split_plan_ok(cins, couts, num_neighbors):
 
 
 class SaMlpPlan:
-    """Packed weights of one SharedMLP(dim=2) on the device + the layer tables.  Where the layer plan fits the split-bf16
+    """Packed weights of one SharedMLP(dim=2) on the device + the layer tables.  Where the layer plan fits the split-f16
     kernel (split_plan_ok: the PointNet++ / PVCNN2 set-abstraction shapes), `run` takes that one; the f32-MFMA plan
     is packed either way (other neighbour counts / widths)."""
 
@@ -77,7 +77,7 @@ class SaMlpPlan:
         self._device = device
 
     def _split_plan(self):
-        """Split-bf16 fragments [cout x K padded to 32] per layer + biases, packed on first use."""
+        """Split-f16 fragments [cout x K padded to 32] per layer + biases, packed on first use."""
         if self._split is None:
             layers = self._layers.layers
             n = len(layers) // 3
@@ -110,7 +110,7 @@ class SaMlpPlan:
         if split_plan_ok(cins, couts, u):
             w3, cin_pad, cout, w_off, b_off = self._split_plan()
             with torch.cuda.device(points.device):
-                L.call("gldm_sa_mlp_forward_bf16x3", L.ptr(points), L.ptr(centers), L.ptr(features), L.ptr(idx), L.ptr(w3),
+                L.call("gldm_sa_mlp_forward_f16x2", L.ptr(points), L.ptr(centers), L.ptr(features), L.ptr(idx), L.ptr(w3),
                        b, c, n, m, u, self.n_layers, ctypes.cast(cin_pad, ctypes.c_void_p), ctypes.cast(cout, ctypes.c_void_p),
                        ctypes.cast(w_off, ctypes.c_void_p), ctypes.cast(b_off, ctypes.c_void_p), L.ptr(out),
                        L.current_stream(points.device))

@@ -24,27 +24,27 @@ def pack_conv3d(weight):
 
 
 def split_conv_supported(cin, cout, r):
-    """Shapes gldm_conv3d_k3_bf16x3 is built for (the shipped PVCNN encoder's 48 ch @ 24^3 and 96 ch @ 12^3, and its
+    """Shapes gldm_conv3d_k3_f16x2 is built for (the shipped PVCNN encoder's 48 ch @ 24^3 and 96 ch @ 12^3, and its
     first conv 3 -> 48 @ 24^3 with K = 81 packed into three 32-deep blocks)."""
     return (cin % 16 == 0 and (cout, r) in ((48, 24), (96, 12))) or (cin, cout, r) == (3, 48, 24)
 
 
-def pack_conv3d_fewch_bf16x3(weight):
-    """[cout, cin <= 4, 3, 3, 3] -> split-bf16 A fragments of [cout, roundup(27 cin, 32)], k = tap * cin + ci (tap-major,
+def pack_conv3d_fewch_f16x2(weight):
+    """[cout, cin <= 4, 3, 3, 3] -> split-f16 A fragments of [cout, roundup(27 cin, 32)], k = tap * cin + ci (tap-major,
     no padding between taps), zero beyond 27 cin."""
-    from .r1d_pack import mfma_a_fragments_bf16x3
+    from .r1d_pack import mfma_a_fragments_f16x2
     cout, cin = weight.shape[:2]
     k = 27 * cin
     w = torch.zeros(cout, (k + 31) // 32 * 32, dtype=torch.float32)
     w[:, :k] = weight.detach().float().cpu().reshape(cout, cin, 27).permute(0, 2, 1).reshape(cout, k)
-    return mfma_a_fragments_bf16x3(w)
+    return mfma_a_fragments_f16x2(w)
 
 
-def pack_conv3d_bf16x3(weight):
-    """[cout, cin, 3, 3, 3] (cin % 16 == 0) -> split-bf16 A fragments of [cout, cblocks * 14 * 32]: K is walked as
+def pack_conv3d_f16x2(weight):
+    """[cout, cin, 3, 3, 3] (cin % 16 == 0) -> split-f16 A fragments of [cout, cblocks * 14 * 32]: K is walked as
     (16-channel block, pair of taps), k = ((cb * 14 + p) * 32 + 16 (tap - 2 p) + ci; tap 27 (second half of the last
     pair) is zero."""
-    from .r1d_pack import mfma_a_fragments_bf16x3
+    from .r1d_pack import mfma_a_fragments_f16x2
     cout, cin = weight.shape[:2]
     cb = cin // 16
     w = torch.zeros(cout, cb, 14, 2, 16, dtype=torch.float32)
@@ -52,18 +52,18 @@ def pack_conv3d_bf16x3(weight):
     taps = torch.zeros(cout, cb, 16, 28)
     taps[..., :27] = wt
     w[:] = taps.reshape(cout, cb, 16, 14, 2).permute(0, 1, 3, 4, 2)          # [cout, cb, pair, half, ci]
-    return mfma_a_fragments_bf16x3(w.reshape(cout, cb * 14 * 32))
+    return mfma_a_fragments_f16x2(w.reshape(cout, cb * 14 * 32))
 
 
 class VoxelBranchPlan:
-    """Packed conv weights of one PVConv on the device (f32 fragments, or split-bf16 ones where the conv has that kernel)."""
+    """Packed conv weights of one PVConv on the device (f32 fragments, or split-f16 ones where the conv has that kernel)."""
 
     def __init__(self, convs, device, r=None):
         self.split = [r is not None and split_conv_supported(c.in_channels, c.out_channels, r) for c in convs]
         # shapes without an MFMA instantiation run the direct kernel on the raw nn.Conv3d weight
         self.generic = [r is not None and not conv_supported(c.out_channels, r) for c in convs]
         self.w = [(c.weight.detach().float().contiguous() if gen else
-                   ((pack_conv3d_fewch_bf16x3(c.weight) if c.in_channels < 16 else pack_conv3d_bf16x3(c.weight)) if sp
+                   ((pack_conv3d_fewch_f16x2(c.weight) if c.in_channels < 16 else pack_conv3d_f16x2(c.weight)) if sp
                     else pack_conv3d(c.weight))).to(device)
                   for c, sp, gen in zip(convs, self.split, self.generic)]
         self.key = None  # set by the owner (PVConv.forward) from _cache.params_key
@@ -74,7 +74,7 @@ def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
 
     GroupNorm + Swish never run as passes of their own where the consumer can apply them: every conv leaves its raw output
     and its per-brick statistics; gldm_groupnorm_coef folds those with the norm's affine into (a, s) per cloud and channel;
-    a following split-bf16 conv applies swish(a x + s) while it stages its bricks (gldm_conv3d_k3_bf16x3_gn), the SE squeeze
+    a following split-f16 conv applies swish(a x + s) while it stages its bricks (gldm_conv3d_k3_f16x2_gn), the SE squeeze
     is a read-only pass (gldm_gn_swish_chan_sum) and the devoxelize pass applies it to the eight corners it reads
     (gldm_devoxelize_gn_fused).  The last conv of the stack, when it is one of the plane-staging kernels, writes its output
     channel-last so that both of those readers take a voxel's channels as one run (gldm_gn_swish_chan_sum_cl,
@@ -100,14 +100,14 @@ def run(plan, convs, norms, se, vox, norm_coords, point_feat, r):
             # the last conv's readers (squeeze, devoxelize) take a voxel's channels as one run
             cl = last and (staged or mfma32) and cout % 4 == 0 and cout <= 256 and cout // gn.num_groups <= 64
             if staged and (coef is not None or cl):
-                L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(x), L.ptr(coef), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r,
+                L.call("gldm_conv3d_k3_f16x2_gn", L.ptr(x), L.ptr(coef), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r,
                        L.ptr(y), L.ptr(partial), 1 if cl else 0, st)
             elif cl:
                 assert coef is None
                 L.call("gldm_conv3d_k3_cl", L.ptr(x), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r, L.ptr(y), L.ptr(partial), st)
             else:
                 assert coef is None
-                entry = "gldm_conv3d_k3_generic" if plan.generic[i] else ("gldm_conv3d_k3_bf16x3" if plan.split[i] else "gldm_conv3d_k3")
+                entry = "gldm_conv3d_k3_generic" if plan.generic[i] else ("gldm_conv3d_k3_f16x2" if plan.split[i] else "gldm_conv3d_k3")
                 L.call(entry, L.ptr(x), L.ptr(plan.w[i]), L.ptr(conv.bias), b, cin, cout, r, L.ptr(y), L.ptr(partial), st)
             x_cl = cl
             # the consumer of this conv's GroupNorm + Swish: the next conv if it stages planes (cin % 16 == 0 split kernel),

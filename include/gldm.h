@@ -166,10 +166,10 @@ typedef struct gldm_r1d_level {
                            row order (q | k | v, head h at rows 32 h of each third): 384 x C packed;
                            0 / negative = absent (the position-major engine is then not used)       */
   int32_t qkvn_s;       /* ABI 4: row sums of W' [384] (the mean term of the folded LayerNorm)     */
-  int32_t qkvn_w3, out_w3, down_w3; /* ABI 5: qkvn_w / out_w / down_w as split-bf16 fragments; 0 = absent */
+  int32_t qkvn_w3, out_w3, down_w3; /* ABI 5: qkvn_w / out_w / down_w as split-f16 fragments; 0 = absent */
 } gldm_r1d_level;
 
-/* Split-bf16 weight fragments (ABI 5; graspldm_amd/r1d_pack.py: mfma_a_fragments_bf16x3).  Every f32 weight is
+/* Split-f16 weight fragments (ABI 5; graspldm_amd/r1d_pack.py: mfma_a_fragments_f16x2).  Every f32 weight is
  * written as hi + mid + lo, three bf16 numbers (exact: 3 x 8 significant bits cover the 24 of an f32); the matrix
  * [M, K] (K % 32 == 0) is stored as [M/16][K/32][plane hi|mid|lo][lane 64][8 bf16], lane l holding
  * W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + j], j = 0..7: the A operand of v_mfma_f32_16x16x32_bf16.  The
@@ -226,7 +226,7 @@ int gldm_r1d_cond_embed(const float *z_cond /*[n_cond,R,Dc]*/, const float *w /*
  * cloud), written by gldm_decode itself before the fused launch.  For a latent-denoiser descriptor of the
  * position-major engine whose last level has 256 channels it holds, behind the granules (256-byte aligned),
  * 64 KiB of scratch per workgroup of the launch (min(tiles, compute units)): the level's residual stream is
- * parked there, by the lanes that re-load it, while LDS holds its split-bf16 planes.
+ * parked there, by the lanes that re-load it, while LDS holds its split-f16 planes.
  * Contract: the caller ZEROES the workspace once, when it allocates it; a workspace is used by one
  * launch at a time (launches on the same stream may share it, concurrent streams may not); the
  * library re-arms it at the end of every launch.  The 32-bit word at byte GLDM_R1D_WS_ERROR is set
@@ -235,7 +235,7 @@ int gldm_r1d_cond_embed(const float *z_cond /*[n_cond,R,Dc]*/, const float *w /*
 long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples);
 
 /* Which engine gldm_denoise / gldm_decode run this descriptor on: 64 = the position-major engine (64-column tiles = 16
- * samples x 4 positions, GEMMs as split-bf16 products on the bf16 matrix pipe: 4-position latent denoisers packed with
+ * samples x 4 positions, GEMMs as split-f16 products on the bf16 matrix pipe: 4-position latent denoisers packed with
  * the ABI >= 5 fields), 32 = the sample-major engine (32-column tiles, f32 matrix pipe: the 16-position pose decoder and
  * every other supported shape), or a negative GLDM_ERR_* status for a descriptor no engine takes.  No reference
  * counterpart: reporting only (bench.py labels its roofline record with it). */
@@ -289,11 +289,11 @@ int gldm_sa_mlp_forward(const float *points /*[b,3,n]*/, const float *centers /*
 
 /* The same module core with the GEMMs on the bf16 matrix pipe (every f32 product as six bf16 partial products of the exact
  * hi / mid / lo splits of both operands, f32 accumulation: the arithmetic of the denoiser engines): 64-column tiles whose
- * gathered rows and hidden-layer outputs live in LDS as pre-split planes.  `weights` holds, per layer, the split-bf16 A
- * fragments of [cout x cin_pad] at w3_off[l] (graspldm_amd/r1d_pack.py: mfma_a_fragments_bf16x3; cin_pad a multiple of 32,
+ * gathered rows and hidden-layer outputs live in LDS as pre-split planes.  `weights` holds, per layer, the split-f16 A
+ * fragments of [cout x cin_pad] at w3_off[l] (graspldm_amd/r1d_pack.py: mfma_a_fragments_f16x2; cin_pad a multiple of 32,
  * zero beyond the real rows) and the folded bias at b_off[l].  Shapes: cin_pad[0] <= 288, hidden widths multiples of 32
  * (32 / 64 / 128 / 256), U in {16, 32, 64}; GLDM_ERR_UNSUPPORTED otherwise (callers then use gldm_sa_mlp_forward). */
-int gldm_sa_mlp_forward_bf16x3(const float *points /*[b,3,n]*/, const float *centers /*[b,3,m]*/,
+int gldm_sa_mlp_forward_f16x2(const float *points /*[b,3,n]*/, const float *centers /*[b,3,m]*/,
                                const float *features /*[b,c,n] or NULL*/, const int32_t *idx /*[b,m,u]*/,
                                const float *weights, int b, int c, int n, int m, int u, int n_layers,
                                const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off, const int32_t *b_off,
@@ -338,14 +338,14 @@ int gldm_pointwise_any(const float *x /*[b,cin,n]*/, const float *w /*[cout,cin]
 int gldm_linear_rows(const float *x /*[rows,n]*/, const float *w /*[nout,n]*/, const float *bias /*[nout] or NULL*/,
                      int rows, int n, int nout, float *y /*[rows,nout]*/, gldm_stream_t stream);
 
-/* The same two entry points with the MAIN layer's weights as split-bf16 fragments (graspldm_amd/r1d_pack.py:
- * mfma_a_fragments_bf16x3; layout above): the GEMM runs on the bf16 matrix pipe with six partial products per f32
+/* The same two entry points with the MAIN layer's weights as split-f16 fragments (graspldm_amd/r1d_pack.py:
+ * mfma_a_fragments_f16x2; layout above): the GEMM runs on the bf16 matrix pipe with six partial products per f32
  * product and f32 accumulation (error of the order of one f32 rounding per product, 6/16 of the f32-MFMA time).  The
- * input tile is split once while it is staged.  Since ABI 6 the front layer's weights `w0_split` are split-bf16 fragments
+ * input tile is split once while it is staged.  Since ABI 6 the front layer's weights `w0_split` are split-f16 fragments
  * too (cin0 % 32 == 0, cin0 <= 96; its f32 input tile is split once per wave into registers); `head_w_packed` stays f32
  * fragments.  cin % 128 == 0, cout % 32 == 0 (with a front layer or a head: % 256; fewer than 256 output rows leave waves
  * idle), n % 32 == 0, 4 (48 cin + 32 cin0) + 16 <= 160 KiB. */
-int gldm_pointwise_mlp_bf16x3(const float *x /*[b,cin,n]*/, const float *w_split, const float *bias /*[cout]*/,
+int gldm_pointwise_mlp_f16x2(const float *x /*[b,cin,n]*/, const float *w_split, const float *bias /*[cout]*/,
                               int b, int cin, int cout, int n, int relu,
                               const float *head_w_packed, const float *head_bias, int hout,
                               float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
@@ -355,11 +355,11 @@ int gldm_pointwise_mlp_bf16x3(const float *x /*[b,cin,n]*/, const float *w_split
  * (cout * n, n, 1).  It serves layers whose input is a concatenation (pointnet.py:117-135 PointNetFPModule, :11-46
  * PointNetAModule): W [x1; x2] = W1 x1 + W2 x2, the wide part here, the other part (three coordinate rows, or one centre's
  * feature vector broadcast to every point) as the addend, and the concatenated tensor is never built. */
-int gldm_pointwise_mlp_bf16x3_add(const float *x /*[b,cin,n]*/, const float *w_split, const float *bias /*[cout]*/,
+int gldm_pointwise_mlp_f16x2_add(const float *x /*[b,cin,n]*/, const float *w_split, const float *bias /*[cout]*/,
                                   const float *add, long long add_cloud_stride, long long add_row_stride,
                                   long long add_col_stride, int b, int cin, int cout, int n, int relu,
                                   float *y /*[b,cout,n]*/, gldm_stream_t stream);
-int gldm_pointwise_mlp2_bf16x3(const float *x /*[b,cin0,n]*/, const float *w0_split, const float *bias0, int cin0,
+int gldm_pointwise_mlp2_f16x2(const float *x /*[b,cin0,n]*/, const float *w0_split, const float *bias0, int cin0,
                                const float *w_split, const float *bias /*[cout]*/, int b, int cin, int cout, int n,
                                const float *head_w_packed, const float *head_bias, int hout,
                                float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
@@ -389,13 +389,13 @@ int gldm_conv3d_k3_generic(const float *x /*[b,cin,r^3]*/, const float *w /*[cou
                            int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/, float *partial,
                            gldm_stream_t stream);
 
-/* The same conv with split-bf16 weights (graspldm_amd/voxel.py: pack_conv3d_bf16x3: [cout, cblocks * 14 * 32] with
- * k = ((16-channel block) * 14 + tap pair) * 32 + 16 (tap - 2 pair) + channel, as mfma_a_fragments_bf16x3 fragments):
+/* The same conv with split-f16 weights (graspldm_amd/voxel.py: pack_conv3d_f16x2: [cout, cblocks * 14 * 32] with
+ * k = ((16-channel block) * 14 + tap pair) * 32 + 16 (tap - 2 pair) + channel, as mfma_a_fragments_f16x2 fragments):
  * six bf16 partial products per f32 product on the bf16 matrix pipe, f32 accumulation.  Built for the shipped
  * encoder's shapes (cout 48 at r = 24, cout 96 at r = 12 with cin % 16 == 0; and the first conv, cin = 3 -> 48 at r = 24,
  * whose weights are packed tap-major without padding between taps, k = tap * 3 + ci < 81 in three 32-deep blocks:
- * pack_conv3d_fewch_bf16x3); GLDM_ERR_UNSUPPORTED otherwise. */
-int gldm_conv3d_k3_bf16x3(const float *x /*[b,cin,r^3]*/, const float *w_split, const float *bias /*[cout]*/,
+ * pack_conv3d_fewch_f16x2); GLDM_ERR_UNSUPPORTED otherwise. */
+int gldm_conv3d_k3_f16x2(const float *x /*[b,cin,r^3]*/, const float *w_split, const float *bias /*[cout]*/,
                           int b, int cin, int cout, int r, float *y /*[b,cout,r^3]*/, float *partial,
                           gldm_stream_t stream);
 
@@ -403,8 +403,8 @@ int gldm_conv3d_k3_bf16x3(const float *x /*[b,cin,r^3]*/, const float *w_split, 
  * folded in.  in_coef [b, cin, 2] (optional) = (a, s) from gldm_groupnorm_coef: x is the previous conv's RAW output and
  * x' = swish(a x + s) is applied per in-grid element while the bricks are staged (the activated tensor is never written).
  * out_channel_last != 0: y is written [b, r^3, cout] (a voxel's channels as one run: the layout the squeeze and
- * devoxelize passes below read; `partial` is unchanged).  cin % 16 == 0, the cout / r of gldm_conv3d_k3_bf16x3. */
-int gldm_conv3d_k3_bf16x3_gn(const float *x /*[b,cin,r^3] raw*/, const float *in_coef /*[b,cin,2] or NULL*/,
+ * devoxelize passes below read; `partial` is unchanged).  cin % 16 == 0, the cout / r of gldm_conv3d_k3_f16x2. */
+int gldm_conv3d_k3_f16x2_gn(const float *x /*[b,cin,r^3] raw*/, const float *in_coef /*[b,cin,2] or NULL*/,
                              const float *w_split, const float *bias /*[cout]*/, int b, int cin, int cout, int r,
                              float *y /*[b,cout,r^3] or [b,r^3,cout]*/, float *partial, int out_channel_last,
                              gldm_stream_t stream);

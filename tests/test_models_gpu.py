@@ -166,8 +166,8 @@ def test_ddpm_sampler_runs_and_is_seed_reproducible(ldm):
                                              (2, 256, 64, 16, 32, (128, 256))])
 @pytest.mark.parametrize("split", [True, False])
 def test_fused_sa_mlp_equals_unfused_oracle(b, c, n, m, u, chans, split, monkeypatch):
-    """gldm_sa_mlp_forward_bf16x3 / gldm_sa_mlp_forward (gather + grouped MLP + max, fused) vs the oracle's
-    ball_group -> shared_mlp -> max on the same weights.  split=True: every case runs on the split-bf16 64-column kernel
+    """gldm_sa_mlp_forward_f16x2 / gldm_sa_mlp_forward (gather + grouped MLP + max, fused) vs the oracle's
+    ball_group -> shared_mlp -> max on the same weights.  split=True: every case runs on the split-f16 64-column kernel
     (sa_mlp3_kernel: 1 / 2 / 4 centres per tile, ragged last tiles, more tiles than persistent workgroups, 2-4 layers,
     1-6 and 9 input blocks, 16-wide hidden layers packed as zero-padded 32-wide ones, the narrow-net form with one and
     with two row quads per gather thread).  split=False forces the f32 kernels: cases 1-3, 5, 6 on the
@@ -254,13 +254,13 @@ def test_conv3d_groupnorm_swish_kernels(cin, cout, r):
 
 @pytest.mark.parametrize("cin,cout,r", [(3, 48, 24), (48, 48, 24), (48, 96, 12), (96, 96, 12)])
 def test_conv3d_split_bf16_kernels(cin, cout, r):
-    """gldm_conv3d_k3_bf16x3 (the shipped encoder's four voxel convs; 3 -> 48 with K = 81 packed into three k-blocks) vs
+    """gldm_conv3d_k3_f16x2 (the shipped encoder's four voxel convs; 3 -> 48 with K = 81 packed into three k-blocks) vs
     torch conv3d on the CPU, and its GroupNorm partials through gldm_groupnorm_swish (fp32, 2e-5)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.nn.functional as F
     from graspldm_amd import _lib as L
-    from graspldm_amd.voxel import pack_conv3d_bf16x3, pack_conv3d_fewch_bf16x3, split_conv_supported
+    from graspldm_amd.voxel import pack_conv3d_f16x2, pack_conv3d_fewch_f16x2, split_conv_supported
     assert split_conv_supported(cin, cout, r)
     g = torch.Generator().manual_seed(cin * 100 + cout + 1)
     b = 3
@@ -273,9 +273,9 @@ def test_conv3d_split_bf16_kernels(cin, cout, r):
     y = torch.empty(b, cout, r, r, r, device="cuda")
     part = torch.empty(int(L.lib().gldm_conv3d_partial_floats(b, cout, r)), device="cuda")
     st = L.current_stream()
-    dw = (pack_conv3d_fewch_bf16x3(w) if cin < 16 else pack_conv3d_bf16x3(w)).cuda()
+    dw = (pack_conv3d_fewch_f16x2(w) if cin < 16 else pack_conv3d_f16x2(w)).cuda()
     dx, db = x.cuda(), bias.cuda()
-    L.call("gldm_conv3d_k3_bf16x3", L.ptr(dx), L.ptr(dw), L.ptr(db), b, cin, cout, r, L.ptr(y), L.ptr(part), st)
+    L.call("gldm_conv3d_k3_f16x2", L.ptr(dx), L.ptr(dw), L.ptr(db), b, cin, cout, r, L.ptr(y), L.ptr(part), st)
     assert _err(y, ref) < 2e-5, _err(y, ref)
     gn = F.group_norm(ref, 8, gamma, beta, 1e-5)
     ref2 = gn * torch.sigmoid(gn)
@@ -286,13 +286,13 @@ def test_conv3d_split_bf16_kernels(cin, cout, r):
 
 def test_groupnorm_folded_into_its_consumers():
     """Conv3d -> GroupNorm -> Swish -> Conv3d -> GroupNorm -> Swish -> SE sum -> devoxelize with no GroupNorm pass:
-    gldm_groupnorm_coef + gldm_conv3d_k3_bf16x3_gn + gldm_gn_swish_chan_sum + gldm_devoxelize_gn_fused against torch on the
+    gldm_groupnorm_coef + gldm_conv3d_k3_f16x2_gn + gldm_gn_swish_chan_sum + gldm_devoxelize_gn_fused against torch on the
     CPU (fp32, 2e-5)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.nn.functional as F
     from graspldm_amd import _lib as L
-    from graspldm_amd.voxel import pack_conv3d_bf16x3
+    from graspldm_amd.voxel import pack_conv3d_f16x2
     g = torch.Generator().manual_seed(77)
     b, c, r, n = 3, 48, 24, 256
     x = torch.randn(b, c, r, r, r, generator=g)
@@ -309,11 +309,11 @@ def test_groupnorm_folded_into_its_consumers():
     y1, y2 = torch.empty(b, c, r, r, r, device="cuda"), torch.empty(b, c, r, r, r, device="cuda")
     p1, p2 = torch.empty(nf, device="cuda"), torch.empty(nf, device="cuda")
     c1, c2 = torch.empty(b, c, 2, device="cuda"), torch.empty(b, c, 2, device="cuda")
-    dw1, dw2 = pack_conv3d_bf16x3(w1).cuda(), pack_conv3d_bf16x3(w2).cuda()
+    dw1, dw2 = pack_conv3d_f16x2(w1).cuda(), pack_conv3d_f16x2(w2).cuda()
     d = [t.cuda() for t in (b1, b2, g1, be1, g2, be2)]
-    L.call("gldm_conv3d_k3_bf16x3", L.ptr(dx), L.ptr(dw1), L.ptr(d[0]), b, c, c, r, L.ptr(y1), L.ptr(p1), st)
+    L.call("gldm_conv3d_k3_f16x2", L.ptr(dx), L.ptr(dw1), L.ptr(d[0]), b, c, c, r, L.ptr(y1), L.ptr(p1), st)
     L.call("gldm_groupnorm_coef", L.ptr(p1), L.ptr(d[2]), L.ptr(d[3]), b, c, r, 8, 1e-5, L.ptr(c1), st)
-    L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(y1), L.ptr(c1), L.ptr(dw2), L.ptr(d[1]), b, c, c, r, L.ptr(y2), L.ptr(p2), 0, st)
+    L.call("gldm_conv3d_k3_f16x2_gn", L.ptr(y1), L.ptr(c1), L.ptr(dw2), L.ptr(d[1]), b, c, c, r, L.ptr(y2), L.ptr(p2), 0, st)
     L.call("gldm_groupnorm_coef", L.ptr(p2), L.ptr(d[4]), L.ptr(d[5]), b, c, r, 8, 1e-5, L.ptr(c2), st)
     cs = torch.empty(b, c, device="cuda")
     L.call("gldm_gn_swish_chan_sum", L.ptr(y2), L.ptr(c2), b, c, r, L.ptr(cs), st)
@@ -330,7 +330,7 @@ def test_groupnorm_folded_into_its_consumers():
     assert _err(out, ref.cpu()) < 2e-5, _err(out, ref.cpu())
     # the same stack with the last conv writing channel-last, its squeeze as partial sums and the run-per-corner devoxelize
     y2cl, p2cl, c2cl = torch.empty(b, r ** 3, c, device="cuda"), torch.empty(nf, device="cuda"), torch.empty(b, c, 2, device="cuda")
-    L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(y1), L.ptr(c1), L.ptr(dw2), L.ptr(d[1]), b, c, c, r, L.ptr(y2cl), L.ptr(p2cl), 1, st)
+    L.call("gldm_conv3d_k3_f16x2_gn", L.ptr(y1), L.ptr(c1), L.ptr(dw2), L.ptr(d[1]), b, c, c, r, L.ptr(y2cl), L.ptr(p2cl), 1, st)
     assert torch.equal(y2cl.view(b, r ** 3, c).permute(0, 2, 1).reshape(b, c, r, r, r), y2) and torch.equal(p2cl, p2)
     L.call("gldm_groupnorm_coef", L.ptr(p2cl), L.ptr(d[4]), L.ptr(d[5]), b, c, r, 8, 1e-5, L.ptr(c2cl), st)
     parts = int(L.lib().gldm_squeeze_parts())
@@ -351,13 +351,13 @@ def test_groupnorm_folded_into_its_consumers():
 @pytest.mark.parametrize("cin,c,r,n", [(48, 96, 12, 100), (3, 32, 16, 77), (64, 64, 8, 1024), (128, 256, 8, 64)])
 def test_channel_last_voxel_stack_tail(cin, c, r, n):
     """A voxel stack's last conv written channel-last by the f32 / split kernels (gldm_conv3d_k3_cl,
-    gldm_conv3d_k3_bf16x3_gn(out_channel_last)) is the channel-major output transposed, bit for bit, and the squeeze /
+    gldm_conv3d_k3_f16x2_gn(out_channel_last)) is the channel-major output transposed, bit for bit, and the squeeze /
     devoxelize passes over it agree with the channel-major ones (ragged point counts, 12 / 16 / 24 / 64 channel quads,
     the two-launch 256-channel conv)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from graspldm_amd import _lib as L
-    from graspldm_amd.voxel import pack_conv3d, pack_conv3d_bf16x3, split_conv_supported
+    from graspldm_amd.voxel import pack_conv3d, pack_conv3d_f16x2, split_conv_supported
     g = torch.Generator().manual_seed(c + r)
     b = 2
     x = torch.randn(b, cin, r, r, r, generator=g).cuda()
@@ -369,9 +369,9 @@ def test_channel_last_voxel_stack_tail(cin, c, r, n):
     y, ycl = torch.empty(b, c, r ** 3, device="cuda"), torch.empty(b, r ** 3, c, device="cuda")
     p, pcl = torch.empty(nf, device="cuda"), torch.empty(nf, device="cuda")
     if split_conv_supported(cin, c, r):
-        dw = pack_conv3d_bf16x3(w).cuda()
-        L.call("gldm_conv3d_k3_bf16x3", L.ptr(x), L.ptr(dw), L.ptr(bias), b, cin, c, r, L.ptr(y), L.ptr(p), st)
-        L.call("gldm_conv3d_k3_bf16x3_gn", L.ptr(x), None, L.ptr(dw), L.ptr(bias), b, cin, c, r, L.ptr(ycl), L.ptr(pcl), 1, st)
+        dw = pack_conv3d_f16x2(w).cuda()
+        L.call("gldm_conv3d_k3_f16x2", L.ptr(x), L.ptr(dw), L.ptr(bias), b, cin, c, r, L.ptr(y), L.ptr(p), st)
+        L.call("gldm_conv3d_k3_f16x2_gn", L.ptr(x), None, L.ptr(dw), L.ptr(bias), b, cin, c, r, L.ptr(ycl), L.ptr(pcl), 1, st)
     else:
         dw = pack_conv3d(w).cuda()
         L.call("gldm_conv3d_k3", L.ptr(x), L.ptr(dw), L.ptr(bias), b, cin, c, r, L.ptr(y), L.ptr(p), st)
@@ -544,8 +544,8 @@ def test_pointwise_mlp_two_layers_one_launch(b, cin0, cin, cout, n, hout):
                                                     (5, 0, 128, 256, 2048, 0), (5, 32, 256, 256, 2048, 0),
                                                     (3, 0, 128, 128, 1024, 0), (2, 0, 256, 128, 512, 0), (1, 0, 128, 64, 32, 0),
                                                     (2, 0, 256, 224, 64, 0)])
-def test_pointwise_mlp_split_bf16(b, cin0, cin, cout, n, hout):
-    """gldm_pointwise_mlp_bf16x3 / gldm_pointwise_mlp2_bf16x3 (both layers on the bf16 matrix pipe, every f32 operand
+def test_pointwise_mlp_split_f16(b, cin0, cin, cout, n, hout):
+    """gldm_pointwise_mlp_f16x2 / gldm_pointwise_mlp2_f16x2 (both layers on the bf16 matrix pipe, every f32 operand
     split exactly into three bf16 numbers; units of output rows handed out to the waves at run time) against a torch-CPU
     reference computed in f64: 2e-5 of the output scale, like the f32-pipe form.  (5, ..., 2048): 320 tiles on 256
     workgroups, i.e. some workgroups take a second tile.  cout 64 / 128 / 224: fewer units of output rows than waves (the
@@ -586,8 +586,8 @@ def test_pointwise_mlp_split_bf16(b, cin0, cin, cout, n, hout):
 @pytest.mark.parametrize("b,ca,na,cb,n,cout", [(3, 128, 1024, 3, 1024, 128), (2, 256, 128, 3, 128, 256), (4, 1024, 1, 256, 128, 256),
                                                (2, 128, 64, 6, 64, 64)])
 def test_first_layer_of_a_concatenation_without_the_concatenation(b, ca, na, cb, n, cout):
-    """dense.concat_conv_bn_relu: relu(BN(conv(cat([xa, xb])))) as the split-bf16 launch over the wide part with the other
-    part as its addend (gldm_pointwise_mlp_bf16x3_add) -- a few coordinate rows as a [B, Cout, N] tensor, or ONE centre's
+    """dense.concat_conv_bn_relu: relu(BN(conv(cat([xa, xb])))) as the split-f16 launch over the wide part with the other
+    part as its addend (gldm_pointwise_mlp_f16x2_add) -- a few coordinate rows as a [B, Cout, N] tensor, or ONE centre's
     feature vector as a per-cloud bias (what nearest-neighbour interpolation from a single centre broadcasts) -- against
     torch on the CPU in f64 (2e-5 of the output scale)."""
     if not torch.cuda.is_available():

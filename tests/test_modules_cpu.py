@@ -206,35 +206,40 @@ def test_modules_refuse_cpu_tensors():
         ldm.generate_grasps(torch.zeros(1, 1024, 3), num_grasps=2)
 
 
-def test_split_bf16_fragments_are_exact_and_in_mfma_order():
-    """mfma_a_fragments_bf16x3 (include/gldm.h, "Split-bf16 weight fragments"): hi + mid + lo == w bit for bit, and
-    lane l of fragment (mt, kb, plane) holds W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + j]."""
-    from graspldm_amd.r1d_pack import mfma_a_fragments_bf16x3, split_bf16x3
+def test_split_f16_fragments_are_tight_and_in_mfma_order():
+    """mfma_a_fragments_f16x2 (include/gldm.h, "Split-f16 weight fragments"): hi + lo == w up to 2^-22 |w| (and 2^-25
+    where the lo part is an f16 subnormal), and lane l of fragment (mt, kb, plane) holds
+    W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + j].  Values beyond the f16 range are refused."""
+    from graspldm_amd.r1d_pack import mfma_a_fragments_f16x2, split_f16x2
     g = torch.Generator().manual_seed(0)
     w = torch.randn(40, 96, generator=g) * torch.logspace(-6, 3, 96).unsqueeze(0)   # wide dynamic range
-    hi, mid, lo = split_bf16x3(w)
-    assert torch.equal(hi.float() + mid.float() + lo.float(), w)
-    assert (mid.float().abs() <= hi.float().abs() * 2.0 ** -7 + 1e-45).all()
-    f = mfma_a_fragments_bf16x3(w)
-    assert f.dtype == torch.float32 and f.numel() == 3 * 3 * 3 * 64 * 4          # 3 m-tiles (40 -> 48 rows) x 3 k-blocks
-    fb = f.view(torch.bfloat16).view(3, 3, 3, 64, 8)
-    planes = (hi, mid, lo)
-    for mt, kb, pl, lane, j in [(0, 0, 0, 0, 0), (1, 2, 1, 37, 5), (2, 1, 2, 63, 7), (2, 0, 0, 8, 3)]:
+    hi, lo = split_f16x2(w)
+    assert hi.dtype == torch.float16 and lo.dtype == torch.float16
+    err = (hi.float() + lo.float() - w).abs()
+    assert (err <= torch.maximum(w.abs() * 2.0 ** -22, torch.full_like(w, 2.0 ** -25))).all()
+    assert (lo.float().abs() <= hi.float().abs() * 2.0 ** -10 + 2.0 ** -24).all()
+    f = mfma_a_fragments_f16x2(w)
+    assert f.dtype == torch.float32 and f.numel() == 3 * 3 * 2 * 64 * 4          # 3 m-tiles (40 -> 48 rows) x 3 k-blocks
+    fb = f.view(torch.float16).view(3, 3, 2, 64, 8)
+    planes = (hi, lo)
+    for mt, kb, pl, lane, j in [(0, 0, 0, 0, 0), (1, 2, 1, 37, 5), (2, 1, 1, 63, 7), (2, 0, 0, 8, 3)]:
         row, k = 16 * mt + (lane & 15), 32 * kb + 8 * (lane >> 4) + j
         exp = planes[pl][row, k].item() if row < 40 else 0.0
         assert fb[mt, kb, pl, lane, j].item() == exp, (mt, kb, pl, lane, j)
     with pytest.raises(ValueError):
-        mfma_a_fragments_bf16x3(torch.randn(16, 48))
+        mfma_a_fragments_f16x2(torch.randn(16, 48))
+    with pytest.raises(ValueError, match="65504"):
+        mfma_a_fragments_f16x2(torch.full((16, 32), 7.0e4))
 
 
 def test_conv3d_split_packing_walks_tap_pairs():
-    """pack_conv3d_bf16x3: k = ((16-channel block) * 14 + pair) * 32 + 16 (tap - 2 pair) + channel; tap 27 is zero."""
-    from graspldm_amd.voxel import pack_conv3d_bf16x3, split_conv_supported
-    from graspldm_amd.r1d_pack import split_bf16x3
+    """pack_conv3d_f16x2: k = ((16-channel block) * 14 + pair) * 32 + 16 (tap - 2 pair) + channel; tap 27 is zero."""
+    from graspldm_amd.voxel import pack_conv3d_f16x2, split_conv_supported
+    from graspldm_amd.r1d_pack import split_f16x2
     g = torch.Generator().manual_seed(1)
     w = torch.randn(48, 32, 3, 3, 3, generator=g)
-    f = pack_conv3d_bf16x3(w).view(torch.bfloat16).view(3, 2 * 14, 3, 64, 8)       # [mt][cb * 14 + pair][plane][lane][j]
-    hi = split_bf16x3(w.reshape(48, 32, 27))[0]
+    f = pack_conv3d_f16x2(w).view(torch.float16).view(3, 2 * 14, 2, 64, 8)       # [mt][cb * 14 + pair][plane][lane][j]
+    hi = split_f16x2(w.reshape(48, 32, 27))[0]
     for co, ci, tap in [(0, 0, 0), (17, 21, 13), (47, 31, 26), (5, 16, 1)]:
         cb, c16, pair, half = ci // 16, ci % 16, tap // 2, tap % 2
         k = 16 * half + c16
@@ -246,18 +251,18 @@ def test_conv3d_split_packing_walks_tap_pairs():
 
 
 def test_conv3d_few_channel_split_packing_is_tap_major_without_padding():
-    """pack_conv3d_fewch_bf16x3 (the encoder's first voxel conv, 3 -> 48 @ 24^3): k = tap * cin + ci, 81 real columns in
+    """pack_conv3d_fewch_f16x2 (the encoder's first voxel conv, 3 -> 48 @ 24^3): k = tap * cin + ci, 81 real columns in
     three 32-deep blocks, zero beyond."""
-    from graspldm_amd.voxel import pack_conv3d_fewch_bf16x3, split_conv_supported
-    from graspldm_amd.r1d_pack import split_bf16x3
+    from graspldm_amd.voxel import pack_conv3d_fewch_f16x2, split_conv_supported
+    from graspldm_amd.r1d_pack import split_f16x2
     g = torch.Generator().manual_seed(2)
     w = torch.randn(48, 3, 3, 3, 3, generator=g)
-    f = pack_conv3d_fewch_bf16x3(w).view(torch.bfloat16).view(3, 3, 3, 64, 8)       # [mt][kb][plane][lane][j]
-    planes = split_bf16x3(w.reshape(48, 3, 27))
+    f = pack_conv3d_fewch_f16x2(w).view(torch.float16).view(3, 3, 2, 64, 8)       # [mt][kb][plane][lane][j]
+    planes = split_f16x2(w.reshape(48, 3, 27))
     for co, ci, tap in [(0, 0, 0), (17, 2, 13), (47, 1, 26), (5, 0, 10), (31, 2, 26)]:
         k = tap * 3 + ci
         kb, g8, j = k // 32, (k % 32) // 8, k % 8
-        for pl in range(3):
+        for pl in range(2):
             assert f[co // 16, kb, pl, (co % 16) + 16 * g8, j].item() == planes[pl][co, ci, tap].item()
     # columns 81 .. 95: lane groups 2 (j >= 1) and 3 of the last block
     assert (f[:, 2, :, 48:, :] == 0).all() and (f[:, 2, :, 32:48, 1:] == 0).all()
@@ -266,7 +271,7 @@ def test_conv3d_few_channel_split_packing_is_tap_major_without_padding():
 
 def test_pad_cin32_and_16_position_descriptors():
     """16-channel levels of the 64-column engines read one zero-padded 32-channel block of planes: the packer pads every
-    tap's channels to 32 with zero weights (r1d_pack.pad_cin32) and provides every split-bf16 copy for both 16-position
+    tap's channels to 32 with zero weights (r1d_pack.pad_cin32) and provides every split-f16 copy for both 16-position
     nets of the shipped experiments (pose decoder, ppc denoiser), which then run on 64-column tiles."""
     import ctypes
     from graspldm_amd import _lib

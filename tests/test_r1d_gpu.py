@@ -371,7 +371,7 @@ def test_position_major_engine_other_widths(block_channels):
 def test_untamed_gains_short_horizon(engines):
     """The recipe weights tame two gains (raw-timestep column x 1e-3, final_conv x 0.1) so that 100 steps are
     contractive.  With O(1) gains instead, a single forward and a SHORT DDIM run (8 steps) of the HIP engine still follow
-    the oracle: the error budget of the split-bf16 / fused arithmetic does not rely on a benign network."""
+    the oracle: the error budget of the split-f16 / fused arithmetic does not rely on a benign network."""
     from oracle import torch_ref as R
     from graspldm_amd.r1d import R1dEngine, SCHED_DDIM
     from graspldm_amd.r1d_pack import pack_resnet1d

@@ -102,8 +102,8 @@ def main():
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "encoder_flops.json")) as f:
         flops = {k: v["flop_per_cloud"] for k, v in json.load(f)["models"].items()}
     PEAK = 157.3                      # f32 MFMA, dense
-    PEAK_SPLIT = 2500.0 / 6           # f32 products as six bf16 partial products on the bf16 matrix pipe
-    # Executed FLOP per cloud by the pipe they run on, where part of a model runs as split-bf16 products: the shipped
+    PEAK_SPLIT = 2500.0 / 3           # f32 products as three f16 partial products on the f16 matrix pipe
+    # Executed FLOP per cloud by the pipe they run on, where part of a model runs as split-f16 products: the shipped
     # PVCNNEncoder (768 -> 1536 layer + its 96 -> 768 front layer + the 48 / 96-channel voxel convs; head convs folded into
     # one 1536 -> 3 GEMM: 2.4 GFLOP of the reference graph never executed).
     # The set-abstraction MLPs of the two PointNet++-style backbones run on the split kernel too (sa_mlp3_kernel), as do the
@@ -125,14 +125,14 @@ def main():
             fl = flops.get(name) if args.points == 1024 else None
             r["reference_gflop_per_cloud"] = fl / 1e9 if fl else None
             r["achieved_tflops"] = fl * b / (r["avg_latency_ms"] * 1e-3) / 1e12 if fl else None
-            # fraction of the peak of the pipe(s) the model runs on: never above 1 (a split-bf16 kernel rated against the f32
+            # fraction of the peak of the pipe(s) the model runs on: never above 1 (a split-f16 kernel rated against the f32
             # peak read 1.6 in round 3).  Mixed models: executed FLOP / the time every GEMM would take at its own pipe's peak.
             if fl and name in split_exec and args.points == 1024:
                 f_split, f_exec = split_exec[name]
                 t_floor = b * (f_split / (PEAK_SPLIT * 1e12) + (f_exec - f_split) / (PEAK * 1e12))
                 r["executed_gflop_per_cloud"] = f_exec / 1e9
                 r["frac_of_pipe_peak"] = t_floor / (r["avg_latency_ms"] * 1e-3)
-                r["pipes"] = "split-bf16 (2500 / 6 TFLOP/s) + f32 MFMA (157.3), time-weighted"
+                r["pipes"] = "split-f16 (2500 / 3 TFLOP/s) + f32 MFMA (157.3), time-weighted"
             else:
                 r["frac_of_pipe_peak"] = r["achieved_tflops"] / PEAK if fl else None
                 r["pipes"] = "f32 MFMA (157.3 TFLOP/s)"

@@ -12,6 +12,6 @@ dis() {  # source file -> listing
 }
 dis graspldm_amd/csrc/resnet1d.hip $tmp/r1d.s
 dis graspldm_amd/csrc/voxel_conv.hip $tmp/vc.s
-for k in r1d_kernelILi64ELi4 r1d_kernelILi32ELi16 pointwise_mlp_bf_kernel; do python3 tools/isa/sunk_prefetch_scan.py $tmp/r1d.s $k; python3 tools/isa/branch_density.py $tmp/r1d.s $k; done
+for k in r1d_kernelILi64ELi4 r1d_kernelILi32ELi16 pointwise_mlp_sp_kernel; do python3 tools/isa/sunk_prefetch_scan.py $tmp/r1d.s $k; python3 tools/isa/branch_density.py $tmp/r1d.s $k; done
 for k in conv3d_k3_pl_kernelILi3ELi24ELi8 conv3d_k3_pl_kernelILi6ELi12ELi4 conv3d_k3_kernelILi3ELi6ELi1; do python3 tools/isa/sunk_prefetch_scan.py $tmp/vc.s $k; python3 tools/isa/branch_density.py $tmp/vc.s $k; done
 rm -rf $tmp

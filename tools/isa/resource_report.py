@@ -7,4 +7,4 @@ for b in re.split(r"remark: [^\n]*Function Name: ", t)[1:]:
         m = re.search(k + r": (\d+)", b)
         return m.group(1) if m else "?"
     print("%-100s VGPR %3s AGPR %3s spillV %3s spillS %3s scratch %4s occ %s" % (
-        name, g("VGPRs"), g("AGPRs"), g("VGPR Spill"), g("SGPR Spill"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]")))
+        name, g("VGPRs"), g("AGPRs"), g("VGPRs Spill"), g("SGPRs Spill"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]")))

@@ -1,5 +1,5 @@
 """Both denoiser engines against the CPU oracle on the same 1024 random latents, 100 DDIM steps (run on the GPU box):
-the position-major engine (split-bf16 GEMMs on the bf16 matrix pipe) and the sample-major engine (f32 matrix pipe only:
+the position-major engine (split-f16 GEMMs on the bf16 matrix pipe) and the sample-major engine (f32 matrix pipe only:
 a descriptor without the split weight copies).   python tools/study/engines_vs_oracle.py
 Measured (round 3): split path max 1.4e-5 / mean 3.3e-7 from the oracle, f32 path max 2.0e-5 / mean 3.3e-7."""
 import sys, os, torch, time
@@ -30,7 +30,7 @@ sched = R.make_scheduler("ddim"); sched.set_timesteps(100)
 t0 = time.time()
 o, _ = R.sample_latents(sd, pre, z, sched, 4, x_T=x)
 print("oracle s", time.time() - t0)
-for name, v in (("split-bf16 PM engine", a), ("f32 sample-major engine", b)):
+for name, v in (("split-f16 PM engine", a), ("f32 sample-major engine", b)):
     d = (v - o).abs().flatten()
     print(f"{name}: vs oracle max {d.max():.2e} mean {d.mean():.2e} p99.9 {torch.quantile(d, 0.999):.2e}")
 d = (a - b).abs().flatten(); print(f"engines vs each other: max {d.max():.2e} mean {d.mean():.2e}")
