@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # GLDM_LIB: another build of the same library (diagnostic builds: make -C graspldm_amd/csrc EXTRA=... OUT=...)
 LIB_PATH = os.environ.get("GLDM_LIB") or os.path.join(_PKG, "libgldm_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class GldmError(RuntimeError):

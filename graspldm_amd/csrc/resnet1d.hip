@@ -89,7 +89,9 @@ struct Geo {
   // 64-column engines: per-sample range of a ResnetBlock's H (conv_pm3_wave): [8 waves][16] published bounds, [16] scales
   static constexpr int kMiscHb = kMiscOld + NC;
   static constexpr int kMiscHs = kMiscHb + (NC == 64 ? 8 * 16 : 0);
-  static constexpr int kLdsFloats = kMiscHs + (NC == 64 ? 16 : 0);
+  static constexpr int kMiscQ = kMiscHs + (NC == 64 ? 16 : 0);    // quad engine hand-shake words (quad_narrow.h): 8 + 4 x 64 ints
+  static constexpr int kMiscQTab = kMiscQ + (NC == 64 ? 16 + 4 * 64 : 0);   // [2 x 292] byte offsets of the quad engine's weight stream
+  static constexpr int kLdsFloats = kMiscQTab + (NC == 64 ? 2 * 292 : 0);
 };
 static_assert(Geo<64>::kLdsFloats * 4 <= 160 * 1024, "LDS budget (1 WG/CU)");
 static_assert(Geo<32>::kLdsFloats * 4 * 2 <= 160 * 1024, "LDS budget (2 WG/CU)");
@@ -2561,6 +2563,8 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
 }
 
 
+#include "quad_narrow.h"
+
 // ---------------------------------------------------------- the network ----
 // Step-segment hand-off between workgroups (a tile whose steps are split over a chain of slots).
 // The whole state of a tile between two steps is its latent row: NC floats.  Each float travels as ONE
@@ -2628,7 +2632,14 @@ struct RunArgs {
 // down conv).  It is written once per workgroup into LDS (12 ints per op) and interpreted by a switch
 // inside the step loop, so every phase body exists once, inlined, with registers allocated across the
 // whole kernel: no calls, no callee-save traffic and no spilled kernel state between phases.
-enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKVLN = 5, OP_OUTLN = 6, OP_QKVATT = 7 };
+enum { OP_CONV = 1, OP_RES4 = 2, OP_LN = 3, OP_ATT = 4, OP_QKVLN = 5, OP_OUTLN = 6, OP_QKVATT = 7, OP_QUAD = 8 };
+// The levels of 4, 32 and 64 channels in front of a 128-channel one run wave-local (quad_narrow.h): the shipped denoiser
+__host__ __device__ __forceinline__ bool quad_levels(const gldm_r1d_desc &d) {
+  return d.seq_len == 4 && d.emb_dim == 16 && d.n_levels >= 3 && d.dims[0] == 4 && d.dims[1] == 32 && d.dims[2] == 64 &&
+         d.dims[3] == 128 && d.lv[0].out_wq > 0 && d.lv[1].out_wq > 0 && d.lv[1].qkvn_wq > 0 && d.lv[1].down_wq > 0 &&
+         d.lv[2].out_wq > 0 && d.lv[2].qkvn_wq > 0 && d.lv[2].down_wq > 0 && d.rb[2].c1_wq > 0 && d.rb[2].c2_wq > 0 &&
+         d.rb[3].c1_wq > 0 && d.rb[3].c2_wq > 0 && d.rb[4].c1_wq > 0 && d.rb[4].c2_wq > 0 && d.rb[5].c1_wq > 0 && d.rb[5].c2_wq > 0;
+}
 // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9 | (scale/shift table offset / 4) << 12
 constexpr int kFlagAlias = 1 << 8;
 constexpr int kFlagFused = 1 << 11;   // position-major engine: this conv and the next tape entry are one ResnetBlock op
@@ -2750,7 +2761,7 @@ __host__ __device__ __forceinline__ bool gn_fusable(int C, int groups) {
 }
 
 template <int NC>
-__host__ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape) {
+__host__ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *tape, bool use_quad = true) {
   using GG = Geo<NC>;
   int n = 0;
   auto emit = [&](int type, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0, int a6 = 0, int a7 = 0,
@@ -2774,9 +2785,12 @@ __host__ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *
          3 | (1 << 9) | (NC == 64 ? kFlagFused : 0) | ((toff >> 2) << kFlagTabShift), rb.n1_w, rb.n1_b, rb.ss_w, rb.ss_b);
     emit(OP_CONV, NC == 64 ? rb.c2_w3 : rb.c2_w, rb.c2_b, H, X, C, C, 3 | (2 << 9), rb.n2_w, rb.n2_b, -1, 0);  // X += act(GN(conv(H)))
   };
+  const bool quad = NC == 64 && use_quad && quad_levels(d);
+  if (quad) emit(OP_QUAD);
   // constant indices only: a dynamically indexed kernel argument is copied to scratch memory
 #pragma unroll
   for (int lv = 0; lv < GLDM_R1D_MAX_LEVELS; ++lv) {
+    if (quad && lv < 3) { tab_off += 4 * d.dims[lv]; continue; }   // two ResnetBlocks' table rows each (16-position engine only)
     if (lv < d.n_levels) {
       const int C = d.dims[lv], Cn = d.dims[lv + 1];
       resblock(d.rb[2 * lv], C, false);
@@ -2837,7 +2851,7 @@ __device__ __forceinline__ void read_op(const int *tape, kernarg_int *ktape, int
 }
 
 template <int NC, int L>
-__device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, kernarg_int *ktape, int n_ops, int E, long long *stamps) {
+__device__ __forceinline__ void run_tape(const Ctx &c0, const gldm_r1d_desc &d, const int *tape, kernarg_int *ktape, int n_ops, int E, long long *stamps) {
 #if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_EXP_LDS_TAPE)   // A/B experiment: the tape from LDS as before
   constexpr bool KARG = false;
 #else
@@ -2874,6 +2888,13 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const int *tape, kernarg
         conv_gemm<NC, L>(c, o[1], o[2], c.lds + o[3], o[5], o[7] & 255, c.lds + o[4], o[6], (o[7] & kFlagAlias) != 0, 0, g);
         break;
       }
+      case OP_QUAD:
+        if constexpr (NC == 64 && L == 4) {
+          if (c.wave < 4) quad_narrow_levels(c, d);
+          else quad_loader(c);
+          __syncthreads();
+        }
+        break;
       case OP_RES4:
         if (!GLDM_SKIP(c, 8)) {
           if constexpr (NC == 64 && L == 4) resblock4_pm(c, o, E);
@@ -2980,6 +3001,10 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
 
   for (int i = c.tid; i < GG::kLdsFloats; i += GG::kThreads) lds[i] = 0.f;  // dead columns must stay finite
   __syncthreads();
+  if constexpr (PM && L == 4) {
+    static_assert(2 * kQNEnd == 2 * 292, "kMiscQTab size");
+    if (quad_levels(d)) quad_build_table(d, reinterpret_cast<int *>(lds + GG::kMiscQTab), c.tid, GG::kThreads);
+  }
   int *tape = reinterpret_cast<int *>(lds + GG::kMiscTape);
   ChainHdr *hdr = reinterpret_cast<ChainHdr *>(a.ws);
   unsigned long long *state = reinterpret_cast<unsigned long long *>(a.ws) + kChainHdrBytes / 8;
@@ -3118,6 +3143,9 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       for (int r = 0; r < R; ++r) g += silu(te + ce[r * E]);
       G[s * E + e] = g;
     }
+    if constexpr (PM && L == 4) {   // quad engine hand-shake words (quad_narrow.h): every step starts from zero
+      if (tid_o < 16 + 4 * 64) reinterpret_cast<int *>(lds + GG::kMiscQ)[tid_o] = 0;
+    }
     // ---- init conv (k = 7, one input channel); the barrier below also publishes G
     const int C0 = d.dims[0];
     // DPM++ feeds the network c_in(sigma) * x (elucidated_diffusion.py:127-128)
@@ -3163,7 +3191,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       __syncthreads();
     }
 
-    run_tape<NC, L>(c, tape, ktape, n_ops, E, blockIdx.x == 0 ? GLDM_STAMPS(a.stamps) : nullptr);
+    run_tape<NC, L>(c, d, tape, ktape, n_ops, E, blockIdx.x == 0 ? GLDM_STAMPS(a.stamps) : nullptr);
     if (GLDM_STAMPS(a.stamps) && blockIdx.x == 0 && c.tid == 0) a.stamps[n_ops] = (long long)__builtin_readcyclecounter();
 
     // ---- final 1x1 conv to one channel: eps[n] = b + sum_c w[c] X[c][n]
@@ -3522,7 +3550,11 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   a.pm_nops = 0;
   if (pm) {
     static_assert(8 * GLDM_R1D_MAX_LEVELS + 2 <= kPmMaxOps && sizeof(RunArgs) <= 4096, "64-column tape in the kernel arguments");
-    a.pm_nops = build_tape<64>(a_in.d, a.pm_tape);
+    bool use_quad = true;
+#ifdef GLDM_DEBUG_KNOBS
+    if (getenv("GLDM_R1D_NOQUAD")) use_quad = false;   // A/B: the narrow levels as position-major phases
+#endif
+    a.pm_nops = build_tape<64>(a_in.d, a.pm_tape, use_quad);
     const WsLayout wl = ws_layout(&a_in.d, a_in.n_samples);
     if (wl.park_off >= 0) a.park = reinterpret_cast<float *>(reinterpret_cast<char *>(a_in.ws) + wl.park_off);
   }
@@ -3548,7 +3580,8 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
                              : (L == 4 ? launch_one<kEngineNC, 4>(a, tiles, s) : launch_one<kEngineNC, 16>(a, tiles, s)));
   if (stamp) {
     static long long host[kMaxOps + 2];
-    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "QKVLN", "OUTLN", "QKVAT"};
+    static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "QKVLN", "OUTLN", "QKVAT", "QUAD"};
+    const bool quad = pm4 && a.pm_nops > 0 && a.pm_tape[0] == OP_QUAD;
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(host, dstamps, sizeof(host), hipMemcpyDeviceToHost);
     // the tape is rebuilt on the host only to label the stamps
@@ -3563,7 +3596,8 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
       if (C == 4 && a.d.seq_len == 4) line(2, C, C, 3);
       else { line(1, C, C, 3); line(1, C, C, 3); }
     };
-    for (int lv = 0; lv < a.d.n_levels; ++lv) {
+    if (quad) line(8, 4, 128, 3);
+    for (int lv = quad ? 3 : 0; lv < a.d.n_levels; ++lv) {
       const int C = dims[lv];
       resblock(C); resblock(C);
       if (pm16) { line(5, C, 384, 1); line(4, C, 128, 0); }
@@ -3577,6 +3611,16 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
     printf("step total (ops): %lld clk; step prologue (embedding sums, init conv): %lld clk\n", host[op] - host[0],
            host[0] - host[kMaxOps + 1]);
 #ifdef GLDM_DEBUG_KNOBS
+    if (quad) {
+      static long long qs[4][16];
+      (void)hipMemcpyFromSymbol(qs, HIP_SYMBOL(g_q_stamp), sizeof(qs));
+      static const char *qn[] = {"pads", "rb4", "rb4", "att4", "down4", "rb32", "rb32", "att32", "down32", "rb64", "rb64", "att64", "down64"};
+      for (int q = 0; q < 4; ++q) {
+        printf("quad %d:", q);
+        for (int i = 1; i <= 12; ++i) printf(" %s %lld", qn[i], qs[q][i] - qs[q][i - 1]);
+        printf(" | total %lld, polls that waited %lld\n", qs[q][12] - qs[q][0], qs[q][13]);
+      }
+    }
     if (pm) {   // per-wave view of the last 32 position-major convs of workgroup 0: k-loop / epilogue, relative to wave 0's entry
       static long long wv[8][32][8];
       int cnt[8];

@@ -22,14 +22,16 @@ SCHED_COEF_STRIDE = 8
 
 class R1dResblock(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("c1_w", "c1_b", "n1_w", "n1_b", "c2_w", "c2_b", "n2_w", "n2_b", "ss_w", "ss_b", "c1_w3", "c2_w3")]
+                ("c1_w", "c1_b", "n1_w", "n1_b", "c2_w", "c2_b", "n2_w", "n2_b", "ss_w", "ss_b", "c1_w3", "c2_w3",
+                 "c1_wq", "c2_wq")]
 
 
 class R1dLevel(ctypes.Structure):
     _fields_ = [("ln_g", ctypes.c_int32), ("qkv_w", ctypes.c_int32 * 2), ("out_w", ctypes.c_int32),
                 ("out_b", ctypes.c_int32), ("ln2_g", ctypes.c_int32), ("down_w", ctypes.c_int32),
                 ("down_b", ctypes.c_int32), ("qkvn_w", ctypes.c_int32), ("qkvn_s", ctypes.c_int32),
-                ("qkvn_w3", ctypes.c_int32), ("out_w3", ctypes.c_int32), ("down_w3", ctypes.c_int32)]
+                ("qkvn_w3", ctypes.c_int32), ("out_w3", ctypes.c_int32), ("down_w3", ctypes.c_int32),
+                ("qkvn_wq", ctypes.c_int32), ("out_wq", ctypes.c_int32), ("down_wq", ctypes.c_int32)]
 
 
 class R1dDesc(ctypes.Structure):
@@ -81,6 +83,18 @@ def mfma_a_fragments_f16x2(w2d):
     planes = planes.view(2, mt, 16, k // 32, 4, 8)                 # (plane, mt, i, kb, g, j): k = 32 kb + 8 g + j
     frag = planes.permute(1, 3, 0, 4, 2, 5).contiguous()           # (mt, kb, plane, g, i, j): lane = 16 g + i
     return frag.reshape(-1, 8).view(torch.float32).reshape(-1)     # bit pattern kept: 8 f16 = 4 floats
+
+
+def quad_perm32(w2d):
+    """Columns of every 32-channel block in the order the wave-local engine of the narrow levels reads them
+    (include/gldm.h, "Quad column order"): new[:, 32 b + 8 g + j] = old[:, 32 b + 16 (j >> 2) + 4 g + (j & 3)]."""
+    m, k = w2d.shape
+    if k % 32:
+        raise ValueError("quad order needs K % 32 == 0")
+    s = torch.arange(32)
+    g, j = s // 8, s % 8
+    src = 16 * (j // 4) + 4 * g + (j % 4)
+    return w2d.reshape(m, k // 32, 32)[:, :, src].reshape(m, k)
 
 
 def conv_as_gemm(w):
@@ -169,6 +183,9 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
         if c % 16 == 0:   # split-f16 copies for the 64-column engines (per tap a multiple of 32 channels: 16 is padded)
             rb.c1_w3 = buf.add(mfma_a_fragments_f16x2(pad_cin32(w1, c, 3)))
             rb.c2_w3 = buf.add(mfma_a_fragments_f16x2(pad_cin32(w2, c, 3)))
+            if seq_len == 4 and c in (32, 64):   # the quad engine's copies (csrc/quad_narrow.h)
+                rb.c1_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(w1)))
+                rb.c2_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(w2)))
         rb.c1_w = buf.add(mfma_a_fragments(conv_as_gemm(weight_standardize(sd[q + "block1.proj.weight"]))))
         rb.c1_b = buf.add(sd[q + "block1.proj.bias"])
         rb.n1_w = buf.add(sd[q + "block1.norm.weight"])
@@ -209,6 +226,16 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
             lv.qkvn_w3 = buf.add(mfma_a_fragments_f16x2(pad_cin32(wn, c, 1)))
             lv.down_w3 = buf.add(mfma_a_fragments_f16x2(pad_cin32(conv_as_gemm(sd[q + "3.weight"]), c, 3)))
         lv.out_w3 = buf.add(mfma_a_fragments_f16x2(sd[q + "2.fn.fn.to_out.0.weight"][:, :, 0]))
+        if seq_len == 4 and c in (4, 32, 64):
+            wo = sd[q + "2.fn.fn.to_out.0.weight"][:, :, 0]
+            if c == 4:   # one value per lane: channel ch in row 4 ch of the m-tile
+                wo4 = torch.zeros(16, wo.shape[1])
+                wo4[0::4] = wo
+                wo = wo4
+            lv.out_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(wo)))
+            if c != 4:
+                lv.qkvn_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(wn)))
+                lv.down_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(conv_as_gemm(sd[q + "3.weight"]))))
         lv.down_b = buf.add(sd[q + "3.bias"])
     resblock(p + "final_res_block.", dims[-1], slot)
     fw = sd[p + "final_conv.weight"]

@@ -152,8 +152,10 @@ typedef struct gldm_r1d_resblock {
   int32_t n2_w, n2_b;   /* block2.norm                                            */
   int32_t ss_w, ss_b;   /* mlp.1 as a [2C x E] GEMM (packed A fragments) and the
                            combined bias R*b (+R on the C scale rows): [2C]       */
-  int32_t c1_w3, c2_w3; /* ABI 5: the two conv weights again as SPLIT-bf16 fragments (see below);
+  int32_t c1_w3, c2_w3; /* ABI 5: the two conv weights again as split-f16 fragments (see below);
                            0 = absent                                              */
+  int32_t c1_wq, c2_wq; /* ABI 9: the same fragments with the columns of every 32-channel block in
+                           "quad" order (see below); 0 = absent                    */
 } gldm_r1d_resblock;
 
 typedef struct gldm_r1d_level {
@@ -167,7 +169,14 @@ typedef struct gldm_r1d_level {
                            0 / negative = absent (the position-major engine is then not used)       */
   int32_t qkvn_s;       /* ABI 4: row sums of W' [384] (the mean term of the folded LayerNorm)     */
   int32_t qkvn_w3, out_w3, down_w3; /* ABI 5: qkvn_w / out_w / down_w as split-f16 fragments; 0 = absent */
+  int32_t qkvn_wq, out_wq, down_wq; /* ABI 9: the same in quad column order; out_wq of a 4-channel level has
+                                       channel ch in row 4 ch of its one m-tile; 0 = absent              */
 } gldm_r1d_level;
+
+/* Quad column order (ABI 9; r1d_pack.quad_perm32): the wave-local engine of the narrow levels (csrc/quad_narrow.h) feeds
+ * a GEMM's B operand straight from the accumulator layout of the previous one -- lane (column, g) holds rows 4 g + r of
+ * m-tiles 2 kb and 2 kb + 1 -- so k-slot 8 g + j of a 32-channel block kb stands for channel 32 kb + 16 (j >> 2) + 4 g +
+ * (j & 3), and the weights' columns are stored in that order: W_q[:, 32 kb + 8 g + j] = W[:, 32 kb + 16 (j >> 2) + 4 g + (j & 3)]. */
 
 /* Split-f16 weight fragments (ABI 5; graspldm_amd/r1d_pack.py: mfma_a_fragments_f16x2).  Every f32 weight is
  * written as hi + mid + lo, three bf16 numbers (exact: 3 x 8 significant bits cover the 24 of an f32); the matrix
