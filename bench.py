@@ -162,19 +162,25 @@ def spawn_ranks(args):
     import socket
     import subprocess
     import threading
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     if not args.dry_run:
         have = count_gpus_without_hip()
         if have is not None and have < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) in the KFD topology")
+    # The rendezvous port: picked by binding port 0, and HELD (SO_REUSEADDR, listening) until the ranks have been started,
+    # so that no other process of this host can be handed the same number in between; rank 0's TCPStore binds it with
+    # SO_REUSEADDR as well.  The user's HSA_ENABLE_IPC_MODE_LEGACY, if set, is kept.
+    sk = socket.socket()
+    sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    sk.close()
     out0 = []
     reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
     reader.start()
@@ -321,13 +327,11 @@ def main():
     def one_batch():
         # DDPM: the per-step noise of every latent is drawn inside sample(), on the device, every batch (part of the step)
         (tm, lg), _ = ldm.generate_grasps(pcs, num_grasps=G, x_T=x_T)
-        rows = torch.cat([tm, lg], dim=1)
+        # the epilogue runs on the rank's OWN rows; what crosses xGMI is one all-gather of the result rows [B G, 7]
+        # (the latent-level outputs the north star names: 28 bytes per grasp), nothing is repeated per rank
+        H, un, conf = pose_epilogue(tm, lg, gmean, gstd, G)
         if world > 1:
-            rows = gather_results(rows, B * G, world * B * G)
-            H, un, conf = pose_epilogue(rows[:, :6].contiguous(), rows[:, 6:7].contiguous(),
-                                        gmean.repeat(world, 1), gstd.repeat(world, 1), G)
-        else:
-            H, un, conf = pose_epilogue(tm, lg, gmean, gstd, G)
+            gather_results(torch.cat([tm, lg], dim=1), B * G, world * B * G)
         return H
 
     if streams is not None:
@@ -508,6 +512,20 @@ def main():
                               avg_ms=t_sa * 1e3, achieved=by / t_sa / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
                               frac=by / t_sa / 1e9 / PEAK_HBM_GBS, algorithmic_bytes_per_launch=by,
                               traffic=sa_traffic, traffic_source=sa_src))
+          # farthest point sampling (us per cloud, distance evaluations per second; B = 1 and B = batch):
+          # the first sampling of PointNet2SSG / PVCNN2, 1024 -> 512 (sampling.cu:86-174)
+          from graspldm_amd.backend import _backend
+          crd = pcs[:, :1024].transpose(1, 2).contiguous()          # [B, 3, 1024]
+          for fb in (1, B):
+              cb = crd[:fb].contiguous()
+              fps = lambda: _backend.furthest_point_sampling(cb, 512)
+              fps()
+              t_fps = event_time(fps, 10)
+              kernels.append(dict(kernel=f"fps_wave_kernel<16, 0> (furthest_point_sampling 1024 -> 512, B = {fb}: one wave per cloud)",
+                                  bound="latency", avg_ms=t_fps * 1e3, us_per_cloud=t_fps * 1e6 / fb, us_per_round=t_fps * 1e6 / 511,
+                                  distance_evals_per_s=fb * 511 * 1024 / t_fps,
+                                  note="511 dependent rounds per cloud; a round = 1024 distance updates + a wave arg-max (round 4: "
+                                       "16 waves + LDS exchange + barrier per round, 0.62 ms = 1.2 us per round)"))
           # fused SA module core (gather + grouped MLP + max; the grouped tensor never reaches HBM)
           from graspldm_amd.pvcnn import PointNetSAModule, ball_query
           from graspldm_amd.sa_pack import SaMlpPlan
@@ -582,6 +600,7 @@ def main():
                         recs.append(json.loads(out_s.strip().splitlines()[-1]))
                     except Exception:  # noqa: BLE001
                         pr.kill()
+                        pr.wait()
                 if len(recs) == nproc:
                     secs = max(r_["seconds"] for r_ in recs)
                     runs.append(dict(threads=16 * nproc, processes=nproc, clouds=per * nproc,

@@ -71,11 +71,36 @@ _NUMPY_NAMES = ("ndarray", "dtype", "_reconstruct", "scalar", "float32", "float6
                 "int8", "int16", "float16", "Float32DType", "Float64DType", "Int64DType", "Int32DType")
 
 
+def _static_torch_globals():
+    """What a tensor-only state dict needs from torch, by exact name (the fallback for _get_allowed_globals)."""
+    import collections
+    import _codecs
+    import torch._utils as tu
+    out = {"collections.OrderedDict": collections.OrderedDict, "_codecs.encode": _codecs.encode,
+           "torch.Size": torch.Size, "torch.device": torch.device, "torch.Tensor": torch.Tensor,
+           "torch.nn.parameter.Parameter": torch.nn.Parameter, "torch.storage.UntypedStorage": torch.UntypedStorage,
+           "torch.storage.TypedStorage": torch.storage.TypedStorage}
+    for n in ("_rebuild_tensor_v2", "_rebuild_tensor", "_rebuild_parameter", "_rebuild_parameter_with_state",
+              "_rebuild_qtensor", "_rebuild_device_tensor_from_numpy"):
+        if hasattr(tu, n):
+            out[f"torch._utils.{n}"] = getattr(tu, n)
+    for n in ("FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage",
+              "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage"):
+        if hasattr(torch, n):
+            out[f"torch.{n}"] = getattr(torch, n)
+    for n in ("float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool"):
+        out[f"torch.{n}"] = getattr(torch, n)
+    return out
+
+
 def _allowed_globals():
     """{"module.name": object} -- built once; the objects themselves, so nothing is looked up by attribute walk."""
     import importlib
-    from torch._weights_only_unpickler import _get_allowed_globals
-    allowed = dict(_get_allowed_globals())
+    try:   # torch's own weights-only set; a private name, so a pinned static list stands in if a release moves it
+        from torch._weights_only_unpickler import _get_allowed_globals
+        allowed = dict(_get_allowed_globals())
+    except Exception:  # noqa: BLE001
+        allowed = _static_torch_globals()
     import builtins
     for n in _SAFE_BUILTINS:
         allowed[f"builtins.{n}"] = getattr(builtins, n)
@@ -103,11 +128,24 @@ def _is_safe_global(module, name):
     return f"{module}.{name}" in _ALLOWED
 
 
-class _TolerantUnpickler(pickle.Unpickler):
+class _TolerantUnpickler(pickle._Unpickler):
+    """The pure-Python unpickler (its opcode handlers can be overridden; the non-tensor part of a checkpoint is small).
+    BUILD with slot state on a CLASS object sets class attributes process-wide -- on allow-listed torch classes that
+    corrupts them for the rest of the process -- so BUILD is only ever applied to instances."""
+
     def find_class(self, module, name):
         if _is_safe_global(module, name):
             return _ALLOWED[f"{module}.{name}"]
         return type(name.rpartition(".")[2] or "Foreign", (_Placeholder,), {"__module__": module})
+
+    def load_build(self):
+        target = self.stack[-2]
+        if isinstance(target, type) or callable(target) and not isinstance(target, _Placeholder):
+            raise pickle.UnpicklingError(f"BUILD on a class or function object ({getattr(target, '__name__', target)!r}): refused")
+        pickle._Unpickler.load_build(self)
+
+    dispatch = dict(pickle._Unpickler.dispatch)
+    dispatch[pickle.BUILD[0]] = load_build
 
 
 class _TolerantPickle:

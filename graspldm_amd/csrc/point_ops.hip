@@ -219,6 +219,76 @@ __global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__
   }
 }
 
+// One WAVE per cloud (n <= 1024): lane l owns points l, l + 64, ... (kPer of them, in registers with their running
+// min-distances), so a round is 10 VALU instructions per point, an in-lane arg-max and ONE wave reduction -- no LDS
+// exchange, no barrier (the 16-wave form above spends most of a round's 1.2 us in its two reductions and the barrier
+// between them: 0.62 ms per 1024 -> 512 sampling whatever the batch).  The reduction runs on the two 32-bit halves of the
+// key one after the other (distance bits, then the tie word among the lanes that hold the maximal distance): four DPP row
+// steps + four v_readlane each.  The previous winner's coordinates come from LDS (a broadcast read).  Same keys, same
+// arithmetic (-ffp-contract=off) as fps_kernel: bit-identical picks.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_shr_u32(unsigned v) {   // lanes without a source read 0 (the identity of max)
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, dpp_shr_u32<0x111>(v));   // row_shr:1
+  v = max(v, dpp_shr_u32<0x112>(v));   // row_shr:2
+  v = max(v, dpp_shr_u32<0x114>(v));   // row_shr:4
+  v = max(v, dpp_shr_u32<0x118>(v));   // row_shr:8: lane 15 of every row holds the row's maximum
+  const unsigned a = __builtin_amdgcn_readlane(v, 15), b = __builtin_amdgcn_readlane(v, 31);
+  const unsigned c = __builtin_amdgcn_readlane(v, 47), d = __builtin_amdgcn_readlane(v, 63);
+  return max(max(a, b), max(c, d));
+}
+template <int kPer, int kRule>
+__global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ coords, int n, int m,
+                                                      int32_t *__restrict__ out) {
+  extern __shared__ float s_xyz[];  // [3][n]
+  const int b = blockIdx.x, lane = threadIdx.x;
+  coords += (size_t)b * 3 * n;
+  out += (size_t)b * m;
+  // Slots beyond n: distance 0 for ever (min(d, 0) = 0) and tie word 0, i.e. key 0, below every real key (whose low word
+  // is never 0): the round needs no per-point test (16 exec-masked branches per round otherwise).
+  float x[kPer], y[kPer], z[kPer], dist[kPer];
+  unsigned tiew[kPer];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const int k = lane + 64 * q;
+    const bool ok = k < n;
+    x[q] = ok ? coords[kRule == 0 ? k : 3 * k] : 0.f;
+    y[q] = ok ? coords[kRule == 0 ? k + n : 3 * k + 1] : 0.f;
+    z[q] = ok ? coords[kRule == 0 ? k + 2 * n : 3 * k + 2] : 0.f;
+    dist[q] = ok ? (kRule == 0 ? 1e38f : 1e7f) : 0.f;
+    const unsigned int tie = kRule == 0 ? ~(((unsigned int)(k & 511) << 22) | (unsigned int)k) : ~(unsigned int)k;
+    tiew[q] = ok ? tie : 0u;
+    if (ok) {
+      s_xyz[k] = x[q];
+      s_xyz[k + n] = y[q];
+      s_xyz[k + 2 * n] = z[q];
+    }
+  }
+  if (lane == 0) out[0] = 0;
+  __syncthreads();
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = s_xyz[old], y1 = s_xyz[old + n], z1 = s_xyz[old + 2 * n];
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      float d = (x[q] - x1) * (x[q] - x1) + (y[q] - y1) * (y[q] - y1) + (z[q] - z1) * (z[q] - z1);
+      if (kRule == 1) d = __fsqrt_rn(d);
+      const float d2 = d < dist[q] ? d : dist[q];
+      dist[q] = d2;
+      const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | tiew[q];
+      best = key > best ? key : best;
+    }
+    const unsigned hi = (unsigned)(best >> 32), lo = (unsigned)best;
+    const unsigned hmax = wave_max_u32(hi);
+    const unsigned lmax = wave_max_u32(hi == hmax ? lo : 0u);
+    old = (int)((~lmax) & 0x3FFFFFu);
+    if (lane == 0) out[j] = old;
+  }
+}
+
 // -------------------------------------------------- 3-NN + interpolation --
 __global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__ points,
                                                        const float *__restrict__ centers, int n, int m,
@@ -766,13 +836,19 @@ int launch_fps(const float *coords, int b, int n, int m, int32_t *out, hipStream
                      s, coords, n, m, out);
   return launch_status();
 }
+template <int kPer, int kRule>
+int launch_fps_wave(const float *coords, int b, int n, int m, int32_t *out, hipStream_t s) {
+  hipLaunchKernelGGL((fps_wave_kernel<kPer, kRule>), dim3(b), dim3(64), (size_t)3 * n * sizeof(float), s, coords, n, m, out);
+  return launch_status();
+}
 template <int kRule>
 int dispatch_fps(const float *coords, int b, int n, int m, int32_t *out_idx, hipStream_t s) {
-  if (n <= 64) return launch_fps<64, 1, kRule>(coords, b, n, m, out_idx, s);
-  if (n <= 128) return launch_fps<128, 1, kRule>(coords, b, n, m, out_idx, s);
-  if (n <= 256) return launch_fps<256, 1, kRule>(coords, b, n, m, out_idx, s);
-  if (n <= 512) return launch_fps<512, 1, kRule>(coords, b, n, m, out_idx, s);
-  if (n <= 1024) return launch_fps<1024, 1, kRule>(coords, b, n, m, out_idx, s);
+  // up to 1024 points: one wave per cloud, no barrier in the round (fps_wave_kernel)
+  if (n <= 64) return launch_fps_wave<1, kRule>(coords, b, n, m, out_idx, s);
+  if (n <= 128) return launch_fps_wave<2, kRule>(coords, b, n, m, out_idx, s);
+  if (n <= 256) return launch_fps_wave<4, kRule>(coords, b, n, m, out_idx, s);
+  if (n <= 512) return launch_fps_wave<8, kRule>(coords, b, n, m, out_idx, s);
+  if (n <= 1024) return launch_fps_wave<16, kRule>(coords, b, n, m, out_idx, s);
   if (n <= 2048) return launch_fps<1024, 2, kRule>(coords, b, n, m, out_idx, s);
   if (n <= 4096) return launch_fps<1024, 4, kRule>(coords, b, n, m, out_idx, s);
   return launch_fps<1024, 8, kRule>(coords, b, n, m, out_idx, s);

@@ -35,8 +35,11 @@ def gather_results(local_rows, per_rank_rows, total_rows, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local_rows[:total_rows]
-    pad = torch.zeros((per_rank_rows, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
-    pad[: local_rows.shape[0]] = local_rows
+    if local_rows.shape[0] == per_rank_rows:   # the usual case (equal shards): nothing to pad, nothing to allocate
+        pad = local_rows.contiguous()
+    else:
+        pad = torch.zeros((per_rank_rows, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
+        pad[: local_rows.shape[0]] = local_rows
     out = torch.empty((world * per_rank_rows, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
     dist.all_gather_into_tensor(out, pad, group=group)
     return out[:total_rows]

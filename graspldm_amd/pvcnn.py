@@ -310,8 +310,9 @@ class SE3d(nn.Module):
         w1, w2 = self.fc[0].weight, self.fc[2].weight
         b, c = chan_sum.shape
         gate = torch.empty((b, c), dtype=torch.float32, device=chan_sum.device)
+        cs = chan_sum.contiguous().float()   # referenced by a local until the call returns, like every launch operand
         with torch.cuda.device(chan_sum.device):
-            L.call("gldm_se_gate", L.ptr(chan_sum.contiguous().float()), L.ptr(w1), L.ptr(w2), b, c, w1.shape[0], int(r),
+            L.call("gldm_se_gate", L.ptr(cs), L.ptr(w1), L.ptr(w2), b, c, w1.shape[0], int(r),
                    1 if self.use_relu else 0, L.ptr(gate), L.current_stream(chan_sum.device))
         return gate
 

@@ -26,7 +26,8 @@ class R1dEngine:
         return ctypes.cast(ctypes.pointer(self.desc), ctypes.c_void_p)
 
     def _workspace(self, n):
-        need = L.lib().gldm_r1d_workspace_bytes(self._desc_ptr(), int(n))
+        with torch.cuda.device(self.device):   # the size depends on the device's compute-unit count (park scratch per workgroup)
+            need = L.lib().gldm_r1d_workspace_bytes(self._desc_ptr(), int(n))
         if need < 0:
             raise L.GldmError("gldm_r1d_workspace_bytes: this ResNet1D configuration is not supported by the HIP engine")
         key = torch.cuda.current_stream(self.device).cuda_stream
