@@ -60,10 +60,7 @@ __device__ __forceinline__ float pos_sum(float v) {   // over the 4 positions of
   v += dpp_mov<0x124>(v);
   return v + dpp_mov<0x128>(v);
 }
-__device__ __forceinline__ float pos_max(float v) {
-  v = fmaxf(v, dpp_mov<0x124>(v));
-  return fmaxf(v, dpp_mov<0x128>(v));
-}
+__device__ __forceinline__ float pos_max(float v) { return dpp_max<0x128>(dpp_max<0x124>(v)); }
 __device__ __forceinline__ float kq_sum(float v) { return half_sum(row_pair_sum(v)); }   // over the four row quarters
 __device__ __forceinline__ float kq_max(float v) { return half_max(row_pair_max(v)); }
 

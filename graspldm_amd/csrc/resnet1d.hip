@@ -183,9 +183,31 @@ __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcp
 // Cross-lane reductions on the VALU: DPP operands for the lanes of a sample (quad / row mirrors: each
 // step adds the partial sum of the complementary lane group, so every lane ends with the total) and
 // v_permlane32_swap for the two halves of a wave.  A ds_bpermute shuffle costs an LDS round trip each.
+// (mov_dpp leaves the destination's previous value undefined for lanes without a source -- every control used with it
+// covers all lanes; update_dpp(0, ...) made the compiler clear the destination with a v_mov_b32 in front of every one.)
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+  static_assert(CTRL <= 0xFF || (CTRL >= 0x121 && CTRL <= 0x12F) || CTRL == 0x140 || CTRL == 0x141, "a control that covers all lanes");
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// max(a, b) as ONE instruction: fmaxf on values that come out of a bit cast (DPP / permlane results) gets a canonicalising
+// v_max_f32 x, x per operand in front of it
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// max(x, x seen through the DPP control): one v_max_f32_dpp (the s_nop covers the VALU-write -> DPP-read hazard, which
+// nobody checks inside an asm statement)
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float x) {
+  float r;
+  if constexpr (CTRL == 0x124) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  else if constexpr (CTRL == 0x128) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  else if constexpr (CTRL == 0xB1) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  else if constexpr (CTRL == 0x4E) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+  else static_assert(CTRL == 0x124, "add the control's assembler spelling");
+  return r;
 }
 template <int L>
 __device__ __forceinline__ float group_sum(float x) {  // sum over the L lanes (columns) of a sample
@@ -205,11 +227,11 @@ __device__ __forceinline__ float row_pair_sum(float x) {  // lanes i and i ^ 16
 }
 __device__ __forceinline__ float row_pair_max(float x) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  return vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float half_max(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  return vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 #ifdef GLDM_DEBUG_KNOBS
@@ -1373,8 +1395,8 @@ __device__ __forceinline__ void conv_pm3_wave(const Ctx &c, const float *wp, con
       for (int r = 0; r < 4; ++r)
         hb = fmaxf(hb, fmaf(__builtin_fabsf(ga[mi][r] * sc[mi][r]), kR, __builtin_fabsf(fmaf(be[mi][r], sc[mi][r], sh[mi][r]))));
     if constexpr (LL == 16) {
-      hb = fmaxf(hb, dpp_mov<0x124>(hb));
-      hb = fmaxf(hb, dpp_mov<0x128>(hb));
+      hb = dpp_max<0x124>(hb);
+      hb = dpp_max<0x128>(hb);
     }
     hb = half_max(row_pair_max(hb));
     if (kq == 0 && (LL != 16 || (cl >> 2) == 0)) ((lds_f *)(c.lds + GG::kMiscHb))[c.wave * 16 + sm] = hb;   // shadow waves too
@@ -2065,8 +2087,8 @@ __device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv, int C) 
         k[j] = q3[off[j] + 2048 * rd];
         km = fmaxf(km, k[j]);
       }
-      km = fmaxf(km, dpp_mov<0x124>(km));   // the other three tiles: row_ror 4, 8
-      km = fmaxf(km, dpp_mov<0x128>(km));
+      km = dpp_max<0x124>(km);   // the other three tiles: row_ror 4, 8
+      km = dpp_max<0x128>(km);
       float ks = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -2091,8 +2113,8 @@ __device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv, int C) 
         q[j] = q3[base + 64 * j + 4096 * rd];
         qm = fmaxf(qm, q[j]);
       }
-      qm = fmaxf(qm, dpp_mov<0xB1>(qm));
-      qm = fmaxf(qm, dpp_mov<0x4E>(qm));  // the four channel quarters of a column: one quad
+      qm = dpp_max<0xB1>(qm);
+      qm = dpp_max<0x4E>(qm);  // the four channel quarters of a column: one quad
       float qs = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -2499,7 +2521,7 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
         k[j] = w3[swz<NC>(row, col0 + j)];
         km = fmaxf(km, k[j]);
       }
-      km = fmaxf(km, dpp_mov<0xB1>(km));  // the other half of the sample's positions: lane ^ 1
+      km = dpp_max<0xB1>(km);  // the other half of the sample's positions: lane ^ 1
       float ks = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -2521,8 +2543,8 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
         q[j] = w3[swz<NC>(row0 + j, col)];
         qm = fmaxf(qm, q[j]);
       }
-      qm = fmaxf(qm, dpp_mov<0xB1>(qm));
-      qm = fmaxf(qm, dpp_mov<0x4E>(qm));  // the four channel quarters of a column: one quad
+      qm = dpp_max<0xB1>(qm);
+      qm = dpp_max<0x4E>(qm);  // the four channel quarters of a column: one quad
       float qs = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -4069,8 +4091,8 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
 // [cout][centres] leaves the CU.  LDS: region A [max(cin_pad0, cout1)][128] (the gathered tile, later layer 2's
 // output) + region B [cout0][128] (+ [cout2] for 4 layers).  Shapes outside this plan run on sa_mlp_kernel.
 __device__ __forceinline__ float row16_max(float x) {  // max over the 16 lanes of a DPP row
-  x = fmaxf(x, dpp_mov<0xB1>(x));   // quad_perm [1,0,3,2]
-  x = fmaxf(x, dpp_mov<0x4E>(x));   // quad_perm [2,3,0,1]
+  x = dpp_max<0xB1>(x);   // quad_perm [1,0,3,2]
+  x = dpp_max<0x4E>(x);   // quad_perm [2,3,0,1]
   x = fmaxf(x, dpp_mov<0x141>(x));  // row_half_mirror
   x = fmaxf(x, dpp_mov<0x140>(x));  // row_mirror
   return x;
