@@ -637,7 +637,12 @@ __device__ __forceinline__ float quad_attention4(const Ctx &c, QRing &ring, cons
 // The chain.  d: the descriptor (constant indices only).  Entry: X rows 0 .. 3 (f32, position-major columns) hold the init
 // conv's output, G the embedding sums.  Exit: the 128-channel residual stream as f32 rows 0 .. 127 and X planes in the
 // position-major layout.  Runs on waves 0-3; the caller puts a barrier behind it.
-__device__ __forceinline__ void quad_narrow_levels(const Ctx &c, const gldm_r1d_desc &d) {
+typedef __attribute__((address_space(4))) const gldm_r1d_desc kernarg_desc;
+// dk: the descriptor where it lies in the kernel-argument segment.  Every stage re-reads the few offsets it needs with
+// scalar loads through a laundered copy of the pointer: read through a reference to the by-value argument they were all
+// loaded at kernel entry, kept across the whole kernel and spilled (v_readlane in front of every use).
+#define GLDM_QDESC() asm volatile("" : "+s"(dk))
+__device__ __forceinline__ void quad_narrow_levels(const Ctx &c, kernarg_desc *dk) {
   using GG = Geo<64>;
   using std::integral_constant;
   const int q = c.wave, col = c.lane & 15, kq = c.lane >> 4;
@@ -654,28 +659,31 @@ __device__ __forceinline__ void quad_narrow_levels(const Ctx &c, const gldm_r1d_
   GLDM_QSTAMP(c, 0);
   qring_load<0>(ring); qring_load<1>(ring); qring_load<2>(ring); qring_load<3>(ring);
   static_assert(kQR == 4, "priming loads");
-#define GLDM_QRB4(i) QRb4{d.rb[i].c1_w, d.rb[i].c1_b, d.rb[i].n1_w, d.rb[i].n1_b, d.rb[i].c2_w, d.rb[i].c2_b, d.rb[i].n2_w, d.rb[i].n2_b, d.rb[i].ss_w, d.rb[i].ss_b}
-#define GLDM_QRB(i) QRb{d.rb[i].c1_b, d.rb[i].n1_w, d.rb[i].n1_b, d.rb[i].c2_b, d.rb[i].n2_w, d.rb[i].n2_b, d.rb[i].ss_b}
-#define GLDM_QLV(i) QLv{d.lv[i].qkvn_s, d.lv[i].out_b, d.lv[i].ln2_g}
+#define GLDM_QRB4(i) QRb4{dk->rb[i].c1_w, dk->rb[i].c1_b, dk->rb[i].n1_w, dk->rb[i].n1_b, dk->rb[i].c2_w, dk->rb[i].c2_b, dk->rb[i].n2_w, dk->rb[i].n2_b, dk->rb[i].ss_w, dk->rb[i].ss_b}
+#define GLDM_QRB(i) QRb{dk->rb[i].c1_b, dk->rb[i].n1_w, dk->rb[i].n1_b, dk->rb[i].c2_b, dk->rb[i].n2_w, dk->rb[i].n2_b, dk->rb[i].ss_b}
+#define GLDM_QLV(i) QLv{dk->lv[i].qkvn_s, dk->lv[i].out_b, dk->lv[i].ln2_g}
   // ---- 4-channel level
+  GLDM_QDESC();
   const QRb4W p0 = quad_resblock4_load(c, GLDM_QRB4(0)), p1 = quad_resblock4_load(c, GLDM_QRB4(1));
   float x = ((const lds_f *)(c.lds + GG::kBufX))[pswz(kq, pmcol)];
   x = quad_resblock4(c, p0, x, smp);
   GLDM_QSTAMP(c, 1);
   x = quad_resblock4(c, p1, x, smp);
   GLDM_QSTAMP(c, 2);
-  x = quad_attention4(c, ring, QLv4{d.lv[0].qkvn_w, d.lv[0].out_b, d.lv[0].ln2_g}, x);
+  GLDM_QDESC();
+  x = quad_attention4(c, ring, QLv4{dk->lv[0].qkvn_w, dk->lv[0].out_b, dk->lv[0].ln2_g}, x);
   GLDM_QSTAMP(c, 3);
   // down conv 4 -> 32: K = 3 taps x 4 channels as three K = 4 steps of the f32 MFMA (k-step = tap, k = channel = kq)
   f32x4 x32[2];
   u32x4 xp32[1][kSplit];
   {
-    const WStream wd(w + d.lv[0].down_w, c.lane);
+    GLDM_QDESC();
+    const WStream wd(w + dk->lv[0].down_w, c.lane);
     const float xl = dpp_zero<0x114>(x), xrr = dpp_zero<0x104>(x);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const f32x4 a = wd[(size_t)mi * 64];
-      f32x4 acc = *reinterpret_cast<const f32x4 *>(w + d.lv[0].down_b + 16 * mi + 4 * kq);
+      f32x4 acc = *reinterpret_cast<const f32x4 *>(w + dk->lv[0].down_b + 16 * mi + 4 * kq);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], xl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], xrr, acc, 0, 0, 0);
@@ -686,17 +694,22 @@ __device__ __forceinline__ void quad_narrow_levels(const Ctx &c, const gldm_r1d_
   // ---- 32-channel level
   GLDM_QSTAMP(c, 4);
   constexpr int kRb1 = qrb_len(2, 1), kAtt1 = qatt_len(2, 1);
+  GLDM_QDESC();
   quad_resblock<kQN1, 2, 1>(c, ring, GLDM_QRB(2), x32, xp32, smp);
   GLDM_QSTAMP(c, 5);
+  GLDM_QDESC();
   quad_resblock<kQN1 + kRb1, 2, 1>(c, ring, GLDM_QRB(3), x32, xp32, smp);
   GLDM_QSTAMP(c, 6);
+  GLDM_QDESC();
   quad_attention<kQN1 + 2 * kRb1, 2, 1>(c, ring, GLDM_QLV(1), x32, xp32);
   GLDM_QSTAMP(c, 7);
   f32x4 x64[4];
   u32x4 xp64[2][kSplit];
   {
+    GLDM_QDESC();
+    const int down_b1 = dk->lv[1].down_b;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) x64[mi] = *reinterpret_cast<const f32x4 *>(w + d.lv[1].down_b + 16 * mi + 4 * kq);
+    for (int mi = 0; mi < 4; ++mi) x64[mi] = *reinterpret_cast<const f32x4 *>(w + down_b1 + 16 * mi + 4 * kq);
     qconv3<kQN1 + 2 * kRb1 + kAtt1, 4, 1>(ring, xp32, x64);
     qsplit8(x64[0], x64[1], xp64[0]);
     qsplit8(x64[2], x64[3], xp64[1]);
@@ -704,20 +717,25 @@ __device__ __forceinline__ void quad_narrow_levels(const Ctx &c, const gldm_r1d_
   // ---- 64-channel level
   GLDM_QSTAMP(c, 8);
   constexpr int kRb2 = qrb_len(4, 2), kAtt2 = qatt_len(4, 2);
+  GLDM_QDESC();
   quad_resblock<kQN2, 4, 2>(c, ring, GLDM_QRB(4), x64, xp64, smp);
   GLDM_QSTAMP(c, 9);
+  GLDM_QDESC();
   quad_resblock<kQN2 + kRb2, 4, 2>(c, ring, GLDM_QRB(5), x64, xp64, smp);
   GLDM_QSTAMP(c, 10);
+  GLDM_QDESC();
   quad_attention<kQN2 + 2 * kRb2, 4, 2>(c, ring, GLDM_QLV(2), x64, xp64);
   GLDM_QSTAMP(c, 11);
   // down conv 64 -> 128, four m-tiles at a time: the 128-channel level's residual stream, position-major
   {
     lds_f *X3 = (lds_f *)(c.lds + GG::kBufX);
+    GLDM_QDESC();
+    const int down_b2 = dk->lv[2].down_b;
     auto pass = [&](auto h_c) {
       constexpr int half = decltype(h_c)::value;
       f32x4 acc[4];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) acc[mi] = *reinterpret_cast<const f32x4 *>(w + d.lv[2].down_b + 16 * (4 * half + mi) + 4 * kq);
+      for (int mi = 0; mi < 4; ++mi) acc[mi] = *reinterpret_cast<const f32x4 *>(w + down_b2 + 16 * (4 * half + mi) + 4 * kq);
       qconv3<kQN2 + 2 * kRb2 + kAtt2 + 24 * half, 4, 2>(ring, xp64, acc);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
@@ -734,6 +752,7 @@ __device__ __forceinline__ void quad_narrow_levels(const Ctx &c, const gldm_r1d_
   if (blockIdx.x == 0 && c.lane == 0) g_q_stamp[c.wave][13] = ring.spins;
 #endif
   static_assert(kQN2 + 2 * kRb2 + kAtt2 + 48 == kQNEnd, "stream length");
+#undef GLDM_QDESC
 #undef GLDM_QRB4
 #undef GLDM_QRB
 #undef GLDM_QLV

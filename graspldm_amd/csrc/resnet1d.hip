@@ -2912,7 +2912,9 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const gldm_r1d_desc &d, 
       }
       case OP_QUAD:
         if constexpr (NC == 64 && L == 4) {
-          if (c.wave < 4) quad_narrow_levels(c, d);
+          if (c.wave < 4)
+            quad_narrow_levels(c, (kernarg_desc *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                    offsetof(RunArgs, d)));
           else quad_loader(c);
           __syncthreads();
         }
