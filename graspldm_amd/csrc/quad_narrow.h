@@ -143,7 +143,7 @@ constexpr int kQG = 4;            // fragments per group
 constexpr int kQS = 32;           // LDS slots (64 KiB): 8 groups
 constexpr int kQGroups = kQNEnd / kQG;
 static_assert(kQNEnd % kQG == 0 && kQS % kQG == 0, "whole groups");
-constexpr int kQR = 4;            // fragments a quad holds in registers ahead of their use
+constexpr int kQR = 6;            // fragments a quad holds in registers ahead of their use
 constexpr int kQSpinMax = 1 << 20; // every wait is bounded (a healthy one is a few polls): a lost hand-shake ends in wrong numbers, not a hang
 // slots 0..15 in the H-plane region of the wide levels, 16..31 behind their X planes: neither overlaps the f32 rows
 // 0 .. 127 or the X planes the chain's last conv writes while other quads are still on their way
@@ -182,6 +182,9 @@ __device__ __forceinline__ void qring_load(QRing &ring) {
       }
       if constexpr (g + 1 < kQGroups) ring.flag = *(volatile lds_i *)(ring.sync + ((g + 1) & 7));
     }
+#if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_QEXP_NOLOAD)   // timing experiment (wrong results): fragments are never read
+    if (N >= kQR) return;
+#endif
     const lds_u4 *slot = (const lds_u4 *)(ring.lds + qslot_floats(N % kQS)) + ring.lane;
     ring.s[N % kQR][0] = slot[0];
     ring.s[N % kQR][1] = slot[64];
@@ -190,9 +193,15 @@ __device__ __forceinline__ void qring_load(QRing &ring) {
 // acc += (stream fragment N) * B, then refill the registers; behind a group's last fragment: tell the loaders
 template <int N>
 __device__ __forceinline__ f32x4 qring_mfma(QRing &ring, const u32x4 (&b)[kSplit], f32x4 acc) {
+#if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_QEXP_NOMFMA)   // timing experiment (wrong results): no matrix instruction
+  acc[0] += __uint_as_float(ring.s[N % kQR][0][0] ^ b[0][0]);
+#else
   acc = mfma_split(ring.s[N % kQR], b, acc);
+#endif
   if constexpr (N % kQG == kQG - 1) ring.sync[16 + 64 * ring.quad + ring.lane] = N / kQG + 1;
-  qring_load<N + kQR>(ring);
+  // refill the registers of the PREVIOUS fragment: this one's are still being read by the MFMAs just issued (a load into
+  // them waits for the matrix pipe to have taken its operands)
+  if constexpr (N >= 1) qring_load<N - 1 + kQR>(ring);
   return acc;
 }
 
@@ -331,7 +340,7 @@ __device__ __forceinline__ void quad_resblock(const Ctx &c, QRing &ring, const Q
         sc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a_sc[j]), gb[j], sc[mi], 0, 0, 0);
         sh[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a_sh[j]), gb[j], sh[mi], 0, 0, 0);
       }
-      qring_load<N0 + mi + kQR>(ring);
+      if constexpr (N0 + mi >= 1) qring_load<N0 + mi - 1 + kQR>(ring);
     };
     ss_m(integral_constant<int, 0>{}); ss_m(integral_constant<int, 1>{});
     if constexpr (MT > 2) { ss_m(integral_constant<int, 2>{}); ss_m(integral_constant<int, 3>{}); }
@@ -657,8 +666,8 @@ __device__ __forceinline__ void quad_narrow_levels(const Ctx &c, kernarg_desc *d
   ring.quad = q;
   ring.flag = 0;   // group 0: the polling path
   GLDM_QSTAMP(c, 0);
-  qring_load<0>(ring); qring_load<1>(ring); qring_load<2>(ring); qring_load<3>(ring);
-  static_assert(kQR == 4, "priming loads");
+  qring_load<0>(ring); qring_load<1>(ring); qring_load<2>(ring); qring_load<3>(ring); qring_load<4>(ring);   // fragments 0 .. kQR - 2; then each use requests one more
+  static_assert(kQR == 6, "priming loads");
 #define GLDM_QRB4(i) QRb4{dk->rb[i].c1_w, dk->rb[i].c1_b, dk->rb[i].n1_w, dk->rb[i].n1_b, dk->rb[i].c2_w, dk->rb[i].c2_b, dk->rb[i].n2_w, dk->rb[i].n2_b, dk->rb[i].ss_w, dk->rb[i].ss_b}
 #define GLDM_QRB(i) QRb{dk->rb[i].c1_b, dk->rb[i].n1_w, dk->rb[i].n1_b, dk->rb[i].c2_b, dk->rb[i].n2_w, dk->rb[i].n2_b, dk->rb[i].ss_b}
 #define GLDM_QLV(i) QLv{dk->lv[i].qkvn_s, dk->lv[i].out_b, dk->lv[i].ln2_g}

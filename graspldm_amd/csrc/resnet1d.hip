@@ -234,7 +234,7 @@ __device__ __forceinline__ float half_max(float x) {
   return vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-#ifdef GLDM_DEBUG_KNOBS
+#if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_WAVE_STAMPS)   // per-wave conv stamps cost ~1.5 k cycles per op: their own switch
 __device__ long long g_wv_stamp[8][32][8];   // per wave, ring of the last 32 position-major convs: in, k-loop done, out, shape,
                                              // statistics published (in front of the exchange barrier), partners merged
 __device__ int g_wv_cnt[8];
@@ -3645,6 +3645,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
         printf(" | total %lld, polls that waited %lld\n", qs[q][12] - qs[q][0], qs[q][13]);
       }
     }
+#ifdef GLDM_WAVE_STAMPS
     if (pm) {   // per-wave view of the last 32 position-major convs of workgroup 0: k-loop / epilogue, relative to wave 0's entry
       static long long wv[8][32][8];
       int cnt[8];
@@ -3660,6 +3661,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
         printf("\n");
       }
     }
+#endif
 #endif
   }
   return rc;
