@@ -2912,10 +2912,10 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const gldm_r1d_desc &d, 
       }
       case OP_QUAD:
         if constexpr (NC == 64 && L == 4) {
-          kernarg_desc *dk = (kernarg_desc *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() +
-                                              offsetof(RunArgs, d));
-          if (c.wave < 4) quad_narrow_levels<0>(c, dk, c.wave);
-          else quad_narrow_levels<1>(c, dk, c.wave - 4);
+          if (c.wave < 4)
+            quad_narrow_levels(c, (kernarg_desc *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                    offsetof(RunArgs, d)));
+          else quad_loader(c);
           __syncthreads();
         }
         break;
@@ -3636,11 +3636,11 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
            host[0] - host[kMaxOps + 1]);
 #ifdef GLDM_DEBUG_KNOBS
     if (quad) {
-      static long long qs[8][16];
+      static long long qs[4][16];
       (void)hipMemcpyFromSymbol(qs, HIP_SYMBOL(g_q_stamp), sizeof(qs));
       static const char *qn[] = {"pads", "rb4", "rb4", "att4", "down4", "rb32", "rb32", "att32", "down32", "rb64", "rb64", "att64", "down64"};
-      for (int q = 0; q < 8; ++q) {
-        printf("quad %d half %d:", q & 3, q >> 2);
+      for (int q = 0; q < 4; ++q) {
+        printf("quad %d:", q);
         for (int i = 1; i <= 12; ++i) printf(" %s %lld", qn[i], qs[q][i] - qs[q][i - 1]);
         printf(" | total %lld, polls that waited %lld\n", qs[q][12] - qs[q][0], qs[q][13]);
       }
