@@ -666,7 +666,7 @@ __device__ __forceinline__ void quad_narrow_levels(const Ctx &c, kernarg_desc *d
   ring.quad = q;
   ring.flag = 0;   // group 0: the polling path
   GLDM_QSTAMP(c, 0);
-  qring_load<0>(ring); qring_load<1>(ring); qring_load<2>(ring); qring_load<3>(ring); qring_load<4>(ring);   // fragments 0 .. kQR - 2; then each use requests one more
+  qring_load<0>(ring); qring_load<1>(ring); qring_load<2>(ring); qring_load<3>(ring); qring_load<4>(ring); qring_load<5>(ring);   // fragments 0 .. kQR - 1; then the use of fragment N >= 1 requests fragment N - 1 + kQR
   static_assert(kQR == 6, "priming loads");
 #define GLDM_QRB4(i) QRb4{dk->rb[i].c1_w, dk->rb[i].c1_b, dk->rb[i].n1_w, dk->rb[i].n1_b, dk->rb[i].c2_w, dk->rb[i].c2_b, dk->rb[i].n2_w, dk->rb[i].n2_b, dk->rb[i].ss_w, dk->rb[i].ss_b}
 #define GLDM_QRB(i) QRb{dk->rb[i].c1_b, dk->rb[i].n1_w, dk->rb[i].n1_b, dk->rb[i].c2_b, dk->rb[i].n2_w, dk->rb[i].n2_b, dk->rb[i].ss_b}
