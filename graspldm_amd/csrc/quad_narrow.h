@@ -419,14 +419,28 @@ __device__ __forceinline__ void quad_resblock(const Ctx &c, QRing &ring, const Q
 //   k: softmax over the sample's positions; q: softmax over the head's 32 channels, times dim_head^-0.5;
 //   A[m][n] = sum_d k[d][m] q[d][n];  out[e][n] = sum_m v[e][m] A[m][n].
 // Positions of the same sample sit 4 lanes apart in the row: position p - j is a row rotation by 4 j.
+// acc += (a seen through a row rotation by 4 J lanes) * b as ONE v_fmac_f32_dpp (the compiler emits v_mov_b32_dpp + v_fma).
+// The DPP operand must not have been written by the two instructions in front (nobody checks that inside an asm statement):
+// the callers put an s_nop behind the code that produces `a`.
+template <int J>
+__device__ __forceinline__ float fmac_ror(float acc, float a, float b) {
+  static_assert(J >= 1 && J <= 3, "rotations by 4, 8, 12 lanes");
+  if constexpr (J == 1) asm("v_fmac_f32_dpp %0, %1, %2 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b));
+  else if constexpr (J == 2) asm("v_fmac_f32_dpp %0, %1, %2 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b));
+  else asm("v_fmac_f32_dpp %0, %1, %2 row_ror:12 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b));
+  return acc;
+}
+// L2E: q and k arrive multiplied by log2(e) (the callers fold it into the normalisation they apply anyway)
+template <bool L2E>
 __device__ __forceinline__ void quad_attention_head(const f32x4 (&qa)[2], const f32x4 (&ka)[2], const f32x4 (&va)[2], f32x4 (&out)[2]) {
+  constexpr float kL2e = 1.44269504088896340736f;
   float kn[2][4], qe[2][4];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float m = pos_max(ka[h][r]);
-      const float ex = fast_exp(ka[h][r] - m);
+      const float ex = L2E ? __builtin_amdgcn_exp2f(ka[h][r] - m) : __builtin_amdgcn_exp2f((ka[h][r] - m) * kL2e);
       kn[h][r] = ex * __builtin_amdgcn_rcpf(pos_sum(ex));
     }
   float qm = fmaxf(fmaxf(fmaxf(qa[0][0], qa[0][1]), fmaxf(qa[0][2], qa[0][3])), fmaxf(fmaxf(qa[1][0], qa[1][1]), fmaxf(qa[1][2], qa[1][3])));
@@ -436,32 +450,35 @@ __device__ __forceinline__ void quad_attention_head(const f32x4 (&qa)[2], const 
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      qe[h][r] = fast_exp(qa[h][r] - qm);
+      qe[h][r] = L2E ? __builtin_amdgcn_exp2f(qa[h][r] - qm) : __builtin_amdgcn_exp2f((qa[h][r] - qm) * kL2e);
       qs += qe[h][r];
     }
   const float qscale = 0.17677669529663687f * __builtin_amdgcn_rcpf(kq_sum(qs));   // dim_head ** -0.5 / sum
   // A_j = sum_d k[d][p - j] q[d][p], j = 0..3 (this lane's channels, then the row quarters)
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 1");   // kn is read through DPP below
   float A[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float a = 0.f;
+  {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float kr = j == 0 ? kn[h][r] : (j == 1 ? dpp_mov<0x124>(kn[h][r]) : (j == 2 ? dpp_mov<0x128>(kn[h][r]) : dpp_mov<0x12C>(kn[h][r])));
-        a = fmaf(kr, qe[h][r], a);
+        a0 = fmaf(kn[h][r], qe[h][r], a0);
+        a1 = fmac_ror<1>(a1, kn[h][r], qe[h][r]);
+        a2 = fmac_ror<2>(a2, kn[h][r], qe[h][r]);
+        a3 = fmac_ror<3>(a3, kn[h][r], qe[h][r]);
       }
-    A[j] = kq_sum(a) * qscale;
+    A[0] = kq_sum(a0) * qscale; A[1] = kq_sum(a1) * qscale; A[2] = kq_sum(a2) * qscale; A[3] = kq_sum(a3) * qscale;
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float o = va[h][r] * A[0];
-      o = fmaf(dpp_mov<0x124>(va[h][r]), A[1], o);
-      o = fmaf(dpp_mov<0x128>(va[h][r]), A[2], o);
-      o = fmaf(dpp_mov<0x12C>(va[h][r]), A[3], o);
+      o = fmac_ror<1>(o, va[h][r], A[1]);
+      o = fmac_ror<2>(o, va[h][r], A[2]);
+      o = fmac_ror<3>(o, va[h][r], A[3]);
       out[h][r] = o;
     }
 }
@@ -512,12 +529,14 @@ __device__ __forceinline__ void quad_attention(const Ctx &c, QRing &ring, const 
     mt6(integral_constant<int, 0>{}); mt6(integral_constant<int, 1>{}); mt6(integral_constant<int, 2>{});
     mt6(integral_constant<int, 3>{}); mt6(integral_constant<int, 4>{}); mt6(integral_constant<int, 5>{});
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 6; ++i) {   // q and k times log2(e): their softmaxes exponentiate with v_exp_f32 = 2^x
+      const float ra = i < 4 ? rstd * 1.44269504088896340736f : rstd, ma = i < 4 ? mr * 1.44269504088896340736f : mr;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) qkv[i][r] = qkv[i][r] * rstd - mr * sv[i][r];
+      for (int r = 0; r < 4; ++r) qkv[i][r] = qkv[i][r] * ra - ma * sv[i][r];
+    }
     f32x4 o[2];
     const f32x4 qa[2] = {qkv[0], qkv[1]}, ka[2] = {qkv[2], qkv[3]}, va[2] = {qkv[4], qkv[5]};
-    quad_attention_head(qa, ka, va, o);
+    quad_attention_head<true>(qa, ka, va, o);
     u32x4 op[kSplit];
     qsplit8(o[0], o[1], op);
     auto om = [&](auto mi_c) {
@@ -631,7 +650,7 @@ __device__ __forceinline__ float quad_attention4(const Ctx &c, QRing &ring, cons
     for (int t = 0; t < 6; ++t) qkv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[h][t], xn, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     f32x4 o[2];
     const f32x4 qa[2] = {qkv[0], qkv[1]}, ka[2] = {qkv[2], qkv[3]}, va[2] = {qkv[4], qkv[5]};
-    quad_attention_head(qa, ka, va, o);
+    quad_attention_head<false>(qa, ka, va, o);
     u32x4 op[kSplit];
     qsplit8(o[0], o[1], op);
     oacc = qring_mfma<kQN0 + h>(ring, op, oacc);
