@@ -106,6 +106,9 @@ def parse():
     ap.add_argument("--ddim-steps", type=int, default=None, help="inference steps (default 100; ppc: 1000)")
     ap.add_argument("--scheduler", choices=["ddim", "ddpm"], default=None,
                     help="default ddim (ppc: ddpm); ddpm with --ddim-steps 1000 --points 4096 --grasps 200 is BASELINE.json configs[4]")
+    ap.add_argument("--noise", choices=["tensor", "kernel", "device"], default="tensor",
+                    help="DDPM step noise: a [steps, B G, 1, D] torch.randn tensor per batch (the reference's draws, default) or "
+                         "drawn inside the fused launch (gldm_denoise_rng: Philox4x32-10 keyed on the global latent index)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--minimal", action="store_true",
                     help="only the timed steps + the roofline launches of the dominant kernel (no stage split, no "
@@ -315,6 +318,10 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
     counter = [0]
 
+    # in-kernel noise: the seed of the job, the rank's first latent as the counter base (results do not depend on the world size)
+    noise_kw = dict(noise_source="kernel", noise_seed=1234, noise_base=rank * B * G) \
+        if (args.noise in ("kernel", "device") and args.scheduler == "ddpm") else {}   # "device" = "kernel"
+
     def step():
         if streams is None:
             return one_batch()
@@ -326,7 +333,7 @@ def main():
 
     def one_batch():
         # DDPM: the per-step noise of every latent is drawn inside sample(), on the device, every batch (part of the step)
-        (tm, lg), _ = ldm.generate_grasps(pcs, num_grasps=G, x_T=x_T)
+        (tm, lg), _ = ldm.generate_grasps(pcs, num_grasps=G, x_T=x_T, **noise_kw)
         # the epilogue runs on the rank's OWN rows; what crosses xGMI is one all-gather of the result rows [B G, 7]
         # (the latent-level outputs the north star names: 28 bytes per grasp), nothing is repeated per rank
         H, un, conf = pose_epilogue(tm, lg, gmean, gstd, G)
@@ -632,7 +639,8 @@ def main():
                                inputs=f"{uniq} distinct synthetic clouds per rank tiled to {B} (resident in HBM); x_T drawn once on the "
                                       "CPU generator and passed in (the reference draws it inside sample(), gaussian_diffusion.py:253: "
                                       f"{B * G * D * 4} bytes per batch, not in the timed region)"
-                                      + ("; DDPM per-step noise drawn on the device inside every timed batch" if args.scheduler == "ddpm" else "")),
+                                      + (("; DDPM per-step noise drawn inside the fused launch (counter-based generator)" if noise_kw else
+                                          "; DDPM per-step noise drawn on the device inside every timed batch") if args.scheduler == "ddpm" else "")),
                    roofline=roof, cpu_baseline=cpu, kernels=kernels)
     if world > 1:
         dist.barrier()

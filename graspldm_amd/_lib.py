@@ -20,6 +20,7 @@ class GldmError(RuntimeError):
 _lib = None
 
 _ll = ctypes.c_longlong
+_ull = ctypes.c_ulonglong
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
 _SIGNATURES = {
@@ -38,6 +39,8 @@ _SIGNATURES = {
     "gldm_sa_group": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "gldm_r1d_cond_embed": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "gldm_denoise": [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gldm_denoise_rng": [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _ull, _ll, _vp, _vp, _vp, _vp],
+    "gldm_step_noise_rng": [_ull, _ll, _i, _i, _i, _vp, _vp],
     "gldm_decode": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "gldm_pose_epilogue": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gldm_conv3d_k3": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],

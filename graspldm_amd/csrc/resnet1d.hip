@@ -2629,6 +2629,12 @@ struct RunArgs {
   int sched_kind, clip_sample;
   const float *sched_coef;
   const float *step_noise;
+  // DDPM noise drawn IN the kernel when step_noise is null and noise_on is set: unit normals from Philox4x32-10 keyed on
+  // noise_seed, counter = (global latent index noise_base + gi, position block, step): independent of tiling, batch
+  // split and world size by construction
+  unsigned long long noise_seed;
+  long long noise_base;
+  int noise_on;
   float *out0;            // denoise: x_out [n][L]; decode: tmrp [n][6]
   float *out1;            // decode: logit [n]
   float *ws;              // workspace: chain header + hand-off granules (+ the decoder's scale/shift table)
@@ -2956,6 +2962,28 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const gldm_r1d_desc &d, 
   }
 }
 
+// Philox4x32-10 (Salmon et al., SC'11: the counter-based generator of curand / torch's device RNG) and Box-Muller: four
+// unit normals per (key, counter).  z[0..3] of counter (latent, position block, step) are positions 4 block + 0..3.
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned c0, unsigned c1, unsigned c2, unsigned c3, float (&z)[4]) {
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const unsigned u[4] = {c0, c1, c2, c3};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float a = ((float)u[2 * h] + 1.0f) * 2.3283064365386963e-10f;   // (0, 1]
+    const float ang = (float)u[2 * h + 1] * (6.283185307179586f * 2.3283064365386963e-10f);
+    const float rad = sqrtf(-2.0f * __logf(a));
+    z[2 * h] = rad * __cosf(ang);
+    z[2 * h + 1] = rad * __sinf(ang);
+  }
+}
+
 #pragma clang fp contract(off)
 // DPM-Solver++(2M) step of ElucidatedDiffusion.sample_using_dpmpp (elucidated_diffusion.py:259-313) on one element:
 // denoised = c_skip x + c_out net (:134, optional clamp :137); denoised_d = (1 - gamma) denoised + gamma old (:303);
@@ -3250,8 +3278,16 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
           const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
           const float cf[8] = {cf_lo[0], cf_lo[1], cf_lo[2], cf_lo[3], cf_hi[0], cf_hi[1], cf_hi[2], cf_hi[3]};
           float nz = 0.f;
-          if (a.sched_kind == GLDM_SCHED_DDPM && cf[7] != 0.f && a.step_noise)
-            nz = a.step_noise[((size_t)step * a.n_samples + gi) * L + l];
+          if (a.sched_kind == GLDM_SCHED_DDPM && cf[7] != 0.f) {
+            if (a.step_noise) {
+              nz = a.step_noise[((size_t)step * a.n_samples + gi) * L + l];
+            } else if (a.noise_on) {
+              const unsigned long long g = (unsigned long long)(a.noise_base + gi);
+              float z4[4];
+              philox_normal4(a.noise_seed, (unsigned)g, (unsigned)(g >> 32), (unsigned)(l >> 2), (unsigned)step, z4);
+              nz = (l & 3) == 0 ? z4[0] : ((l & 3) == 1 ? z4[1] : ((l & 3) == 2 ? z4[2] : z4[3]));
+            }
+          }
           if (a.sched_kind == GLDM_SCHED_DPMPP) lat[tid_f] = dpmpp_update(a.clip_sample, cf, lat[tid_f], e, lds + GG::kMiscOld + tid_f);
           else lat[tid_f] = scheduler_update(a.sched_kind, a.clip_sample, cf, lat[tid_f], e, nz);
         }
@@ -4635,6 +4671,47 @@ GLDM_API int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const
   a.sched_kind = sched_kind; a.clip_sample = clip_sample; a.sched_coef = sched_coef; a.step_noise = step_noise;
   a.out0 = x_out; a.out1 = nullptr; a.ws = reinterpret_cast<float *>(workspace);
   return launch_r1d(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+GLDM_API int gldm_denoise_rng(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,
+                              int samples_per_cond, const float *x_in, int n_samples, const int32_t *timesteps, int n_steps,
+                              int clip_sample, const float *sched_coef, unsigned long long noise_seed,
+                              long long noise_base, const float *sample_emb, float *x_out, void *workspace,
+                              gldm_stream_t stream) {
+  int st = validate(desc);
+  if (st != GLDM_OK) return st;
+  if (!weights || !cemb || !x_in || !x_out || !workspace || n_samples <= 0 || n_steps <= 0 || samples_per_cond <= 0 ||
+      noise_base < 0)
+    return GLDM_ERR_INVALID_ARG;
+  if (desc->latent_dim != 0 || (temb && !timesteps)) return GLDM_ERR_INVALID_ARG;
+  if (!sched_coef || ((unsigned long long)sched_coef & 15)) return GLDM_ERR_INVALID_ARG;
+  RunArgs a{};
+  a.d = *desc;
+  a.weights = weights; a.temb = temb; a.cemb = cemb; a.semb = sample_emb; a.samples_per_cond = samples_per_cond;
+  a.x_in = x_in; a.n_samples = n_samples; a.timesteps = timesteps; a.sample_t = nullptr; a.n_steps = n_steps;
+  a.sched_kind = GLDM_SCHED_DDPM; a.clip_sample = clip_sample; a.sched_coef = sched_coef; a.step_noise = nullptr;
+  a.noise_seed = noise_seed; a.noise_base = noise_base; a.noise_on = 1;
+  a.out0 = x_out; a.out1 = nullptr; a.ws = reinterpret_cast<float *>(workspace);
+  return launch_r1d(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The generator on its own (n latents x L positions of one step), for the statistical tests: out [n][L]
+__global__ void philox_normal_kernel(unsigned long long seed, long long base, int step, int n, int L, float *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * L) return;
+  const int gi = i / L, l = i - gi * L;
+  const unsigned long long g = (unsigned long long)(base + gi);
+  float z4[4];
+  philox_normal4(seed, (unsigned)g, (unsigned)(g >> 32), (unsigned)(l >> 2), (unsigned)step, z4);
+  out[i] = z4[l & 3];
+}
+GLDM_API int gldm_step_noise_rng(unsigned long long noise_seed, long long noise_base, int step, int n_samples, int seq_len,
+                                 float *out, gldm_stream_t stream) {
+  if (!out || n_samples <= 0 || seq_len <= 0 || step < 0 || noise_base < 0) return GLDM_ERR_INVALID_ARG;
+  const int total = n_samples * seq_len;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), noise_seed,
+                     noise_base, step, n_samples, seq_len, out);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
 
 GLDM_API int gldm_decode(const gldm_r1d_desc *desc, const float *weights, const float *cemb, int samples_per_cond,

@@ -120,12 +120,17 @@ class GaussianDiffusion1D(nn.Module):
 
     @torch.no_grad()
     def sample(self, z_cond=None, batch_size=1, return_all=False, device=None, samples_per_cond=1, x_T=None,
-               step_noise=None, **kwargs):
+               step_noise=None, noise_source="tensor", noise_seed=None, noise_base=0, **kwargs):
         """Reverse diffusion (gaussian_diffusion.py:232-277).  x_T is drawn on the CPU
         generator then moved, exactly like the reference (:253); DDPM per-step noise is
         drawn on the device ([steps, B, 1, D]) unless `step_noise` is given.  One HIP launch
         runs every step.  `z_cond` is [B/samples_per_cond, R, Dc] (the reference passes the
-        repeat_interleaved tensor: samples_per_cond = 1)."""
+        repeat_interleaved tensor: samples_per_cond = 1).
+
+        noise_source="kernel" (DDPM, return_all=False): the per-step normals are drawn INSIDE the launch from a counter-based
+        generator (gldm_denoise_rng) instead of from a [steps, B, 1, D] tensor -- the same distribution, not torch's
+        stream; `noise_seed` defaults to one draw of torch's CPU generator (so torch.manual_seed still fixes a run) and
+        `noise_base` is the global index of this batch's first latent (sharded jobs)."""
         device = torch.device(device if device is not None else z_cond.device)
         if device.type != "cuda":
             raise RuntimeError("sampling runs on the GPU only (graspldm_amd has no CPU path)")
@@ -134,7 +139,12 @@ class GaussianDiffusion1D(nn.Module):
         x_T = x_T.to(device)
         ts, coef = self._schedule(device)
         kind = SCHED_DDIM if self._noise_scheduler_type == "ddim" else SCHED_DDPM
-        if kind == SCHED_DDPM and step_noise is None:
+        if noise_source not in ("tensor", "kernel"):
+            raise ValueError(f"noise_source must be 'tensor' or 'kernel', not {noise_source!r}")
+        in_kernel = noise_source == "kernel" and kind == SCHED_DDPM and step_noise is None and not return_all
+        if in_kernel and noise_seed is None:
+            noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if kind == SCHED_DDPM and step_noise is None and not in_kernel:
             step_noise = torch.randn((ts.numel(), batch_size, self.channels, self.n_dims), device=device)
         model = self.model
         model._cond_rows_of(z_cond)
@@ -144,6 +154,10 @@ class GaussianDiffusion1D(nn.Module):
         # call in the reference (gaussian_diffusion.py:271); here it becomes one [n, emb] operand of the launch
         semb = model.class_embedding(kwargs.get("cls_cond"), n=batch_size, metas=kwargs.get("metas")) \
             if hasattr(model, "class_embedding") else None
+        if in_kernel:
+            x = eng.denoise_rng(x_T, cemb, samples_per_cond, ts, coef, noise_seed, noise_base=noise_base,
+                                clip_sample=self.clip_sample, sample_emb=semb)
+            return x, []
         if not return_all:
             x = eng.denoise(x_T, cemb, samples_per_cond, timesteps=ts, sched_kind=kind, clip_sample=self.clip_sample,
                             coef=coef, step_noise=step_noise, sample_emb=semb)

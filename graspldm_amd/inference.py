@@ -175,7 +175,8 @@ class InferenceLDM(_InferenceBase):
             self.model.set_inference_timesteps(self.num_inference_steps)
         if return_intermediate and batch.shape[0] > 1:  # the reference raises after sampling; fail before the work
             raise NotImplementedError("Batched grasps for all diffusion steps are not implemented")
-        extra = {k: kwargs[k] for k in ("step_noise", "cls_cond") if k in kwargs}
+        # noise_source="kernel" (+ noise_seed / noise_base): DDPM step noise drawn inside the fused launch (diffusion.py)
+        extra = {k: kwargs[k] for k in ("step_noise", "cls_cond", "noise_source", "noise_seed", "noise_base") if k in kwargs}
         extra.update(extra_sampler)
         denoiser = getattr(self.model.diffusion_model, "model", None) or getattr(self.model.diffusion_model, "net")
         if hasattr(denoiser, "class_embedding"):

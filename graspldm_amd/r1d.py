@@ -77,6 +77,8 @@ class R1dEngine:
         z = z.contiguous().float()
         n, r, dc = z.shape
         e = self.cond_w.shape[0]
+        if dc != self.cond_w.shape[1]:   # the launch strides the weight rows by dc: another width reads across rows
+            raise RuntimeError(f"z_cond has {dc} features per row; this network's conditioning Linear takes {self.cond_w.shape[1]}")
         out = torch.empty((n, r, e), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             L.call("gldm_r1d_cond_embed", L.ptr(z), L.ptr(self.cond_w), L.ptr(self.cond_b), n, r, dc, e, L.ptr(out),
@@ -109,6 +111,31 @@ class R1dEngine:
                 self._arm_probe(key, ws)
         return out
 
+    def denoise_rng(self, x_in, cemb, samples_per_cond, timesteps, coef, noise_seed, noise_base=0, clip_sample=True,
+                    sample_emb=None):
+        """DDPM reverse loop with the per-step noise drawn inside the kernel (gldm_denoise_rng: Philox4x32-10 keyed on
+        `noise_seed`, counter = (noise_base + latent index, position block, step)).  No [steps, n, 1, L] noise tensor
+        exists; results do not depend on how a batch is split when each part passes its first latent's global index."""
+        n = x_in.shape[0]
+        x_in = x_in.contiguous().float()
+        if sample_emb is not None:
+            sample_emb = sample_emb.reshape(n, -1).contiguous().float()
+            if sample_emb.shape[1] != self.cond_w.shape[0]:
+                raise RuntimeError(f"sample_emb must be [n, {self.cond_w.shape[0]}]")
+        out = torch.empty_like(x_in)
+        n_steps = int(timesteps.numel())
+        ws = self._workspace(n)
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        self._raise_if_failed(key, wait=False)
+        with torch.cuda.device(self.device):
+            L.call("gldm_denoise_rng", self._desc_ptr(), L.ptr(self.weights), L.ptr(self.temb), L.ptr(cemb),
+                   int(samples_per_cond), L.ptr(x_in), n, L.ptr(timesteps), n_steps, 1 if clip_sample else 0, L.ptr(coef),
+                   int(noise_seed) & 0xFFFFFFFFFFFFFFFF, int(noise_base), L.ptr(sample_emb), L.ptr(out), L.ptr(ws),
+                   L.current_stream(self.device))
+            if n_steps > 1:
+                self._arm_probe(key, ws)
+        return out
+
     def decode(self, z_h, cemb, samples_per_cond):
         n = z_h.shape[0]
         z_h = z_h.contiguous().float()
@@ -119,6 +146,15 @@ class R1dEngine:
             L.call("gldm_decode", self._desc_ptr(), L.ptr(self.weights), L.ptr(cemb), int(samples_per_cond), L.ptr(z_h),
                    n, L.ptr(tmrp), L.ptr(logit), L.ptr(ws), L.current_stream(self.device))
         return tmrp, logit
+
+
+def step_noise_rng(noise_seed, noise_base, step, n, seq_len, device):
+    """[n, seq_len] unit normals: exactly what denoise_rng adds at `step` to latents noise_base .. noise_base + n - 1."""
+    out = torch.empty((n, seq_len), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        L.call("gldm_step_noise_rng", int(noise_seed) & 0xFFFFFFFFFFFFFFFF, int(noise_base), int(step), int(n), int(seq_len),
+               L.ptr(out), L.current_stream(device))
+    return out
 
 
 def _per_cloud_rows(t, n_clouds, name):

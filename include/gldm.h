@@ -269,6 +269,23 @@ int gldm_denoise(const gldm_r1d_desc *desc, const float *weights, const float *t
                  const float *step_noise, const float *sample_emb, float *x_out /*[n,1,L]*/, void *workspace,
                  gldm_stream_t stream);
 
+/* gldm_denoise for DDPM throughput runs with the per-step noise drawn IN the kernel (ABI 9): the reference draws one
+ * [n,1,D] normal tensor per step on the device (gaussian_diffusion.py:258-272); a fused launch fed from memory needs all of
+ * them up front ([steps,n,1,D]: 205 MB per 12,800-latent batch of BASELINE configs[4]).  Here every (latent, position,
+ * step) gets its unit normal from Philox4x32-10 + Box-Muller keyed on `noise_seed`, counter = (noise_base + latent index,
+ * position / 4, step): results depend on the seed and on a latent's GLOBAL index only -- not on tiling, batch splits or the
+ * world size (a rank passes the global index of its first latent as noise_base).  Not bit-compatible with torch's stream:
+ * parity tests use gldm_denoise with recorded noise.  Arguments as gldm_denoise (DDPM, no per-sample timesteps). */
+int gldm_denoise_rng(const gldm_r1d_desc *desc, const float *weights, const float *temb, const float *cemb,
+                     int samples_per_cond, const float *x_in /*[n,1,L]*/, int n_samples,
+                     const int32_t *timesteps /*[n_steps]*/, int n_steps, int clip_sample,
+                     const float *sched_coef /*[n_steps,8]*/, unsigned long long noise_seed, long long noise_base,
+                     const float *sample_emb, float *x_out /*[n,1,L]*/, void *workspace, gldm_stream_t stream);
+/* The same generator on its own: out[i][l] = the normal gldm_denoise_rng adds to latent noise_base + i, position l, at
+ * step `step` (statistical tests; no reference counterpart). */
+int gldm_step_noise_rng(unsigned long long noise_seed, long long noise_base, int step, int n_samples, int seq_len,
+                        float *out /*[n,L]*/, gldm_stream_t stream);
+
 /* ref: grasp_ldm/models/grasp_vae.py:401-436 (ConditionalGraspPoseDecoder.forward:
  * in_layer -> ResNet1D -> tmrp / class_logits heads). */
 int gldm_decode(const gldm_r1d_desc *desc, const float *weights, const float *cemb, int samples_per_cond,

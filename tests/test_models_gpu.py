@@ -159,6 +159,37 @@ def test_ddpm_sampler_runs_and_is_seed_reproducible(ldm):
     assert torch.equal(a, b) and torch.isfinite(a).all() and a.abs().max() < 10
 
 
+def test_ddpm_sampler_with_noise_drawn_in_the_kernel(ldm):
+    """sample(noise_source="kernel"): torch.manual_seed still fixes the run, the seed decides the result, the [steps, n, 1, D]
+    tensor is never allocated, and the samples have the statistics of the tensor-fed sampler (same distribution, another
+    stream: 4096 latents of one conditioning row, per-dimension mean and spread)."""
+    m = build_fpc(scheduler="ddpm")
+    m.load_state_dict(ldm.state_dict(), strict=True)
+    m = m.cuda().eval()
+    dm = m.diffusion_model
+    dm.set_inference_timesteps(40)
+    z = torch.randn(1, 3, 64, device="cuda")
+    torch.manual_seed(3)
+    a, _ = dm.sample(z_cond=z, batch_size=4096, samples_per_cond=4096, device="cuda", noise_source="kernel")
+    torch.manual_seed(3)
+    b, _ = dm.sample(z_cond=z, batch_size=4096, samples_per_cond=4096, device="cuda", noise_source="kernel")
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    x_T = torch.randn(4096, 1, 4)
+    c, _ = dm.sample(z_cond=z, batch_size=4096, samples_per_cond=4096, device="cuda", noise_source="kernel", noise_seed=1, x_T=x_T)
+    d, _ = dm.sample(z_cond=z, batch_size=4096, samples_per_cond=4096, device="cuda", noise_source="kernel", noise_seed=2, x_T=x_T)
+    assert not torch.equal(c, d)
+    torch.cuda.reset_peak_memory_stats()
+    before = torch.cuda.max_memory_allocated()
+    dm.sample(z_cond=z, batch_size=4096, samples_per_cond=4096, device="cuda", noise_source="kernel", noise_seed=1, x_T=x_T)
+    assert torch.cuda.max_memory_allocated() - before < 40 * 4096 * 4 * 4   # less than the noise tensor alone would take
+    t, _ = dm.sample(z_cond=z, batch_size=4096, samples_per_cond=4096, device="cuda", x_T=x_T)
+    se = t.std(0) / 4096 ** 0.5
+    assert ((c.mean(0) - t.mean(0)).abs() < 6 * se + 1e-4).all()
+    assert ((c.std(0) / t.std(0).clamp_min(1e-6) - 1).abs() < 0.1).all()
+    with pytest.raises(ValueError):
+        dm.sample(z_cond=z, batch_size=4, samples_per_cond=4, device="cuda", noise_source="philox")
+
+
 @pytest.mark.parametrize("b,c,n,m,u,chans", [(2, 128, 512, 128, 64, (128, 128, 256)), (3, 0, 1024, 512, 64, (64, 64, 128)),
                                              (2, 32, 1024, 1024, 32, (32, 64)), (1, 5, 300, 37, 16, (16, 32, 32, 64)),
                                              (2, 64, 256, 37, 32, (64, 128)), (300, 16, 128, 5, 16, (32, 64, 128, 256)),

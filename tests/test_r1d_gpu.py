@@ -483,3 +483,44 @@ def test_step_split_chain_on_the_sixteen_position_engine(extra_tiles, steps, kin
     again = den.denoise(x, cemb, spc, timesteps=ts, sched_kind=sk, coef=coef, step_noise=noise)
     assert torch.equal(big, again)
     assert den.workspace_errors() == 0
+
+
+# ---- DDPM noise drawn inside the launch (gldm_denoise_rng)
+def test_in_kernel_noise_generator_matches_the_restated_philox():
+    import numpy as np
+    from oracle.philox import step_noise
+    from graspldm_amd.r1d import step_noise_rng
+    for seed, base, step, n, L in [(0, 0, 0, 257, 4), (0xDEADBEEFCAFEF00D, (1 << 32) - 100, 999, 300, 16), (42, 12800 * 7, 17, 1000, 4)]:
+        got = step_noise_rng(seed, base, step, n, L, "cuda:0").cpu().numpy()
+        want = step_noise(seed, base, step, n, L)
+        # same words, same Box-Muller; the device's fast log / sin / cos differ from numpy's in the last bits
+        assert np.abs(got - want).max() < 2e-5, np.abs(got - want).max()
+    z = step_noise_rng(7, 0, 5, 1 << 20, 4, "cuda:0").double()
+    assert abs(z.mean().item()) < 3e-3 and abs(z.var().item() - 1) < 5e-3 and abs((z ** 4).mean().item() - 3) < 0.03
+
+
+def test_in_kernel_noise_equals_the_same_normals_fed_from_memory(engines):
+    """gldm_denoise_rng is gldm_denoise with step_noise[s] = gldm_step_noise_rng(seed, base, s): bit for bit, and
+    independent of how the batch is cut when every part passes its first latent's global index."""
+    from graspldm_amd.diffusion import make_schedule_tables
+    from graspldm_amd.r1d import SCHED_DDPM, step_noise_rng
+    den, _ = engines
+    steps, n, base, seed = 12, 300, 1000, 0x1234567887654321
+    ts, coef = make_schedule_tables("ddpm", 1000, 5e-5, 1e-3, "linear", "fixed_large", steps)
+    ts, coef = ts.cuda(), coef.cuda()
+    g = torch.Generator().manual_seed(5)
+    x_T = torch.randn((n, 1, 4), generator=g).cuda()
+    cemb = den.cond_embed(torch.randn((n, 3, 64), generator=g).cuda())
+    with pytest.raises(RuntimeError):
+        den.cond_embed(torch.randn((n, 3, 4)).cuda())   # not this network's conditioning width
+    noise = torch.stack([step_noise_rng(seed, base, s, n, 4, "cuda:0") for s in range(steps)]).reshape(steps, n, 1, 4)
+    want = den.denoise(x_T, cemb, 1, timesteps=ts, sched_kind=SCHED_DDPM, coef=coef, step_noise=noise)
+    got = den.denoise_rng(x_T, cemb, 1, ts, coef, seed, noise_base=base)
+    assert torch.equal(got, want)
+    cut = 172
+    a = den.denoise_rng(x_T[:cut], cemb[:cut], 1, ts, coef, seed, noise_base=base)
+    b = den.denoise_rng(x_T[cut:], cemb[cut:], 1, ts, coef, seed, noise_base=base + cut)
+    assert torch.equal(torch.cat([a, b]), want)
+    other = den.denoise_rng(x_T, cemb, 1, ts, coef, seed + 1, noise_base=base)
+    assert (other - want).abs().max().item() > 1e-3
+
