@@ -40,7 +40,7 @@
 
 #ifdef GLDM_DEBUG_KNOBS
 __device__ long long g_q_stamp[4][16];   // per quad: cycle counter behind every stage of the chain (last step of workgroup 0)
-#define GLDM_QSTAMP(c, i) do { if (blockIdx.x == 0 && (c).lane == 0) g_q_stamp[(c).wave][i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define GLDM_QSTAMP(c, i) do { if (blockIdx.x == 0 && (c).lane == 0) g_q_stamp[(c).wave & 3][i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define GLDM_QSTAMP(c, i) do {} while (0)
 #endif
@@ -172,7 +172,11 @@ __device__ __forceinline__ void qring_load(QRing &ring) {
   if constexpr (N < kQNEnd) {
     if constexpr (N % kQG == 0) {
       constexpr int g = N / kQG;
+#if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_QEXP_DUP)   // timing experiment (wrong results): nobody loads, nobody waits; stale slots are read
+      if (false) {
+#else
       if (__builtin_expect(ring.flag != g + 1, 0)) {
+#endif
         for (int spin = 0; spin < kQSpinMax && lds_poll(ring.sync + (g & 7)) != g + 1; ++spin) {
           __builtin_amdgcn_s_sleep(1);
 #ifdef GLDM_DEBUG_KNOBS
@@ -673,7 +677,7 @@ typedef __attribute__((address_space(4))) const gldm_r1d_desc kernarg_desc;
 __device__ __forceinline__ void quad_narrow_levels(const Ctx &c, kernarg_desc *dk) {
   using GG = Geo<64>;
   using std::integral_constant;
-  const int q = c.wave, col = c.lane & 15, kq = c.lane >> 4;
+  const int q = c.wave & 3, col = c.lane & 15, kq = c.lane >> 4;   // (wave > 3: GLDM_QEXP_DUP only)
   const int p = col >> 2, sl = col & 3;
   const int smp = 4 * q + sl;          // the lane's sample inside the workgroup's tile
   const int pmcol = 16 * p + smp;      // its column in the position-major layout
@@ -777,7 +781,7 @@ __device__ __forceinline__ void quad_narrow_levels(const Ctx &c, kernarg_desc *d
   }
   GLDM_QSTAMP(c, 12);
 #ifdef GLDM_DEBUG_KNOBS
-  if (blockIdx.x == 0 && c.lane == 0) g_q_stamp[c.wave][13] = ring.spins;
+  if (blockIdx.x == 0 && c.lane == 0) g_q_stamp[c.wave & 3][13] = ring.spins;
 #endif
   static_assert(kQN2 + 2 * kRb2 + kAtt2 + 48 == kQNEnd, "stream length");
 #undef GLDM_QDESC

@@ -2921,7 +2921,15 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const gldm_r1d_desc &d, 
           if (c.wave < 4)
             quad_narrow_levels(c, (kernarg_desc *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() +
                                                     offsetof(RunArgs, d)));
+#if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_QEXP_DUP)
+          // timing experiment (wrong results): GLDM_QEXP_DUP=2 -> waves 4-7 run the chain of quads 0-3 a second time beside
+          // them (two compute waves per SIMD); =1 -> they do nothing (one compute wave per SIMD, no loader)
+          else if (GLDM_QEXP_DUP == 2)
+            quad_narrow_levels(c, (kernarg_desc *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                    offsetof(RunArgs, d)));
+#else
           else quad_loader(c);
+#endif
           __syncthreads();
         }
         break;
