@@ -82,7 +82,12 @@ def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True, front=N
     pointwise_mlp_kernel / pointwise_mlp_sp_kernel) and optionally z = Wh y + bh on the accumulators.
     head = (packed Wh, bh, hout).  front = (packed W0, b0, cin): a ReLU layer x -> relu(W0 x + b0) in front, its output
     kept in LDS only.  split=True: `w_packed` (and the front layer's W0) hold split-f16 fragments (the GEMMs run on the
-    bf16 matrix pipe with six partial products per f32 product)."""
+    f16 matrix pipe with three partial products per f32 product).
+
+    Numerics depend on the path a shape takes: the split launch (hi + lo f16 operands, three products: ~2e-7 of sum|a b|
+    per output, measured 1.7e-6 on a denoiser forward) and the f32-MFMA launch (exact f32 fma chain in k order) differ in
+    the last bits, and so do two shapes of one layer that land on different launches (e.g. cout 64 vs 48).  Both are
+    within the parity bars (2e-5 per forward); bitwise equality holds between runs of the SAME path only."""
     from . import _lib as L
     b, cin, n = x.shape
     y = torch.empty((b, cout, n), dtype=torch.float32, device=x.device) if keep_y or head is None else None

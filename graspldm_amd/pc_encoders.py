@@ -66,7 +66,7 @@ class PVCNNEncoder(nn.Module):
                     _, b0, wp0, ws0 = dense.folded_conv_bn(conv0, bn0, feats.device)
                     _, bf, wp, ws = dense.folded_conv_bn(conv, bn, feats.device)
                     if ws is not None and ws0 is not None and dense.split_supported(cin, conv0.weight.shape[1]):
-                        # both GEMMs on the bf16 matrix pipe (split-f32 operands)
+                        # both GEMMs on the f16 matrix pipe (split-f32 operands)
                         return dense.pointwise_mlp(feats, ws, bf, cout, True, head=self._packed_head(w, b), keep_y=False,
                                                    front=(ws0, b0, cin), split=True)[1]
                     return dense.pointwise_mlp(feats, wp, bf, cout, True, head=self._packed_head(w, b), keep_y=False,

@@ -178,13 +178,14 @@ typedef struct gldm_r1d_level {
  * m-tiles 2 kb and 2 kb + 1 -- so k-slot 8 g + j of a 32-channel block kb stands for channel 32 kb + 16 (j >> 2) + 4 g +
  * (j & 3), and the weights' columns are stored in that order: W_q[:, 32 kb + 8 g + j] = W[:, 32 kb + 16 (j >> 2) + 4 g + (j & 3)]. */
 
-/* Split-f16 weight fragments (ABI 5; graspldm_amd/r1d_pack.py: mfma_a_fragments_f16x2).  Every f32 weight is
- * written as hi + mid + lo, three bf16 numbers (exact: 3 x 8 significant bits cover the 24 of an f32); the matrix
- * [M, K] (K % 32 == 0) is stored as [M/16][K/32][plane hi|mid|lo][lane 64][8 bf16], lane l holding
- * W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + j], j = 0..7: the A operand of v_mfma_f32_16x16x32_bf16.  The
- * position-major engine computes every f32 product as the six partial products of weight >= 2^-16
- * (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) on the bf16 matrix pipe with f32 accumulation: the dropped terms
- * are <= 2^-23 of |a||b| per product, the order of an f32 rounding, at 6/16 of the f32-MFMA time. */
+/* Split-f16 weight fragments (layout since ABI 5, two f16 planes since ABI 9; graspldm_amd/r1d_pack.py:
+ * mfma_a_fragments_f16x2).  Every f32 weight is written as hi + lo, two f16 numbers (hi = f16(w), lo = f16(w - hi):
+ * 2 x 11 significant bits, |w - hi - lo| <= 2^-22 |w|; |w| < 65504 or the packer raises); the matrix [M, K]
+ * (K % 32 == 0) is stored as [M/16][K/32][plane hi|lo][lane 64][8 f16] = 2 KiB per fragment, lane l holding
+ * W[16 mt + (l & 15)][32 kb + 8 (l >> 4) + j], j = 0..7: the A operand of v_mfma_f32_16x16x32_f16.  The 64-column
+ * engines compute every f32 product as the three partial products hi*hi + hi*lo + lo*hi on the f16 matrix pipe with f32
+ * accumulation (the pipe keeps f16 subnormals); the dropped lo*lo term is <= 2^-22 of |a||b| per product, the order of an
+ * f32 rounding, at 3/16 of the f32-MFMA time.  (ABI 5-8 stored three bf16 planes, hi|mid|lo, for six products.) */
 
 typedef struct gldm_r1d_desc {
   int32_t seq_len;      /* L: 4 (latent denoiser) or 16 (pose decoder)            */
@@ -232,10 +233,11 @@ int gldm_r1d_cond_embed(const float *z_cond /*[n_cond,R,Dc]*/, const float *w /*
  * left-over tiles are split along the step axis over several workgroups.  For a pose-decoder descriptor
  * (seq_len 16, latent_dim > 0, emb_dim >= 32) it also holds, behind those, the ResnetBlocks' scale/shift
  * rows per conditioning cloud (4 bytes x n_samples x sum of 2 C over the blocks: sized for one grasp per
- * cloud), written by gldm_decode itself before the fused launch.  For a latent-denoiser descriptor of the
- * position-major engine whose last level has 256 channels it holds, behind the granules (256-byte aligned),
- * 64 KiB of scratch per workgroup of the launch (min(tiles, compute units)): the level's residual stream is
- * parked there, by the lanes that re-load it, while LDS holds its split-f16 planes.
+ * cloud), written by gldm_decode itself before the fused launch.  For a 16-position latent-denoiser
+ * descriptor (the `ppc` experiment) of the 64-column engine whose last level has 256 channels it holds, behind the granules
+ * (256-byte aligned), 64 KiB of scratch per workgroup of the launch (min(tiles, compute units)): the level's residual
+ * stream is parked there, by the lanes that re-load it, while LDS holds its padded split-f16 planes (the 4-position
+ * engine keeps both in LDS since ABI 9 and needs header + granules only).
  * Contract: the caller ZEROES the workspace once, when it allocates it; a workspace is used by one
  * launch at a time (launches on the same stream may share it, concurrent streams may not); the
  * library re-arms it at the end of every launch.  The 32-bit word at byte GLDM_R1D_WS_ERROR is set
@@ -244,9 +246,8 @@ int gldm_r1d_cond_embed(const float *z_cond /*[n_cond,R,Dc]*/, const float *w /*
 long long gldm_r1d_workspace_bytes(const gldm_r1d_desc *desc, int n_samples);
 
 /* Which engine gldm_denoise / gldm_decode run this descriptor on: 64 = the position-major engine (64-column tiles = 16
- * samples x 4 positions, GEMMs as split-f16 products on the bf16 matrix pipe: 4-position latent denoisers packed with
- * the ABI >= 5 fields), 32 = the sample-major engine (32-column tiles, f32 matrix pipe: the 16-position pose decoder and
- * every other supported shape), or a negative GLDM_ERR_* status for a descriptor no engine takes.  No reference
+ * samples x 4 positions, or 4 samples x 16 positions; GEMMs as split-f16 products on the f16 matrix pipe: nets packed with
+ * the split fields), 32 = the sample-major engine (32-column tiles, f32 matrix pipe: every other supported shape), or a negative GLDM_ERR_* status for a descriptor no engine takes.  No reference
  * counterpart: reporting only (bench.py labels its roofline record with it). */
 int gldm_r1d_tile_columns(const gldm_r1d_desc *desc);
 
@@ -313,8 +314,8 @@ int gldm_sa_mlp_forward(const float *points /*[b,3,n]*/, const float *centers /*
                         const int32_t *cin_pad, const int32_t *cout, const int32_t *w_off, const int32_t *b_off,
                         float *out /*[b,cout_last,m]*/, gldm_stream_t stream);
 
-/* The same module core with the GEMMs on the bf16 matrix pipe (every f32 product as six bf16 partial products of the exact
- * hi / mid / lo splits of both operands, f32 accumulation: the arithmetic of the denoiser engines): 64-column tiles whose
+/* The same module core with the GEMMs on the f16 matrix pipe (every f32 product as three f16 partial products of the
+ * hi / lo splits of both operands, f32 accumulation: the arithmetic of the denoiser engines): 64-column tiles whose
  * gathered rows and hidden-layer outputs live in LDS as pre-split planes.  `weights` holds, per layer, the split-f16 A
  * fragments of [cout x cin_pad] at w3_off[l] (graspldm_amd/r1d_pack.py: mfma_a_fragments_f16x2; cin_pad a multiple of 32,
  * zero beyond the real rows) and the folded bias at b_off[l].  Shapes: cin_pad[0] <= 288, hidden widths multiples of 32
@@ -365,8 +366,8 @@ int gldm_linear_rows(const float *x /*[rows,n]*/, const float *w /*[nout,n]*/, c
                      int rows, int n, int nout, float *y /*[rows,nout]*/, gldm_stream_t stream);
 
 /* The same two entry points with the MAIN layer's weights as split-f16 fragments (graspldm_amd/r1d_pack.py:
- * mfma_a_fragments_f16x2; layout above): the GEMM runs on the bf16 matrix pipe with six partial products per f32
- * product and f32 accumulation (error of the order of one f32 rounding per product, 6/16 of the f32-MFMA time).  The
+ * mfma_a_fragments_f16x2; layout above): the GEMM runs on the f16 matrix pipe with three partial products per f32
+ * product and f32 accumulation (error of the order of one f32 rounding per product, 3/16 of the f32-MFMA time).  The
  * input tile is split once while it is staged.  Since ABI 6 the front layer's weights `w0_split` are split-f16 fragments
  * too (cin0 % 32 == 0, cin0 <= 96; its f32 input tile is split once per wave into registers); `head_w_packed` stays f32
  * fragments.  cin % 128 == 0, cout % 32 == 0 (with a front layer or a head: % 256; fewer than 256 output rows leave waves
@@ -417,7 +418,7 @@ int gldm_conv3d_k3_generic(const float *x /*[b,cin,r^3]*/, const float *w /*[cou
 
 /* The same conv with split-f16 weights (graspldm_amd/voxel.py: pack_conv3d_f16x2: [cout, cblocks * 14 * 32] with
  * k = ((16-channel block) * 14 + tap pair) * 32 + 16 (tap - 2 pair) + channel, as mfma_a_fragments_f16x2 fragments):
- * six bf16 partial products per f32 product on the bf16 matrix pipe, f32 accumulation.  Built for the shipped
+ * three f16 partial products per f32 product on the f16 matrix pipe, f32 accumulation.  Built for the shipped
  * encoder's shapes (cout 48 at r = 24, cout 96 at r = 12 with cin % 16 == 0; and the first conv, cin = 3 -> 48 at r = 24,
  * whose weights are packed tap-major without padding between taps, k = tap * 3 + ci < 81 in three 32-deep blocks:
  * pack_conv3d_fewch_f16x2); GLDM_ERR_UNSUPPORTED otherwise. */

@@ -8,6 +8,7 @@ mkdir -p $out
 cd $root
 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/bench.err
 python bench.py --scheduler ddpm --ddim-steps 1000 --points 4096 --grasps 200 --clouds-per-gpu 64 --steps 3 --warmup 1 > $out/${tag}_bench_c5.json 2>> $out/bench.err
+python bench.py --scheduler ddpm --ddim-steps 1000 --points 4096 --grasps 200 --clouds-per-gpu 64 --steps 3 --warmup 1 --minimal --noise kernel > $out/${tag}_bench_c5_noise_in_kernel.json 2>> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_s1 -o run -- /usr/bin/python3 $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --streams 1 --minimal > $out/${tag}_bench_streams1_under_rocprof.json 2> $out/prof.err
 cd $root
