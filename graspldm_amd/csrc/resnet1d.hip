@@ -3732,6 +3732,7 @@ struct PwArgs {
   int cin0;
   int dyn_first;   // split-f16 kernel: units (pairs of m-tiles) >= dyn_first are handed out at run time
   int ticket_off;  // ... from a ticket at this float index of the LDS plan
+  int x0_in_planes; // 48-column tiles: the front layer's f32 tile lies under the planes (see pointwise_mlp_sp_kernel)
   // split-f16 kernel, ADD instantiation: an addend in front of the activation, add[cloud * add_bs + row * add_rs + col * add_cs]
   // (a per-cloud bias: bs = cout, rs = 1, cs = 0; a [b, cout, n] tensor: bs = cout * n, rs = n, cs = 1)
   const float *add;
@@ -3860,35 +3861,41 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
 // The optional layer in front (96 -> 768: an eighth of the FLOPs) runs on the same pipe (pw_front_split: 20-25 k cycles
 // per tile on the f32 pipe before) and writes its ReLU output straight into those planes; the head product is taken on the
 // accumulators exactly as in the f32 kernel (the C layout of the two MFMA shapes is the same).
-__device__ __forceinline__ void store_planes4_32(float *planes, int c0, int n, float v0, float v1, float v2, float v3) {
+// f32 [row][NC] tile of the front layer: swz<32> on the first 32 columns (the two n-tiles trade places on odd rows), any
+// further n-tile in place
+template <int NC>
+__device__ __forceinline__ int pw_swz(int row, int col) { return row * NC + (col < 32 ? (col ^ ((row & 1) << 4)) : col); }
+template <int NC>   // columns of the tile: 32 or 48
+__device__ __forceinline__ void store_planes4_pw(float *planes, int c0, int n, float v0, float v1, float v2, float v3) {
   unsigned h0, h1, l0, l1;
   split_f16x2(v0, v1, h0, l0);
   split_f16x2(v2, v3, h1, l1);
-  const int a = ((((c0 >> 5) * kSplit) * 4 + ((c0 >> 3) & 3)) * 32 + n) * 4 + ((c0 >> 2) & 1) * 2;   // dwords
+  const int a = ((((c0 >> 5) * kSplit) * 4 + ((c0 >> 3) & 3)) * NC + n) * 4 + ((c0 >> 2) & 1) * 2;   // dwords
   lds_u2 *d = (lds_u2 *)(planes + a);
   d[0] = u32x2_t{h0, h1};
-  d[256] = u32x2_t{l0, l1};   // next plane: 4 * 32 * 4 dwords
+  d[8 * NC] = u32x2_t{l0, l1};   // next plane: 4 * NC * 4 dwords
 }
 
 // The layer in front of the split-f16 main layer, on the same pipe: x0 = the f32 [cin0][32] tile (swizzled), w0s =
 // split fragments of W0 [cin x cin0], KB0 = cin0 / 32.  A wave splits the whole tile ONCE into registers (its B planes
 // serve all of the wave's m-tiles) and walks its m-tiles in pairs; the A registers of a (m-tile, block) are refilled
 // with the next pair's fragments as soon as its MFMAs have issued.  Output: ReLU, split, into the main layer's planes.
-template <int KB0>
+template <int KB0, int NT>
 __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *bias0, const float *x0, float *planes,
-                                               int wave, int lane, int mt_per_wave0) {
-  constexpr int NC = 32;
+                                               int wave, int lane, int mt_per_wave0, bool x0_in_planes) {
+  constexpr int NC = 16 * NT;
   const int col = lane & 15, kq = lane >> 4;
-  u32x4 bp[KB0][2][kSplit];
+  u32x4 bp[KB0][NT][kSplit];
 #pragma unroll
   for (int kb = 0; kb < KB0; ++kb)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < NT; ++ni) {
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = x0[swz<NC>(32 * kb + 8 * kq + j, 16 * ni + col)];
+      for (int j = 0; j < 8; ++j) v[j] = x0[pw_swz<NC>(32 * kb + 8 * kq + j, 16 * ni + col)];
       split_planes8(v, bp[kb][ni]);
     }
+  if (x0_in_planes) __syncthreads();   // 48-column tiles: the f32 tile lies under the planes this layer is about to write
   u32x4 af[2][KB0][kSplit];
   const int mt_first = wave * mt_per_wave0, mt_last = mt_first + mt_per_wave0 - 2;
   auto load_a = [&](int mi, int kb, int mt0) {
@@ -3901,19 +3908,19 @@ __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *
     for (int kb = 0; kb < KB0; ++kb) load_a(mi, kb, mt_first);
   for (int mt0 = mt_first; mt0 <= mt_last; mt0 += 2) {
     const int mtn = mt0 + 2 <= mt_last ? mt0 + 2 : mt_last;
-    f32x4 acc[2][2];
+    f32x4 acc[2][NT];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias0 + 16 * (mt0 + mi) + 4 * kq);
-      acc[mi][0] = bv;
-      acc[mi][1] = bv;
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = bv;
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int kb = 0; kb < KB0; ++kb) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_split(af[mi][kb], bp[kb][ni], acc[mi][ni]);
+        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma_split(af[mi][kb], bp[kb][ni], acc[mi][ni]);
         __builtin_amdgcn_sched_barrier(0);
         load_a(mi, kb, mtn);   // pinned here: the scheduler sinks such requests to their first use otherwise
         __builtin_amdgcn_sched_barrier(0);
@@ -3921,9 +3928,9 @@ __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-        store_planes4_32(planes, 16 * (mt0 + mi) + 4 * kq, 16 * ni + col, fmaxf(acc[mi][ni][0], 0.f),
-                         fmaxf(acc[mi][ni][1], 0.f), fmaxf(acc[mi][ni][2], 0.f), fmaxf(acc[mi][ni][3], 0.f));
+      for (int ni = 0; ni < NT; ++ni)
+        store_planes4_pw<NC>(planes, 16 * (mt0 + mi) + 4 * kq, 16 * ni + col, fmaxf(acc[mi][ni][0], 0.f),
+                             fmaxf(acc[mi][ni][1], 0.f), fmaxf(acc[mi][ni][2], 0.f), fmaxf(acc[mi][ni][3], 0.f));
   }
 }
 
@@ -3935,64 +3942,72 @@ __device__ long long g_pw_stamp[64];
 #else
 #define GLDM_PW_STAMP(i) do {} while (0)
 #endif
-template <bool ADD>
+// NT: n-tiles per tile.  2 = 32 points (96 KiB of planes at cin = 768).  3 = 48 points (144 KiB): a weight fragment then
+// serves three n-tiles -- with three f16 products per block the kernel is bound by the CU's L2 rate (5 MB of fragments per
+// tile at 52 B/clk = 96 k cycles against 59 k of MFMAs at 32 points), so bytes per POINT are what counts.  n % 16 == 0: a
+// cloud's last tile holds 1-3 whole n-tiles (`ntv`); the others are computed on zeros and never stored.
+template <bool ADD, int NT>
 __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a) {
-  constexpr int NC = 32;
+  constexpr int NC = 16 * NT;
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kq = lane >> 4;
   const int kb32 = a.cin >> 5, mtiles = a.cout >> 4;
-  float *planes = lds;                       // [kb32][kSplit][4][32][4 dwords]
-  float *zpart = lds;                        // [8 waves][16 rows][32 cols], over the planes once they are dead
-  float *x0 = lds + a.cin * 16 * kSplit;     // front layer's f32 input tile [cin0][32] behind the planes (cin / 32 blocks x kSplit x 512 floats)
-  float *zdyn = x0;                          // head products of the drawn units [unit - dyn_first][hout][32] (x0 is dead then)
+  float *planes = lds;                       // [kb32][kSplit][4][NC][4 dwords]
+  float *zpart = lds;                        // [8 waves][16 rows][NC cols], over the planes once they are dead
+  float *zdyn = lds + a.cin * (NC / 2) * kSplit;   // behind the planes: head products of the drawn units [unit - dyn_first][hout][NC]
+  // front layer's f32 input tile [cin0][NC]: behind the planes, under zdyn (dead by then); 48-column tiles have no room
+  // there -- it lies UNDER the planes and the front layer takes it into registers, then a barrier, before it writes them
+  float *x0 = a.x0_in_planes ? lds : zdyn;
   int *ticket = (int *)(lds + a.ticket_off); // next unit of output rows to hand out (main layer)
   const WStream hw(a.head_w ? a.head_w : a.w, lane);
   const WStream wv(a.w, lane);
-  const lds_u4 *pl3 = (const lds_u4 *)planes + kq * 32 + col;   // + ((kb * kSplit + plane) * 4) * 32 + 16 ni
+  const lds_u4 *pl3 = (const lds_u4 *)planes + kq * NC + col;   // + ((kb * kSplit + plane) * 4) * NC + 16 ni
   for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_cloud, c0 = (tile - b * a.tiles_per_cloud) * NC;
+    const int ntv = min(NT, (a.n - c0) >> 4);   // whole n-tiles of this tile that exist
     __syncthreads();  // the previous tile's readers are done
     GLDM_PW_STAMP(0);
     if (tid == 0) *ticket = a.dyn_first;
     if (a.w0) {
       const float *xb0 = a.x + (size_t)b * a.cin0 * a.n + c0;
-      for (int i = tid; i < a.cin0 * 8; i += 512) {
-        const int row = i >> 3, q = i & 7;
-        *reinterpret_cast<f32x4 *>(x0 + swz<NC>(row, 4 * q)) = *reinterpret_cast<const f32x4 *>(xb0 + (size_t)row * a.n + 4 * q);
+      for (int i = tid; i < a.cin0 * (NC / 4); i += 512) {
+        const int row = i / (NC / 4), q = i - row * (NC / 4);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (4 * q < 16 * ntv) v = *reinterpret_cast<const f32x4 *>(xb0 + (size_t)row * a.n + 4 * q);
+        *reinterpret_cast<f32x4 *>(x0 + pw_swz<NC>(row, 4 * q)) = v;
       }
       __syncthreads();
       GLDM_PW_STAMP(1);
       const int mt_per_wave0 = a.cin >> 7;   // cin / 16 m-tiles over 8 waves
       const WStream w0s(a.w0, lane);
       switch (a.cin0 >> 5) {
-        case 1: pw_front_split<1>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0); break;
-        case 2: pw_front_split<2>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0); break;
-        default: pw_front_split<3>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0); break;
+        case 1: pw_front_split<1, NT>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0, a.x0_in_planes != 0); break;
+        case 2: pw_front_split<2, NT>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0, a.x0_in_planes != 0); break;
+        default: pw_front_split<3, NT>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0, a.x0_in_planes != 0); break;
       }
     } else {
-      // stage + split: thread = (8-channel group, column); a pass covers 128 channels
+      // stage + split: item = (8-channel group, column)
       const float *xb = a.x + (size_t)b * a.cin * a.n + c0;
-      const int scol = tid & 31, kg = tid >> 5;
-      for (int r0 = 0; r0 < a.cin; r0 += 128) {
-        const int row = r0 + 8 * kg;
-        if (row < a.cin) {
-          float v[8];
+      for (int i = tid; i < (a.cin >> 3) * NC; i += 512) {
+        const int kg = i / NC, scol = i - kg * NC, row = 8 * kg;
+        float v[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = xb[(size_t)(row + j) * a.n + scol];
-          u32x4 pl[kSplit];
-          split_planes8(v, pl);
-          lds_u4 *d = (lds_u4 *)planes + (((row >> 5) * kSplit) * 4 + ((row >> 3) & 3)) * 32 + scol;
-          d[0] = pl[0];
-          d[128] = pl[1];
-        }
+        for (int j = 0; j < 8; ++j) v[j] = scol < 16 * ntv ? xb[(size_t)(row + j) * a.n + scol] : 0.f;
+        u32x4 pl[kSplit];
+        split_planes8(v, pl);
+        lds_u4 *d = (lds_u4 *)planes + (((row >> 5) * kSplit) * 4 + ((row >> 3) & 3)) * NC + scol;
+        d[0] = pl[0];
+        d[4 * NC] = pl[1];
       }
     }
     GLDM_PW_STAMP(2);
     __syncthreads();
     GLDM_PW_STAMP(3);
-    f32x4 zacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 zacc[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) zacc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---- the output rows in units of two m-tiles, handed out at run time.  With a fixed share per wave the older wave
     // of a SIMD gets the matrix pipe whenever it wants it, finishes its share at 95 % of the pair's rate and then idles
     // at the tile's last barrier while its partner, alone, cannot hide its own LDS / weight latencies (stamps: wave 0
@@ -4008,12 +4023,12 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
 #pragma unroll
         for (int pl = 0; pl < kSplit; ++pl) af[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kb32 + kb) * kFragBytes, pl * 1024);
     };
-    u32x4 bs[2][2][kSplit];
+    u32x4 bs[2][NT][kSplit];
     auto load_b = [&](int buf, int kb) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-        for (int pl = 0; pl < kSplit; ++pl) bs[buf][ni][pl] = pl3[(kb * kSplit + pl) * 128 + 16 * ni];
+        for (int pl = 0; pl < kSplit; ++pl) bs[buf][ni][pl] = pl3[(kb * kSplit + pl) * 4 * NC + 16 * ni];
     };
     auto draw = [&]() {
       int t = 0;
@@ -4033,13 +4048,13 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
       const int nxt = unit + 8 < dyn_first ? unit + 8 : draw();
       const int mtn = 2 * (nxt < units ? nxt : unit);   // past the end: harmless re-reads of this unit's fragments
       // bias and head fragments of this unit: requested now, used behind the k-loop (the bias is added last)
-      f32x4 acc[2][2], bv[2], ah[2];
+      f32x4 acc[2][NT], bv[2], ah[2];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         bv[mi] = *reinterpret_cast<const f32x4 *>(a.bias + 16 * (mt0 + mi) + 4 * kq);
         ah[mi] = hw[(size_t)(a.head_w ? mt0 + mi : 0) * 64];
-        acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       for (int kb0 = 0; kb0 < kb32; kb0 += 4) {
         const bool tail = kb0 + 4 >= kb32;
@@ -4051,7 +4066,7 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_split(af[u][mi], bs[u & 1][ni], acc[mi][ni]);
+            for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma_split(af[u][mi], bs[u & 1][ni], acc[mi][ni]);
           __builtin_amdgcn_sched_barrier(0);
           load_a(u, tail ? mtn : mt0, tail ? u : kb + 4);
         }
@@ -4059,13 +4074,13 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = acc[mi][ni][r] + bv[mi][r];
             if constexpr (ADD)
               v += a.add[(long long)b * a.add_bs + (long long)(16 * (mt0 + mi) + 4 * kq + r) * a.add_rs +
-                         (long long)(c0 + 16 * ni + col) * a.add_cs];
+                         (long long)(c0 + (ni < ntv ? 16 * ni + col : col)) * a.add_cs];
             acc[mi][ni][r] = a.relu ? fmaxf(v, 0.f) : v;
           }
         if (a.y) {
@@ -4073,20 +4088,21 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) __builtin_nontemporal_store(acc[mi][ni][r], yb + (size_t)r * a.n + 16 * ni);
+            for (int ni = 0; ni < NT; ++ni)
+              if (ni < ntv) __builtin_nontemporal_store(acc[mi][ni][r], yb + (size_t)r * a.n + 16 * ni);
         }
       }
       if (a.head_w) {
         const bool drawn = unit >= dyn_first;
-        f32x4 zu[2];
+        f32x4 zu[NT];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) zu[ni] = drawn ? f32x4{0.f, 0.f, 0.f, 0.f} : zacc[ni];
+        for (int ni = 0; ni < NT; ++ni) zu[ni] = drawn ? f32x4{0.f, 0.f, 0.f, 0.f} : zacc[ni];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NT; ++ni)
               zu[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mi][r], acc[mi][ni][r], zu[ni], 0, 0, 0);
         }
         if (drawn) {
@@ -4095,11 +4111,11 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
           for (int r = 0; r < 4; ++r)
             if (4 * kq + r < a.hout) {
 #pragma unroll
-              for (int ni = 0; ni < 2; ++ni) slot[(4 * kq + r) * NC + 16 * ni + col] = zu[ni][r];
+              for (int ni = 0; ni < NT; ++ni) slot[(4 * kq + r) * NC + 16 * ni + col] = zu[ni][r];
             }
         } else {
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) zacc[ni] = zu[ni];
+          for (int ni = 0; ni < NT; ++ni) zacc[ni] = zu[ni];
         }
       }
       unit = nxt;
@@ -4109,7 +4125,7 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
       __syncthreads();  // every wave is done with the planes: the z partials go over them
       GLDM_PW_STAMP(17);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) zpart[(wave * 16 + 4 * kq + r) * NC + 16 * ni + col] = zacc[ni][r];
       __syncthreads();
@@ -4123,7 +4139,7 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
         for (int d = p; d < nd; d += 4) v += zdyn[(d * a.hout + row) * NC + cc];
         v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
         v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-        if (live && p == 0) a.z[((size_t)b * a.hout + row) * a.n + c0 + cc] = v + (a.head_b ? a.head_b[row] : 0.f);
+        if (live && p == 0 && cc < 16 * ntv) a.z[((size_t)b * a.hout + row) * a.n + c0 + cc] = v + (a.head_b ? a.head_b[row] : 0.f);
       }
     }
     GLDM_PW_STAMP(18);
@@ -4774,7 +4790,7 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   if (head_w && (!z || hout <= 0 || hout > 16)) return GLDM_ERR_INVALID_ARG;
   // k-blocks in pairs, 32-point tiles; output rows: 2 m-tiles x 8 waves per round on the f32 kernel, units of two m-tiles on
   // the split one (fewer than eight units -- 64 .. 224 output rows -- leave waves without a unit idle)
-  if ((cin & 31) || (n & 31) || (split_f16 ? (cout & 31) : (cout & 255))) return GLDM_ERR_UNSUPPORTED;
+  if ((cin & 31) || (split_f16 ? (n & 15) : (n & 31)) || (split_f16 ? (cout & 31) : (cout & 255))) return GLDM_ERR_UNSUPPORTED;
   if ((w0 || head_w) && (cout & 255)) return GLDM_ERR_UNSUPPORTED;   // front layer / head: whole rounds of units only
   if (w0 && (!b0 || cin0 <= 0 || (cin0 & 31) || (cin & 255))) return GLDM_ERR_UNSUPPORTED;
   size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
@@ -4782,24 +4798,40 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
     if (cin & 127) return GLDM_ERR_UNSUPPORTED;  // the A ring walks four 32-deep blocks per trip
     if (w0 && cin0 > 96) return GLDM_ERR_UNSUPPORTED;  // the front layer keeps its whole split tile in registers (72)
   }
-  int dyn_first = 0, ticket_off = 0;
+  int dyn_first = 0, ticket_off = 0, nt = 2, x0_in_planes = 0;
   if (split_f16) {
-    // LDS plan: planes | front tile, later the head products of the drawn units | ticket.  As many units are drawn as
-    // have room for their head slot (all but the first round when there is no head).
-    const size_t planes = (size_t)cin * 16 * kSplit * sizeof(float), cap = (size_t)160 * 1024 - 16;
-    size_t region = w0 ? (size_t)cin0 * 32 * sizeof(float) : 0;
-    if (planes + region > cap) return GLDM_ERR_UNSUPPORTED;
+    // LDS plan: planes | head products of the drawn units (the front layer's f32 tile lies under them: dead by then) |
+    // ticket.  As many units are drawn as have room for their head slot (all but the first round when there is no head).
+    // Tile width: 48 points where 32-point planes already take more than half a CU's LDS (one workgroup per CU either way)
+    // and the 48-point plan fits; the front tile then goes UNDER the planes (x0_in_planes).
+    const size_t cap = (size_t)160 * 1024 - 16;
     const int units = cout / 32;
-    int drawn = units > 8 ? units - 8 : 0;
-    if (head_w) {
-      const size_t slot = (size_t)hout * 32 * sizeof(float);
-      const int room = (int)((cap - planes) / slot);
-      if (drawn > room) drawn = room;
-      if (planes < (size_t)8 * 16 * 32 * sizeof(float)) drawn = 0;   // z partials need the planes' space
+    auto plan = [&](int ncol, bool x0_under, size_t &planes, size_t &region, int &first) {
+      planes = (size_t)cin * ncol * 2 * kSplit;   // bytes: cin x ncol x kSplit f16
+      region = (w0 && !x0_under) ? (size_t)cin0 * ncol * sizeof(float) : 0;
+      if (planes + region > cap) return false;
+      if (x0_under && (size_t)cin0 * ncol * sizeof(float) > planes) return false;
+      int drawn = units > 8 ? units - 8 : 0;
+      if (head_w) {
+        const size_t slot = (size_t)hout * ncol * sizeof(float);
+        const int room = (int)((cap - planes) / slot);
+        if (drawn > room) drawn = room;
+        if (planes < (size_t)8 * 16 * ncol * sizeof(float)) drawn = 0;   // z partials need the planes' space
+      }
+      first = (units - drawn + 7) & ~7;   // whole rounds are dealt
+      if (head_w && (size_t)(units - first) * hout * ncol * sizeof(float) > region)
+        region = (size_t)(units - first) * hout * ncol * sizeof(float);
+      return planes + region <= cap;
+    };
+    size_t planes = 0, region = 0;
+    if (!plan(32, false, planes, region, dyn_first)) return GLDM_ERR_UNSUPPORTED;
+    if ((planes + region + 16) * 2 > (size_t)160 * 1024 && n >= 48) {
+      size_t p3 = 0, r3 = 0;
+      int f3 = 0;
+      if (plan(48, w0 != nullptr, p3, r3, f3)) {
+        nt = 3; planes = p3; region = r3; dyn_first = f3; x0_in_planes = w0 ? 1 : 0;
+      }
     }
-    dyn_first = (units - drawn + 7) & ~7;   // whole rounds are dealt
-    if (head_w && (size_t)(units - dyn_first) * hout * 32 * sizeof(float) > region)
-      region = (size_t)(units - dyn_first) * hout * 32 * sizeof(float);
     ticket_off = (int)((planes + region) / sizeof(float));
     lds_bytes = planes + region + 16;
   }
@@ -4807,22 +4839,28 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   struct PwTag { int site; };
   struct PwBfTag { int site; };
   struct PwBfAddTag { int site; };
-  if (split_f16 && add) gldm_dev::allow_dynamic_lds<PwBfAddTag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<true>), 160 * 1024);
-  else if (split_f16) gldm_dev::allow_dynamic_lds<PwBfTag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<false>), 160 * 1024);
+  struct PwBf3Tag { int site; };
+  struct PwBfAdd3Tag { int site; };
+  if (split_f16 && add && nt == 3) gldm_dev::allow_dynamic_lds<PwBfAdd3Tag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<true, 3>), 160 * 1024);
+  else if (split_f16 && nt == 3) gldm_dev::allow_dynamic_lds<PwBf3Tag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<false, 3>), 160 * 1024);
+  else if (split_f16 && add) gldm_dev::allow_dynamic_lds<PwBfAddTag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<true, 2>), 160 * 1024);
+  else if (split_f16) gldm_dev::allow_dynamic_lds<PwBfTag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<false, 2>), 160 * 1024);
   else gldm_dev::allow_dynamic_lds<PwTag>(reinterpret_cast<const void *>(&pointwise_mlp_kernel), 160 * 1024);
   PwArgs a{};
   a.x = x; a.w = w; a.bias = bias; a.head_w = head_w; a.head_b = head_b; a.y = y; a.z = z;
   a.cin = cin; a.cout = cout; a.n = n; a.relu = relu; a.hout = hout;
   a.w0 = w0; a.bias0 = b0; a.cin0 = cin0;
-  a.dyn_first = dyn_first; a.ticket_off = ticket_off;
+  a.dyn_first = dyn_first; a.ticket_off = ticket_off; a.x0_in_planes = x0_in_planes;
   a.add = add; a.add_bs = add_bs; a.add_rs = add_rs; a.add_cs = add_cs;
-  a.tiles_per_cloud = n / 32;
+  a.tiles_per_cloud = (n + 16 * nt - 1) / (16 * nt);
   a.total_tiles = b * a.tiles_per_cloud;
   const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
   int grid = cu_count() * per_cu;
   if (grid > a.total_tiles) grid = a.total_tiles;
-  if (split_f16 && add) hipLaunchKernelGGL(pointwise_mlp_sp_kernel<true>, dim3(grid), dim3(512), lds_bytes, stream, a);
-  else if (split_f16) hipLaunchKernelGGL(pointwise_mlp_sp_kernel<false>, dim3(grid), dim3(512), lds_bytes, stream, a);
+  if (split_f16 && add && nt == 3) hipLaunchKernelGGL((pointwise_mlp_sp_kernel<true, 3>), dim3(grid), dim3(512), lds_bytes, stream, a);
+  else if (split_f16 && nt == 3) hipLaunchKernelGGL((pointwise_mlp_sp_kernel<false, 3>), dim3(grid), dim3(512), lds_bytes, stream, a);
+  else if (split_f16 && add) hipLaunchKernelGGL((pointwise_mlp_sp_kernel<true, 2>), dim3(grid), dim3(512), lds_bytes, stream, a);
+  else if (split_f16) hipLaunchKernelGGL((pointwise_mlp_sp_kernel<false, 2>), dim3(grid), dim3(512), lds_bytes, stream, a);
   else hipLaunchKernelGGL(pointwise_mlp_kernel, dim3(grid), dim3(512), lds_bytes, stream, a);
 #ifdef GLDM_DEBUG_KNOBS
   if (split_f16 && getenv("GLDM_PW_STAMP")) {   // diagnostic builds: phase clocks of one steady-state tile (waves 0 and 7)

@@ -387,8 +387,12 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   // out_cl: y is written channel-LAST, [b][r^3][cout] (one 16-byte store per accumulator instead of four 4-byte ones):
   // the layout of a PVConv's last conv, whose readers (SE squeeze, devoxelize) then take a voxel's channels as one run
   constexpr int r = R, NTW = ZB / WAVES, kThreads = 64 * WAVES, kZParts = R / ZB;
-  static_assert(NTW % 3 == 0 && MT % 3 == 0 && R % ZB == 0, "tiles walked in 3 x 3 groups");
-  constexpr int MG = MT / 3, NG = NTW / 3;
+  // tiles walked in GM x GN groups: 3 x 3 for the shipped encoder's 48 / 96 channels on 24^3 / 12^3 bricks; the power-of-two
+  // widths and grids of PVCNN2 (32 / 64 / 128 channels at 32^3 .. 4^3) in groups of 4, 2 or 1
+  constexpr int GM = MT % 3 == 0 ? 3 : (MT % 4 == 0 ? 4 : (MT % 2 == 0 ? 2 : 1));
+  constexpr int GN = NTW % 3 == 0 ? 3 : (NTW % 2 == 0 ? 2 : 1);
+  static_assert(R % ZB == 0 && ZB % WAVES == 0, "whole n-tiles per wave");
+  constexpr int MG = MT / GM, NG = NTW / GN;
   // (Measured and kept out: 4 waves x 6 n-tiles on the 24^3 brick -- half the weight-fragment deliveries, but more than
   // 256 registers, hence one wave per SIMD -- 0.74 ms per launch against 0.67 for 8 waves x 3 n-tiles.)
   constexpr int zp = ZB + 2, nvox = 36 * zp, r3 = r * r * r;
@@ -505,30 +509,30 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
     if (cb < 3) GLDM_C3_STAMP(4 + 4 * cb);
     __syncthreads();
     if (cb < 3) GLDM_C3_STAMP(5 + 4 * cb);
-    c3_u32x4 a[2][3][kC3Split];
+    c3_u32x4 a[2][GM][kC3Split];
     auto load_a = [&](int buf, int step) {   // step = pair * MG + mg
       const int p = step / MG, mg = step - p * MG;
 #pragma unroll
-      for (int mi = 0; mi < 3; ++mi)
+      for (int mi = 0; mi < GM; ++mi)
 #pragma unroll
         for (int k = 0; k < kC3Split; ++k)
-          a[buf][mi][k] = wv.raw_at((((3 * mg + mi) * kblocks + cb * kPairs + p) * kC3Split) * 1024, k * 1024);
+          a[buf][mi][k] = wv.raw_at((((GM * mg + mi) * kblocks + cb * kPairs + p) * kC3Split) * 1024, k * 1024);
     };
     load_a(0, 0);
     __builtin_amdgcn_s_setprio(0);
     constexpr int kSteps = kPairs * MG;
     constexpr int kUnits = kPairs * NG;   // (pair, n-group) units: the B planes of unit u + 1 are requested during unit u
     constexpr bool kBPre = NG > 1;   // a second B set costs 36 registers: only where a wave has two n-groups
-    c3_u32x4 bs[kBPre ? 2 : 1][3][kC3Split];
+    c3_u32x4 bs[kBPre ? 2 : 1][GN][kC3Split];
     auto load_b = [&](int buf, int unit) {
       const int p = unit / NG, ng = unit - p * NG;
       const int ta = 2 * p, tb = 2 * p + 1 < 27 ? 2 * p + 1 : 26;
       const int offa = ((ta / 9) * 6 + (ta / 3) % 3) * zp + ta % 3, offb = ((tb / 9) * 6 + (tb / 3) % 3) * zp + tb % 3;
       const int toff = (kq >> 1) ? offb : offa;
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < GN; ++q)
 #pragma unroll
-        for (int k = 0; k < kC3Split; ++k) bs[buf][q][k] = pl[k * 2 * hs + vb[3 * ng + q] + toff];
+        for (int k = 0; k < kC3Split; ++k) bs[buf][q][k] = pl[k * 2 * hs + vb[GN * ng + q] + toff];
     };
     if (kBPre) load_b(0, 0);
     for (int p0 = 0; p0 < kPairs; p0 += 2) {
@@ -549,10 +553,10 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
             if (ng == 0) load_a(cur ^ 1, step + 1 < kSteps ? step + 1 : step);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mi = 0; mi < 3; ++mi)
+            for (int mi = 0; mi < GM; ++mi)
 #pragma unroll
-              for (int q = 0; q < 3; ++q)
-                acc[3 * mg + mi][3 * ng + q] = c3_mfma3(a[cur][mi], bs[bcur][q], acc[3 * mg + mi][3 * ng + q]);
+              for (int q = 0; q < GN; ++q)
+                acc[GM * mg + mi][GN * ng + q] = c3_mfma3(a[cur][mi], bs[bcur][q], acc[GM * mg + mi][GN * ng + q]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -1361,7 +1365,7 @@ static int conv3d_k3_f16x2_impl(const float *x, const float *in_coef, const floa
     hipLaunchKernelGGL((conv3d_k3_fewch_sp_kernel<3, 24, 3, 8>), dim3(36, b), dim3(512), lds_bytes, s, x, w_split, bias, y, partial);
     return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
   }
-  if (cin % 16 || cout % 48) return GLDM_ERR_UNSUPPORTED;   // the kernels below: cout == 16 MT exactly, no row guards
+  if (cin % 16) return GLDM_ERR_UNSUPPORTED;   // the kernels below: cout == 16 MT exactly, no row guards
 #ifdef GLDM_DEBUG_KNOBS
   struct StampDump {  // diagnostic builds: GLDM_C3_STAMP=1 prints the phase clocks of one mid-grid workgroup per call
     hipStream_t s; int cin, cout, r, b;
@@ -1383,6 +1387,16 @@ static int conv3d_k3_f16x2_impl(const float *x, const float *in_coef, const floa
   // halves pay a z halo and the weight stream twice.  Kept as an instantiable option, not used.)
   if (cout == 48 && r == 24) return launch_conv_pl<3, 24, 24, 8>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
   if (cout == 96 && r == 12) return launch_conv_pl<6, 12, 12, 4>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
+  // PVCNN2's power-of-two shapes (round 5; f32-MFMA kernels before): <MT, R, ZB, WAVES>
+  if (cout == 32 && r == 32) return launch_conv_pl<2, 32, 32, 8>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
+  if (cout == 64 && r == 32) return launch_conv_pl<4, 32, 32, 8>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
+  if (cout == 32 && r == 16) return launch_conv_pl<2, 16, 16, 4>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
+  if (cout == 64 && r == 16) return launch_conv_pl<4, 16, 16, 4>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
+  if (cout == 128 && r == 16) return launch_conv_pl<8, 16, 16, 8>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
+  if (cout == 64 && r == 8) return launch_conv_pl<4, 8, 8, 4>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
+  if (cout == 128 && r == 8) return launch_conv_pl<8, 8, 8, 4>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
+  if (cout == 256 && r == 8) return launch_conv_pl<16, 8, 8, 8>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
+  if (cout == 128 && r == 4) return launch_conv_pl<8, 4, 4, 4>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
   return GLDM_ERR_UNSUPPORTED;
 }
 

@@ -10,6 +10,11 @@ SUPPORTED = {(3, 6), (6, 3), (2, 8), (4, 4), (8, 2), (4, 8), (2, 4), (4, 2), (1,
              (16, 2), (8, 4)}  # (cout/16, r/4) instantiated in voxel_conv.hip (the last two as two half-width launches)
 
 
+# (cout, r) of the plane-staging split-f16 kernel (gldm_conv3d_k3_f16x2; cin % 16 == 0): the shipped encoder's two shapes
+# and, since round 5, PVCNN2's power-of-two ones
+SPLIT_SHAPES = {(48, 24), (96, 12), (32, 32), (64, 32), (32, 16), (64, 16), (128, 16), (64, 8), (128, 8), (256, 8), (128, 4)}
+
+
 def conv_supported(cout, r):
     return cout % 16 == 0 and r % 4 == 0 and (cout // 16, r // 4) in SUPPORTED
 
@@ -24,9 +29,9 @@ def pack_conv3d(weight):
 
 
 def split_conv_supported(cin, cout, r):
-    """Shapes gldm_conv3d_k3_f16x2 is built for (the shipped PVCNN encoder's 48 ch @ 24^3 and 96 ch @ 12^3, and its
-    first conv 3 -> 48 @ 24^3 with K = 81 packed into three 32-deep blocks)."""
-    return (cin % 16 == 0 and (cout, r) in ((48, 24), (96, 12))) or (cin, cout, r) == (3, 48, 24)
+    """Shapes gldm_conv3d_k3_f16x2 is built for (SPLIT_SHAPES with cin % 16 == 0, and the shipped encoder's first conv
+    3 -> 48 @ 24^3 with K = 81 packed into three 32-deep blocks)."""
+    return (cin % 16 == 0 and (cout, r) in SPLIT_SHAPES) or (cin, cout, r) == (3, 48, 24)
 
 
 def pack_conv3d_fewch_f16x2(weight):

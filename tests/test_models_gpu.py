@@ -283,9 +283,12 @@ def test_conv3d_groupnorm_swish_kernels(cin, cout, r):
     assert _err(cs / r ** 3, ref2.mean(dim=(2, 3, 4))) < 1e-5
 
 
-@pytest.mark.parametrize("cin,cout,r", [(3, 48, 24), (48, 48, 24), (48, 96, 12), (96, 96, 12)])
-def test_conv3d_split_bf16_kernels(cin, cout, r):
-    """gldm_conv3d_k3_f16x2 (the shipped encoder's four voxel convs; 3 -> 48 with K = 81 packed into three k-blocks) vs
+@pytest.mark.parametrize("cin,cout,r", [(3, 48, 24), (48, 48, 24), (48, 96, 12), (96, 96, 12),
+                                        (32, 32, 16), (16, 32, 32), (32, 64, 16), (64, 64, 8), (64, 64, 32), (64, 128, 8),
+                                        (128, 128, 4), (128, 128, 16), (128, 256, 8)])
+def test_conv3d_split_f16_kernels(cin, cout, r):
+    """gldm_conv3d_k3_f16x2 (the shipped encoder's four voxel convs; 3 -> 48 with K = 81 packed into three k-blocks; PVCNN2's
+    power-of-two widths and grids, tiles walked in 2- and 4-groups) vs
     torch conv3d on the CPU, and its GroupNorm partials through gldm_groupnorm_swish (fp32, 2e-5)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
