@@ -56,7 +56,8 @@ def pack_head(wh):
 def split_supported(cin, cin0=0):
     """The split-f16 form of the fused launch (gldm_pointwise_mlp*_f16x2): A ring of four 32-deep blocks, the tile
     as planes (48 floats per channel) + the front layer's f32 tile (split once per wave into registers: cin0 <= 96)."""
-    return cin % 128 == 0 and cin0 % 32 == 0 and cin0 <= 96 and 4 * (48 * cin + 32 * cin0) + 16 <= 160 * 1024
+    from .numerics import split_enabled
+    return split_enabled() and cin % 128 == 0 and cin0 % 32 == 0 and cin0 <= 96 and 4 * (48 * cin + 32 * cin0) + 16 <= 160 * 1024
 
 
 def fused_mlp_supported(x, cin, cout):

@@ -257,6 +257,12 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
     else:
         d.latent_dim = 0
     d.seq_len = seq_len
+    from .numerics import split_enabled
+    if not split_enabled():   # numerics.f32_only(): the descriptor names no split copy -> sample-major engine, exact f32 products
+        for rb in d.rb:
+            rb.c1_w3 = rb.c2_w3 = rb.c1_wq = rb.c2_wq = 0
+        for lv in d.lv:
+            lv.qkvn_w3 = lv.out_w3 = lv.down_w3 = lv.qkvn_wq = lv.out_wq = lv.down_wq = 0
     temb = None
     if (p + "time_mlp.1.weight") in sd:
         if num_steps is None:

@@ -31,7 +31,8 @@ def fusable(shared_mlp, num_neighbors):
 
 def split_plan_ok(cins, couts, num_neighbors):
     """Shapes gldm_sa_mlp_forward_f16x2 takes (csrc/resnet1d.hip: sa_mlp3_kernel): 64-column tiles on split-f16 planes."""
-    if int(num_neighbors) not in (16, 32, 64) or not 1 <= len(couts) <= 4:
+    from .numerics import split_enabled
+    if not split_enabled() or int(num_neighbors) not in (16, 32, 64) or not 1 <= len(couts) <= 4:
         return False
     # hidden widths are packed padded to the 32-row plane blocks (zero weight rows, zero bias: ReLU leaves zeros, and the
     # next layer's weights over those rows are zero): a 16-wide hidden layer (half-width PVCNN2) runs as a 32-wide one

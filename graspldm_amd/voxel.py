@@ -31,7 +31,12 @@ def pack_conv3d(weight):
 def split_conv_supported(cin, cout, r):
     """Shapes gldm_conv3d_k3_f16x2 is built for (SPLIT_SHAPES with cin % 16 == 0, and the shipped encoder's first conv
     3 -> 48 @ 24^3 with K = 81 packed into three 32-deep blocks)."""
-    return (cin % 16 == 0 and (cout, r) in SPLIT_SHAPES) or (cin, cout, r) == (3, 48, 24)
+    if (cin, cout, r) == (3, 48, 24):
+        return True   # its f32 form pads K to 27 x 16: kept on the split kernel whatever numerics.f32_only() says
+    if cin % 16 or (cout, r) not in SPLIT_SHAPES:
+        return False
+    from .numerics import split_enabled
+    return split_enabled() or not conv_supported(cout, r)   # a shape without an f32 instantiation keeps its only MFMA kernel
 
 
 def pack_conv3d_fewch_f16x2(weight):

@@ -838,3 +838,30 @@ def test_standalone_wide_layer_with_narrow_input_runs_the_f32_launch():
         exp = torch.relu(bn(conv(x)))
         got = dense.pointwise_conv_bn_relu(x.cuda(), conv.cuda(), bn.cuda())
     assert _err(got, exp) < 2e-5
+
+
+def test_f32_only_switch_runs_the_exact_f32_kernels(ldm):
+    """numerics.f32_only(): the same module API on the f32 matrix pipe everywhere (descriptor without split copies ->
+    sample-major engine; SA / pointwise / voxel launches on their f32 forms).  Both paths meet the reference's vectors; they
+    differ from each other in the last bits only."""
+    from graspldm_amd import numerics
+    from graspldm_amd.r1d import R1dEngine, pack_resnet1d
+    from graspldm_amd import _lib as L
+    g = load_golden("ldm_e2e.npz")
+    with numerics.f32_only():
+        m = build_fpc(scheduler="ddim")
+        m.load_state_dict(ldm.state_dict(), strict=True)
+        m = m.cuda().eval()
+        m.set_inference_timesteps(100)
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        packed = pack_resnet1d(sd, "diffusion_model.model.", groups=4, seq_len=4, num_steps=1000)
+        assert L.lib().gldm_r1d_tile_columns(R1dEngine(packed, "cuda:0")._desc_ptr()) == 32
+        torch.manual_seed(int(g["seed"]))
+        (tm, lg), _ = m.generate_grasps(g["pc"].cuda(), num_grasps=20)
+    assert numerics.split_enabled()
+    ldm.set_inference_timesteps(100)
+    torch.manual_seed(int(g["seed"]))
+    (tm2, lg2), _ = ldm.generate_grasps(g["pc"].cuda(), num_grasps=20)
+    assert _err(tm, g["tmrp"]) < 1e-4 and _err(tm2, g["tmrp"]) < 1e-4
+    assert (tm - tm2).abs().max().item() < 5e-5
+    assert not torch.equal(tm, tm2)   # another summation, not the same bits
