@@ -3573,7 +3573,12 @@ long long park_bytes(const gldm_r1d_desc *d, long long tiles, long long *base) {
 struct Plan { int grid, slots, rounds, left, chain, seglen; };
 
 Plan make_plan(int n_samples, int n_steps, int L, int nc, bool allow_chain = true) {
-  const int slots = cu_count() * (nc == 32 ? 2 : 1);
+  int slots = cu_count() * (nc == 32 ? 2 : 1);
+#ifdef GLDM_DEBUG_KNOBS
+  // co-residence experiment: fewer persistent workgroups than CUs, so that another stream's kernels find free
+  // CUs while the fused launch runs
+  if (const char *e = getenv("GLDM_R1D_SLOTS")) slots = atoi(e) > 0 ? atoi(e) : slots;
+#endif
   const int S = nc / L;
   const int tiles = (n_samples + S - 1) / S;
   Plan p{tiles, slots, 1, 0, 1, n_steps};
