@@ -592,16 +592,18 @@ __global__ __launch_bounds__(kVoxBlock) void avg_voxelize_dense_kernel(const flo
   // round trips inside the chains).  stage_feat == 2: fetched as 16-byte loads into registers a round AHEAD (requested
   // before the previous round's chains, stored after them): with one block per CU nothing else hides those round trips
   float *sf = grid + (size_t)g_rows * r3;
-  constexpr int kPre = 4;
-  float4 pre[kPre];
+  // four named registers (an indexed float4[4] behind the lambda and the data-dependent round loop was kept in scratch:
+  // 96 B per lane of private memory in a latency-bound kernel)
+  float4 pre0 = z4, pre1 = z4, pre2 = z4, pre3 = z4;
   auto fetch = [&](int l0, int rows) {
     const float4 *src = reinterpret_cast<const float4 *>(feat + (size_t)l0 * n);
     const int cnt4 = (rows * n) >> 2;
-#pragma unroll
-    for (int k = 0; k < kPre; ++k) {
-      const int i = tid + k * kVoxBlock;
-      pre[k] = i < cnt4 ? src[i] : z4;
-    }
+    // unconditional loads on clamped addresses; lanes beyond the rows keep a value nobody stores
+    const int last = cnt4 > 0 ? cnt4 - 1 : 0;
+    pre0 = src[min(tid, last)];
+    pre1 = src[min(tid + kVoxBlock, last)];
+    pre2 = src[min(tid + 2 * kVoxBlock, last)];
+    pre3 = src[min(tid + 3 * kVoxBlock, last)];
   };
   if (stage_feat == 2) fetch(c0, min(g_rows, c1 - c0));
   for (int l0 = c0; l0 < c1; l0 += g_rows) {
@@ -609,11 +611,11 @@ __global__ __launch_bounds__(kVoxBlock) void avg_voxelize_dense_kernel(const flo
     for (int i = tid; i < rows * (r3 / 4); i += kVoxBlock) reinterpret_cast<float4 *>(grid)[i] = z4;
     if (stage_feat == 2) {
       const int cnt4 = (rows * n) >> 2;
-#pragma unroll
-      for (int k = 0; k < kPre; ++k) {
-        const int i = tid + k * kVoxBlock;
-        if (i < cnt4) reinterpret_cast<float4 *>(sf)[i] = pre[k];
-      }
+      float4 *sf4 = reinterpret_cast<float4 *>(sf);
+      if (tid < cnt4) sf4[tid] = pre0;
+      if (tid + kVoxBlock < cnt4) sf4[tid + kVoxBlock] = pre1;
+      if (tid + 2 * kVoxBlock < cnt4) sf4[tid + 2 * kVoxBlock] = pre2;
+      if (tid + 3 * kVoxBlock < cnt4) sf4[tid + 3 * kVoxBlock] = pre3;
     } else if (stage_feat) {
       for (int i = tid; i < rows * n; i += kVoxBlock) sf[i] = feat[(size_t)l0 * n + i];
     }
