@@ -297,3 +297,24 @@ def test_pad_cin32_and_16_position_descriptors():
     d.rb[0].c1_w3 = 0   # a packer without the padded 16-channel copies -> the sample-major f32 engine
     assert _lib.lib().gldm_r1d_tile_columns(ptr) == 32
     d.rb[0].c1_w3 = keep
+
+
+def test_f32_only_switch_changes_what_is_packed_and_chosen(fpc_state_dict):
+    """numerics.f32_only(): descriptors name no split copy (-> sample-major f32 engine), the split shape predicates say no
+    wherever an f32 kernel exists, and the switch restores itself."""
+    from graspldm_amd import numerics, voxel, dense
+    from graspldm_amd.r1d_pack import pack_resnet1d
+    from graspldm_amd.sa_pack import split_plan_ok
+    sd = fpc_state_dict
+    on = pack_resnet1d(sd, "diffusion_model.model.", groups=4, seq_len=4, num_steps=1000)["desc"]
+    assert on.rb[2].c1_w3 > 0 and on.rb[2].c1_wq > 0 and on.lv[1].qkvn_wq > 0
+    assert voxel.split_conv_supported(48, 48, 24) and dense.split_supported(768, 96) and split_plan_ok([131], [128, 128, 256], 64)
+    with numerics.f32_only():
+        assert not numerics.split_enabled()
+        off = pack_resnet1d(sd, "diffusion_model.model.", groups=4, seq_len=4, num_steps=1000)["desc"]
+        assert all(rb.c1_w3 == rb.c2_w3 == rb.c1_wq == rb.c2_wq == 0 for rb in off.rb)
+        assert all(lv.qkvn_w3 == lv.out_w3 == lv.down_w3 == lv.qkvn_wq == lv.out_wq == lv.down_wq == 0 for lv in off.lv)
+        assert not voxel.split_conv_supported(48, 48, 24) and not dense.split_supported(768, 96)
+        assert not split_plan_ok([131], [128, 128, 256], 64)
+        assert voxel.split_conv_supported(3, 48, 24)          # the 3-channel conv has no other MFMA form
+    assert numerics.split_enabled()
