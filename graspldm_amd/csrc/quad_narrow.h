@@ -61,6 +61,34 @@ __device__ __forceinline__ float pos_sum(float v) {   // over the 4 positions of
   return v + dpp_mov<0x128>(v);
 }
 __device__ __forceinline__ float pos_max(float v) { return dpp_max<0x128>(dpp_max<0x124>(v)); }
+// The same two reductions over EIGHT independent values at once, in place, as 16 v_max_f32_dpp / v_add_f32_dpp in one block:
+// one at a time every DPP read sits right behind the write of its operand and pays the hazard's wait states (or, from the
+// intrinsics, a v_mov_b32_dpp + the op); eight deep, an instruction's operand was written eight instructions earlier and only
+// the block's first needs the s_nop.  (The chain is issue bound: instructions are what it costs.)
+__device__ __forceinline__ void pos_max8(float (&v)[8]) {
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %6, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+__device__ __forceinline__ void pos_sum8(float (&v)[8]) {
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
 __device__ __forceinline__ float kq_sum(float v) { return half_sum(row_pair_sum(v)); }   // over the four row quarters
 __device__ __forceinline__ float kq_max(float v) { return half_max(row_pair_max(v)); }
 
@@ -439,14 +467,21 @@ template <bool L2E>
 __device__ __forceinline__ void quad_attention_head(const f32x4 (&qa)[2], const f32x4 (&ka)[2], const f32x4 (&va)[2], f32x4 (&out)[2]) {
   constexpr float kL2e = 1.44269504088896340736f;
   float kn[2][4], qe[2][4];
+  {
+    float m8[8], e8[8], s8[8];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int i = 0; i < 8; ++i) m8[i] = ka[i >> 2][i & 3];
+    pos_max8(m8);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float m = pos_max(ka[h][r]);
-      const float ex = L2E ? __builtin_amdgcn_exp2f(ka[h][r] - m) : __builtin_amdgcn_exp2f((ka[h][r] - m) * kL2e);
-      kn[h][r] = ex * __builtin_amdgcn_rcpf(pos_sum(ex));
+    for (int i = 0; i < 8; ++i) {
+      const float d = ka[i >> 2][i & 3] - m8[i];
+      e8[i] = L2E ? __builtin_amdgcn_exp2f(d) : __builtin_amdgcn_exp2f(d * kL2e);
+      s8[i] = e8[i];
     }
+    pos_sum8(s8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kn[i >> 2][i & 3] = e8[i] * __builtin_amdgcn_rcpf(s8[i]);
+  }
   float qm = fmaxf(fmaxf(fmaxf(qa[0][0], qa[0][1]), fmaxf(qa[0][2], qa[0][3])), fmaxf(fmaxf(qa[1][0], qa[1][1]), fmaxf(qa[1][2], qa[1][3])));
   qm = kq_max(qm);
   float qs = 0.f;
