@@ -65,29 +65,17 @@ __device__ __forceinline__ float pos_max(float v) { return dpp_max<0x128>(dpp_ma
 // one at a time every DPP read sits right behind the write of its operand and pays the hazard's wait states (or, from the
 // intrinsics, a v_mov_b32_dpp + the op); eight deep, an instruction's operand was written eight instructions earlier and only
 // the block's first needs the s_nop.  (The chain is issue bound: instructions are what it costs.)
-__device__ __forceinline__ void pos_max8(float (&v)[8]) {
+__device__ __forceinline__ void pos_max8(const float (&x)[8], float (&r)[8]) {   // r[i] = max over the sample's four positions of x[i]
   asm("s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %6, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
-      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+      "v_max_f32_dpp %0, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %12, %12 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %13, %13 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %14, %14 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %15, %15 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
 }
-__device__ __forceinline__ void pos_sum8(float (&v)[8]) {
+__device__ __forceinline__ void pos_sum8(const float (&x)[8], float (&r)[8]) {   // r[i] = sum over the sample's four positions of x[i]
   asm("s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
-      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+      "v_add_f32_dpp %0, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %2, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %4, %12, %12 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %13, %13 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %6, %14, %14 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %15, %15 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
 }
 __device__ __forceinline__ float kq_sum(float v) { return half_sum(row_pair_sum(v)); }   // over the four row quarters
 __device__ __forceinline__ float kq_max(float v) { return half_max(row_pair_max(v)); }
@@ -468,17 +456,16 @@ __device__ __forceinline__ void quad_attention_head(const f32x4 (&qa)[2], const 
   constexpr float kL2e = 1.44269504088896340736f;
   float kn[2][4], qe[2][4];
   {
-    float m8[8], e8[8], s8[8];
+    float k8[8], m8[8], e8[8], s8[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m8[i] = ka[i >> 2][i & 3];
-    pos_max8(m8);
+    for (int i = 0; i < 8; ++i) k8[i] = ka[i >> 2][i & 3];
+    pos_max8(k8, m8);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float d = ka[i >> 2][i & 3] - m8[i];
+      const float d = k8[i] - m8[i];
       e8[i] = L2E ? __builtin_amdgcn_exp2f(d) : __builtin_amdgcn_exp2f(d * kL2e);
-      s8[i] = e8[i];
     }
-    pos_sum8(s8);
+    pos_sum8(e8, s8);
 #pragma unroll
     for (int i = 0; i < 8; ++i) kn[i >> 2][i & 3] = e8[i] * __builtin_amdgcn_rcpf(s8[i]);
   }
