@@ -535,31 +535,36 @@ __device__ __forceinline__ void quad_attention(const Ctx &c, QRing &ring, const 
       v = fmaf(d, d, v);
     }
   const float rstd = __builtin_amdgcn_rsqf(kq_sum(v) * (1.0f / (float)C) + 1e-5f);
-  const float mr = mean * rstd;
+  // B operand of to_qkv: the normalised column itself, split here (MT values per lane, once per level).  The packer's
+  // quad copy of W' = W diag(g) carries log2(e) on the q and k rows, so a head's accumulators are what its softmaxes
+  // exponentiate: nothing stands between the MFMAs and the attention core (48 VALU instructions and six parameter
+  // loads per head before).
+  u32x4 xn[KB][kSplit];
+  {
+    const float mr = mean * rstd;
+    f32x4 t[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[mi][r] = fmaf(xr[mi][r], rstd, -mr);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) qsplit8(t[2 * kb], t[2 * kb + 1], xn[kb]);
+  }
   f32x4 oacc[MT];
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) oacc[mi] = *reinterpret_cast<const f32x4 *>(w + lv.out_b + 16 * mi + 4 * kq);
   auto head = [&](auto h_c) {
     constexpr int h = decltype(h_c)::value, NH = N0 + h * kPer;
-    f32x4 sv[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sv[i] = *reinterpret_cast<const f32x4 *>(w + lv.qkvn_s + 16 * (2 * h + (i & 1) + 8 * (i >> 1)) + 4 * kq);
     f32x4 qkv[6];   // [part q|k|v][half]: m-tiles 2 h + half + 8 part of to_qkv
 #pragma unroll
     for (int i = 0; i < 6; ++i) qkv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto mt6 = [&](auto i_c) {
       constexpr int i = decltype(i_c)::value;
-      qkv[i] = qring_mfma<NH + i * KB>(ring, xp[0], qkv[i]);
-      if constexpr (KB > 1) qkv[i] = qring_mfma<NH + i * KB + 1>(ring, xp[KB - 1], qkv[i]);
+      qkv[i] = qring_mfma<NH + i * KB>(ring, xn[0], qkv[i]);
+      if constexpr (KB > 1) qkv[i] = qring_mfma<NH + i * KB + 1>(ring, xn[KB - 1], qkv[i]);
     };
     mt6(integral_constant<int, 0>{}); mt6(integral_constant<int, 1>{}); mt6(integral_constant<int, 2>{});
     mt6(integral_constant<int, 3>{}); mt6(integral_constant<int, 4>{}); mt6(integral_constant<int, 5>{});
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {   // q and k times log2(e): their softmaxes exponentiate with v_exp_f32 = 2^x
-      const float ra = i < 4 ? rstd * 1.44269504088896340736f : rstd, ma = i < 4 ? mr * 1.44269504088896340736f : mr;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) qkv[i][r] = qkv[i][r] * ra - ma * sv[i][r];
-    }
     f32x4 o[2];
     const f32x4 qa[2] = {qkv[0], qkv[1]}, ka[2] = {qkv[2], qkv[3]}, va[2] = {qkv[4], qkv[5]};
     quad_attention_head<true>(qa, ka, va, o);
@@ -663,7 +668,8 @@ __device__ __forceinline__ float quad_attention4(const Ctx &c, QRing &ring, cons
 #pragma unroll
   for (int h = 0; h < kHeads; ++h)
 #pragma unroll
-    for (int t = 0; t < 6; ++t) fq[h][t] = w[lv.qkvn_w + ((2 * h + (t & 1) + 8 * (t >> 1)) * 64 + c.lane) * 4];
+    for (int t = 0; t < 6; ++t)   // q and k rows times log2(e): their softmaxes exponentiate with 2^x
+      fq[h][t] = w[lv.qkvn_w + ((2 * h + (t & 1) + 8 * (t >> 1)) * 64 + c.lane) * 4] * (t < 4 ? 1.44269504088896340736f : 1.0f);
   const float outb = w[lv.out_b + kq], g2 = w[lv.ln2_g + kq];
   const float mean = kq_sum(x) * 0.25f;
   const float d = x - mean;
@@ -676,7 +682,7 @@ __device__ __forceinline__ float quad_attention4(const Ctx &c, QRing &ring, cons
     for (int t = 0; t < 6; ++t) qkv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[h][t], xn, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     f32x4 o[2];
     const f32x4 qa[2] = {qkv[0], qkv[1]}, ka[2] = {qkv[2], qkv[3]}, va[2] = {qkv[4], qkv[5]};
-    quad_attention_head<false>(qa, ka, va, o);
+    quad_attention_head<true>(qa, ka, va, o);
     u32x4 op[kSplit];
     qsplit8(o[0], o[1], op);
     oacc = qring_mfma<kQN0 + h>(ring, op, oacc);

@@ -234,7 +234,12 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
                 wo = wo4
             lv.out_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(wo)))
             if c != 4:
-                lv.qkvn_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(wn)))
+                # the quad engine multiplies these rows with the NORMALISED column, (x - mean) rstd, split on the spot (no
+                # mean / rstd correction behind the GEMM), and exponentiates q and k with v_exp_f32 = 2^x: their rows
+                # (the first 2 x 128) carry log2(e)
+                wq = wn.double().clone()
+                wq[:2 * hid] *= 1.4426950408889634
+                lv.qkvn_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(wq.float())))
                 lv.down_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(conv_as_gemm(sd[q + "3.weight"]))))
         lv.down_b = buf.add(sd[q + "3.bias"])
     resblock(p + "final_res_block.", dims[-1], slot)

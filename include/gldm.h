@@ -170,7 +170,9 @@ typedef struct gldm_r1d_level {
   int32_t qkvn_s;       /* ABI 4: row sums of W' [384] (the mean term of the folded LayerNorm)     */
   int32_t qkvn_w3, out_w3, down_w3; /* ABI 5: qkvn_w / out_w / down_w as split-f16 fragments; 0 = absent */
   int32_t qkvn_wq, out_wq, down_wq; /* ABI 9: the same in quad column order; out_wq of a 4-channel level has
-                                       channel ch in row 4 ch of its one m-tile; 0 = absent              */
+                                       channel ch in row 4 ch of its one m-tile; qkvn_wq = W' = W diag(g) with
+                                       its q and k rows (the first 256) times log2(e): the engine multiplies it
+                                       with the normalised column and exponentiates with 2^x; 0 = absent   */
 } gldm_r1d_level;
 
 /* Quad column order (ABI 9; r1d_pack.quad_perm32): the wave-local engine of the narrow levels (csrc/quad_narrow.h) feeds
