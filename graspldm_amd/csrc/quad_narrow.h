@@ -65,17 +65,22 @@ __device__ __forceinline__ float pos_max(float v) { return dpp_max<0x128>(dpp_ma
 // one at a time every DPP read sits right behind the write of its operand and pays the hazard's wait states (or, from the
 // intrinsics, a v_mov_b32_dpp + the op); eight deep, an instruction's operand was written eight instructions earlier and only
 // the block's first needs the s_nop.  (The chain is issue bound: instructions are what it costs.)
+#define GLDM_DPP8_STAGE1(op, i, j) "v_" op "_f32_dpp %" #i ", %" #j ", %" #j " row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+#define GLDM_DPP8_STAGE2(op, i) "v_" op "_f32_dpp %" #i ", %" #i ", %" #i " row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+#define GLDM_DPP8(op)                                                                                                  \
+  "s_nop 1\n\t"                                                                                                         \
+  GLDM_DPP8_STAGE1(op, 0, 8) GLDM_DPP8_STAGE1(op, 1, 9) GLDM_DPP8_STAGE1(op, 2, 10) GLDM_DPP8_STAGE1(op, 3, 11)          \
+  GLDM_DPP8_STAGE1(op, 4, 12) GLDM_DPP8_STAGE1(op, 5, 13) GLDM_DPP8_STAGE1(op, 6, 14) GLDM_DPP8_STAGE1(op, 7, 15)        \
+  GLDM_DPP8_STAGE2(op, 0) GLDM_DPP8_STAGE2(op, 1) GLDM_DPP8_STAGE2(op, 2) GLDM_DPP8_STAGE2(op, 3)                        \
+  GLDM_DPP8_STAGE2(op, 4) GLDM_DPP8_STAGE2(op, 5) GLDM_DPP8_STAGE2(op, 6) GLDM_DPP8_STAGE2(op, 7)
+#define GLDM_DPP8_OPERANDS                                                                                             \
+  : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])            \
+  : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7])
 __device__ __forceinline__ void pos_max8(const float (&x)[8], float (&r)[8]) {   // r[i] = max over the sample's four positions of x[i]
-  asm("s_nop 1\n\t"
-      "v_max_f32_dpp %0, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %12, %12 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %13, %13 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %14, %14 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %15, %15 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
-      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
-      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+  asm(GLDM_DPP8("max") GLDM_DPP8_OPERANDS);
 }
 __device__ __forceinline__ void pos_sum8(const float (&x)[8], float (&r)[8]) {   // r[i] = sum over the sample's four positions of x[i]
-  asm("s_nop 1\n\t"
-      "v_add_f32_dpp %0, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %2, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %4, %12, %12 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %13, %13 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %6, %14, %14 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %15, %15 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
-      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
-      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+  asm(GLDM_DPP8("add") GLDM_DPP8_OPERANDS);
 }
 __device__ __forceinline__ float kq_sum(float v) { return half_sum(row_pair_sum(v)); }   // over the four row quarters
 __device__ __forceinline__ float kq_max(float v) { return half_max(row_pair_max(v)); }
