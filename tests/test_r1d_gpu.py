@@ -524,3 +524,34 @@ def test_in_kernel_noise_equals_the_same_normals_fed_from_memory(engines):
     other = den.denoise_rng(x_T, cemb, 1, ts, coef, seed + 1, noise_base=base)
     assert (other - want).abs().max().item() > 1e-3
 
+
+
+@pytest.mark.parametrize("engine_columns", [64, 32])
+def test_in_kernel_noise_on_the_sixteen_position_engines(engine_columns):
+    """gldm_denoise_rng on a 16-position denoiser (the `ppc` experiment's shape class): four position blocks per latent, on
+    the 64-column engine and on the sample-major f32 engine -- each bit for bit what the memory-fed launch gives with
+    gldm_step_noise_rng's normals."""
+    from graspldm_amd import _lib as L
+    from graspldm_amd.diffusion import make_schedule_tables
+    from graspldm_amd.resnets import TimeConditionedResNet1D
+    from graspldm_amd.r1d import SCHED_DDPM, step_noise_rng
+    from graspldm_amd.synthetic import load_synthetic_weights
+    net = TimeConditionedResNet1D(dim=16, channels=1, block_channels=(32, 64), input_conditioning_dims=64,
+                                  resnet_block_groups=4, dropout=0.1, is_time_conditioned=True, learned_variance=False,
+                                  learned_sinusoidal_cond=False, random_fourier_features=True)
+    load_synthetic_weights(net, seed=11)
+    net = net.cuda().eval()
+    eng = net.engine(torch.device("cuda:0"))
+    if engine_columns == 32:
+        eng.desc.rb[0].c1_w3 = 0   # no padded split copy of the 16-channel level -> the f32 engine
+    assert L.lib().gldm_r1d_tile_columns(eng._desc_ptr()) == engine_columns
+    steps, n, base, seed = 9, 37, (1 << 33) + 5, 99
+    ts, coef = make_schedule_tables("ddpm", 1000, 5e-5, 1e-3, "linear", "fixed_large", steps)
+    ts, coef = ts.cuda(), coef.cuda()
+    g = torch.Generator().manual_seed(8)
+    x_T = torch.randn((n, 1, 16), generator=g).cuda()
+    cemb = eng.cond_embed(torch.randn((n, 3, 64), generator=g).cuda())
+    noise = torch.stack([step_noise_rng(seed, base, s, n, 16, "cuda:0") for s in range(steps)]).reshape(steps, n, 1, 16)
+    want = eng.denoise(x_T, cemb, 1, timesteps=ts, sched_kind=SCHED_DDPM, coef=coef, step_noise=noise)
+    got = eng.denoise_rng(x_T, cemb, 1, ts, coef, seed, noise_base=base)
+    assert torch.isfinite(got).all() and torch.equal(got, want)
