@@ -398,6 +398,11 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   constexpr int zp = ZB + 2, nvox = 36 * zp, r3 = r * r * r;
   constexpr int hs = (nvox + 15) & ~15;   // units between the two channel halves of a plane: a multiple of the 16-unit bank row
   constexpr int kItems = 2 * nvox, kRounds = (kItems + kThreads - 1) / kThreads;
+  // Two plane sets where the brick leaves room for them and the workgroup has the CU to itself anyway (24^3: 2 x 60 KiB): a
+  // wave that is through the tap loop of block cb writes the planes of block cb + 1 into the OTHER set at once instead of
+  // waiting at a barrier for the slowest wave's last reads (phase stamps: 2-5 k cycles of such waits per block, then the
+  // stores, then a second barrier); one barrier per block is left.
+  constexpr bool kDB = R == 24 && ZB == 24;
   extern __shared__ float lds[];
   GLDM_C3_STAMP(0);
   __builtin_amdgcn_s_setprio(3);
@@ -412,7 +417,8 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   y += (size_t)b * cout * r3;
   const WStream wv(wp3, lane);
   typedef __attribute__((address_space(3))) c3_u32x4 lds_c4;
-  lds_c4 *pl = (lds_c4 *)lds;   // 16-byte units: plane * 2 hs + half * hs + voxel.  A ds_read_b128 is served in 16-lane groups
+  constexpr int kSet = kC3Split * 2 * hs;   // 16-byte units of one plane set
+  lds_c4 *pl0 = (lds_c4 *)lds;   // 16-byte units: plane * 2 hs + half * hs + voxel.  A ds_read_b128 is served in 16-lane groups
                                 // that mix columns 0-3, 12-15 of one lane row with columns 4-11 of the next (the other channel
                                 // half): with hs a multiple of 16 units the two sets fall on disjoint banks
 
@@ -457,7 +463,10 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
     for (int q = 0; q < kRounds; ++q)
       if (s_lds[q] >= 0 && s_glb[q] < 0) {
 #pragma unroll
-        for (int p3 = 0; p3 < kC3Split; ++p3) pl[p3 * 2 * hs + s_lds[q]] = z4;
+        for (int p3 = 0; p3 < kC3Split; ++p3) {
+          pl0[p3 * 2 * hs + s_lds[q]] = z4;
+          if constexpr (kDB) pl0[kSet + p3 * 2 * hs + s_lds[q]] = z4;
+        }
       }
   }
   float stg[kRounds][8];
@@ -472,11 +481,12 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   };
   // ACT: (a, s) of every input channel of this cloud, behind the planes (the launcher adds the room): read back as
   // wave-wide broadcasts of four 16-byte pairs-of-pairs per staged item
-  float *s_coef = lds + kC3Split * 2 * hs * 4;   // [cin][2]
+  float *s_coef = lds + (kDB ? 2 : 1) * kSet * 4;   // [cin][2]
   if constexpr (ACT) {
     for (int i = tid; i < 2 * cin; i += kThreads) s_coef[i] = in_coef[(size_t)b * cin * 2 + i];
   }
   auto stage_store = [&](int cb) {
+    lds_c4 *pl = pl0 + (kDB ? (cb & 1) * kSet : 0);
 #pragma unroll
     for (int q = 0; q < kRounds; ++q)
       if (s_glb[q] >= 0) {
@@ -501,14 +511,15 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   stage_load(0);
   GLDM_C3_STAMP(2);
   for (int cb = 0; cb < cblocks; ++cb) {
-    __syncthreads();   // the previous block's readers are done
+    if (!kDB || cb == 0) __syncthreads();   // the previous block's readers are done (two sets: its planes are not touched)
     if (cb < 3) GLDM_C3_STAMP(3 + 4 * cb);
     stage_store(cb);
     if (cb + 1 < cblocks) stage_load(cb + 1);
     __builtin_amdgcn_sched_barrier(0);
     if (cb < 3) GLDM_C3_STAMP(4 + 4 * cb);
-    __syncthreads();
+    __syncthreads();   // two sets: also "everyone is through block cb - 1's taps", so block cb + 1 may overwrite its set
     if (cb < 3) GLDM_C3_STAMP(5 + 4 * cb);
+    const lds_c4 *pl = pl0 + (kDB ? (cb & 1) * kSet : 0);
     c3_u32x4 a[2][GM][kC3Split];
     auto load_a = [&](int buf, int step) {   // step = pair * MG + mg
       const int p = step / MG, mg = step - p * MG;
@@ -1336,7 +1347,8 @@ GLDM_API int gldm_conv3d_k3_cl(const float *x, const float *w_packed, const floa
 template <int MT, int R, int ZB, int WAVES, bool ACT>
 int launch_conv_pl_act(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
                        const float *in_coef, int out_cl, hipStream_t s) {
-  const size_t lds_bytes = (size_t)kC3Split * 2 * ((36 * (ZB + 2) + 15) & ~15) * 16 + (ACT ? (size_t)2 * cin * sizeof(float) : 0);
+  const size_t lds_bytes = (size_t)(R == 24 && ZB == 24 ? 2 : 1) * kC3Split * 2 * ((36 * (ZB + 2) + 15) & ~15) * 16 +
+                           (ACT ? (size_t)2 * cin * sizeof(float) : 0);
   struct Tag {};
   gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_pl_kernel<MT, R, ZB, WAVES, ACT>), (int)lds_bytes);
   const int bpr = R / kBrick;
