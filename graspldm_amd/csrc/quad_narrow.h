@@ -6,7 +6,8 @@
 // Why.  On the position-major engine a narrow level is ~7 barrier-separated phases of 8 cooperating waves, each
 // with a few hundred cycles of matrix work and 4-9 k cycles of latency (cold parameter loads, a cross-wave GroupNorm
 // exchange, two barriers, the interpreter's set-up): ops 0-18 of the shipped denoiser took 123 k of a 260 k-cycle
-// step for 16 % of its FLOPs (profiles/r05_denoise_stamps_f16_start.txt).  Nothing in those levels needs more than
+// step for 16 % of its FLOPs (profiles/r05_denoise_stamps_f16_start.txt); this chain takes 72 k
+// (profiles/r05_denoise_stamps_end_of_round.txt).  Nothing in those levels needs more than
 // one wave: 4 samples x 4 positions are exactly one 16-column MFMA n-tile.
 //
 // How.  Wave q < 4 (one per SIMD) owns samples 4 q .. 4 q + 3 of the workgroup's 16 ("a quad") and walks
