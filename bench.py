@@ -94,8 +94,8 @@ def usable_cores():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clouds-per-gpu", type=int, default=256)
     ap.add_argument("--grasps", type=int, default=20)
     ap.add_argument("--points", type=int, default=1024)
