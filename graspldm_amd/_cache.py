@@ -2,7 +2,7 @@
 set-abstraction / voxel / ResNet1D weight buffers) share two rules:
 
   * key: an entry is rebuilt when any source tensor's (data_ptr, _version) changes, when the
-    device changes, or after `invalidate()`.  `_version` is bumped by in-place autograd-visible
+    device changes, when the arithmetic mode changes (numerics.f32_only), or after `invalidate()`.  `_version` is bumped by in-place autograd-visible
     writes (`load_state_dict`, `p.copy_()`, optimiser steps) but NOT by writes through `p.data`;
     code that edits weights that way calls `graspldm_amd.invalidate_caches()`.
   * publication: an entry is produced by copies / kernels on whichever HIP stream is current at
@@ -22,7 +22,11 @@ def invalidate():
 
 
 def params_key(tensors, device, *extra):
-    return (_EPOCH[0], str(device)) + tuple(extra) + tuple((t.data_ptr(), t._version) for t in tensors)
+    # the arithmetic mode is part of every key: a plan packed under numerics.f32_only() (no split copies, f32 launches) is
+    # not the plan of the default mode, and entering / leaving the switch after a module's first forward repacks instead of
+    # silently mixing the two arithmetics
+    from .numerics import split_enabled
+    return (_EPOCH[0], str(device), split_enabled()) + tuple(extra) + tuple((t.data_ptr(), t._version) for t in tensors)
 
 
 def publish(device):

@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # GLDM_LIB: another build of the same library (diagnostic builds: make -C graspldm_amd/csrc EXTRA=... OUT=...)
 LIB_PATH = os.environ.get("GLDM_LIB") or os.path.join(_PKG, "libgldm_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class GldmError(RuntimeError):
@@ -65,9 +65,9 @@ _SIGNATURES = {
     "gldm_linear_rows": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp_f16x2": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "gldm_pointwise_mlp_f16x2_add": [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _vp],
-    "gldm_pointwise_mlp2_f16x2": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "gldm_pointwise_mlp2_f16x2": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "gldm_sa_mlp_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "gldm_sa_mlp_forward_f16x2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gldm_sa_mlp_forward_f16x2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 
 

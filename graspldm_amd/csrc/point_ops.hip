@@ -785,7 +785,7 @@ int ilog2_ceil(int v) {
 
 // =========================================================== C ABI =========
 
-GLDM_API int gldm_abi_version(void) { return 9; }
+GLDM_API int gldm_abi_version(void) { return 10; }
 
 GLDM_API const char *gldm_status_string(int status) {
   switch (status) {

@@ -176,6 +176,22 @@ __device__ __forceinline__ void store_planes4(float *planes, int c0, int n, floa
   d[2 * G::kPlaneU4] = u32x2_t{l0, l1};    // next plane: kPlaneU4 entries of 16 bytes = 2 kPlaneU4 u2
 }
 
+// ---- range scale of split operands ------------------------------------------------------------------------------------
+// f16 carries 5 exponent bits: a value of 65520 or more has hi = inf (and lo = x - inf = NaN), one below 2^-14 a subnormal
+// hi.  Where the DATA sets an operand's magnitude (a gathered neighbourhood, a cloud's features, the ReLU outputs behind
+// them: BatchNorm is folded, so everything scales with the input) the tile is split as x / s with s a power of two chosen
+// from the tile's largest magnitude (measured where the staged values sit in registers, a bound  R m + B  -- R the layer's
+// largest row sum of |W|, B its largest |bias| -- for the hidden layers behind them) and s is folded back where the
+// accumulators leave the matrix pipe: exact, wave uniform, three or four VALU instructions per tile and layer.  s = 1 for
+// anything ordinary (2^-8 <= m < 2^14): every bit is then what it was without the scale.
+__device__ __forceinline__ float range_pow2(float m) {   // m >= 0 (a maximum of magnitudes or a bound on one), wave uniform
+  int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;   // floor(log2 m) of a normal m
+  if ((e >= -8 && e < 14) || e < -100 || e > 100) return 1.0f;   // ordinary; nothing there; beyond rescue (inf / nan included)
+  e = e < -40 ? -40 : e;                                     // biases divided by s stay finite
+  return __uint_as_float((unsigned)(e - 13 + 127) << 23);    // m / s in [2^13, 2^14)
+}
+__device__ __forceinline__ float pow2_inv(float s) { return __uint_as_float((254u << 23) - __float_as_uint(s)); }   // s = 2^k, |k| <= 126
+
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 
@@ -232,6 +248,14 @@ __device__ __forceinline__ float row_pair_max(float x) {
 __device__ __forceinline__ float half_max(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__device__ __forceinline__ float row16_max(float x) {  // max over the 16 lanes of a DPP row
+  x = dpp_max<0xB1>(x);   // quad_perm [1,0,3,2]
+  x = dpp_max<0x4E>(x);   // quad_perm [2,3,0,1]
+  x = fmaxf(x, dpp_mov<0x141>(x));  // row_half_mirror
+  x = fmaxf(x, dpp_mov<0x140>(x));  // row_mirror
+  return x;
 }
 
 #if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_WAVE_STAMPS)   // per-wave conv stamps cost ~1.5 k cycles per op: their own switch
@@ -3399,6 +3423,10 @@ struct SaArgs {
   float *out;
   int c, n, m, u, n_layers;
   int cin_pad[4], cout[4], w_off[4], b_off[4];
+  // split-f16 kernel: range scales on (range_pow2).  gain_r / gain_b: per layer, the largest row sum of |W| and the largest
+  // |bias| (BatchNorm folded), from the packer: |layer output| <= gain_r * max |input| + gain_b
+  int ranged;
+  float gain_r[4], gain_b[4];
 };
 
 __global__ __launch_bounds__(Geo<64>::kThreads, 2) void sa_mlp_kernel(const SaArgs a) {
@@ -3742,6 +3770,11 @@ struct PwArgs {
   // (a per-cloud bias: bs = cout, rs = 1, cs = 0; a [b, cout, n] tensor: bs = cout * n, rs = n, cs = 1)
   const float *add;
   long long add_bs, add_rs, add_cs;
+  // split-f16 kernel: range scales (range_pow2).  The staged input tile's is measured; the front layer's output planes take
+  // theirs from the bound gain0_r * max |x| + gain0_b (largest row sum of |W0|, largest |bias0|).  rng_off: float index of the
+  // eight per-wave range words in the LDS plan.  ranged == 0: operands are split as they are.
+  int ranged, rng_off;
+  float gain0_r, gain0_b;
 };
 
 __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
@@ -3885,9 +3918,11 @@ __device__ __forceinline__ void store_planes4_pw(float *planes, int c0, int n, f
 // split fragments of W0 [cin x cin0], KB0 = cin0 / 32.  A wave splits the whole tile ONCE into registers (its B planes
 // serve all of the wave's m-tiles) and walks its m-tiles in pairs; the A registers of a (m-tile, block) are refilled
 // with the next pair's fragments as soon as its MFMAs have issued.  Output: ReLU, split, into the main layer's planes.
+// bsc = 1 / (range scale of the input tile), osc = that scale / the scale of the output planes (range_pow2; 1 and 1 for
+// ordinary data)
 template <int KB0, int NT>
 __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *bias0, const float *x0, float *planes,
-                                               int wave, int lane, int mt_per_wave0, bool x0_in_planes) {
+                                               int wave, int lane, int mt_per_wave0, bool x0_in_planes, float bsc, float osc) {
   constexpr int NC = 16 * NT;
   const int col = lane & 15, kq = lane >> 4;
   u32x4 bp[KB0][NT][kSplit];
@@ -3897,7 +3932,7 @@ __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *
     for (int ni = 0; ni < NT; ++ni) {
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = x0[pw_swz<NC>(32 * kb + 8 * kq + j, 16 * ni + col)];
+      for (int j = 0; j < 8; ++j) v[j] = x0[pw_swz<NC>(32 * kb + 8 * kq + j, 16 * ni + col)] * bsc;
       split_planes8(v, bp[kb][ni]);
     }
   if (x0_in_planes) __syncthreads();   // 48-column tiles: the f32 tile lies under the planes this layer is about to write
@@ -3916,7 +3951,7 @@ __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *
     f32x4 acc[2][NT];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias0 + 16 * (mt0 + mi) + 4 * kq);
+      const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias0 + 16 * (mt0 + mi) + 4 * kq) * bsc;
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = bv;
     }
@@ -3934,8 +3969,8 @@ __device__ __forceinline__ void pw_front_split(const WStream &w0s, const float *
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni)
-        store_planes4_pw<NC>(planes, 16 * (mt0 + mi) + 4 * kq, 16 * ni + col, fmaxf(acc[mi][ni][0], 0.f),
-                             fmaxf(acc[mi][ni][1], 0.f), fmaxf(acc[mi][ni][2], 0.f), fmaxf(acc[mi][ni][3], 0.f));
+        store_planes4_pw<NC>(planes, 16 * (mt0 + mi) + 4 * kq, 16 * ni + col, fmaxf(acc[mi][ni][0], 0.f) * osc,
+                             fmaxf(acc[mi][ni][1], 0.f) * osc, fmaxf(acc[mi][ni][2], 0.f) * osc, fmaxf(acc[mi][ni][3], 0.f) * osc);
   }
 }
 
@@ -3975,31 +4010,66 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
     __syncthreads();  // the previous tile's readers are done
     GLDM_PW_STAMP(0);
     if (tid == 0) *ticket = a.dyn_first;
+    // range scale of the main layer's planes (range_pow2): the accumulators run in its units, `v = acc * s_main + bias` below
+    float s_main = 1.0f;
+    float *rng = lds + a.rng_off;   // [8]: the waves' largest staged magnitudes
+    auto range_publish = [&](float mx) {
+      mx = half_max(row_pair_max(row16_max(mx)));
+      if (lane == 0) rng[wave] = mx;
+    };
+    auto range_read = [&]() {
+      const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rng), r1 = *reinterpret_cast<const f32x4 *>(rng + 4);
+      const float mx = fmaxf(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])), fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
+      return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
+    };
     if (a.w0) {
       const float *xb0 = a.x + (size_t)b * a.cin0 * a.n + c0;
+      float mx = 0.f;
       for (int i = tid; i < a.cin0 * (NC / 4); i += 512) {
         const int row = i / (NC / 4), q = i - row * (NC / 4);
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (4 * q < 16 * ntv) v = *reinterpret_cast<const f32x4 *>(xb0 + (size_t)row * a.n + 4 * q);
         *reinterpret_cast<f32x4 *>(x0 + pw_swz<NC>(row, 4 * q)) = v;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       }
+      if (a.ranged) range_publish(mx);
       __syncthreads();
       GLDM_PW_STAMP(1);
+      float bsc = 1.0f, osc = 1.0f;
+      if (a.ranged) {
+        const float m0 = range_read(), s0 = range_pow2(m0);
+        s_main = range_pow2(a.gain0_r * m0 + a.gain0_b);
+        bsc = pow2_inv(s0);
+        osc = s0 * pow2_inv(s_main);
+      }
       const int mt_per_wave0 = a.cin >> 7;   // cin / 16 m-tiles over 8 waves
       const WStream w0s(a.w0, lane);
       switch (a.cin0 >> 5) {
-        case 1: pw_front_split<1, NT>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0, a.x0_in_planes != 0); break;
-        case 2: pw_front_split<2, NT>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0, a.x0_in_planes != 0); break;
-        default: pw_front_split<3, NT>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0, a.x0_in_planes != 0); break;
+        case 1: pw_front_split<1, NT>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0, a.x0_in_planes != 0, bsc, osc); break;
+        case 2: pw_front_split<2, NT>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0, a.x0_in_planes != 0, bsc, osc); break;
+        default: pw_front_split<3, NT>(w0s, a.bias0, x0, planes, wave, lane, mt_per_wave0, a.x0_in_planes != 0, bsc, osc); break;
       }
     } else {
       // stage + split: item = (8-channel group, column)
       const float *xb = a.x + (size_t)b * a.cin * a.n + c0;
+      float inv = 1.0f;
+      if (a.ranged) {   // a first pass over the tile for its largest magnitude (the second one then reads it from L2 / L1)
+        float mx = 0.f;
+        for (int i = tid; i < (a.cin >> 3) * NC; i += 512) {
+          const int kg = i / NC, scol = i - kg * NC, row = 8 * kg;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(scol < 16 * ntv ? xb[(size_t)(row + j) * a.n + scol] : 0.f));
+        }
+        range_publish(mx);
+        __syncthreads();
+        s_main = range_pow2(range_read());
+        inv = pow2_inv(s_main);
+      }
       for (int i = tid; i < (a.cin >> 3) * NC; i += 512) {
         const int kg = i / NC, scol = i - kg * NC, row = 8 * kg;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = scol < 16 * ntv ? xb[(size_t)(row + j) * a.n + scol] : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = (scol < 16 * ntv ? xb[(size_t)(row + j) * a.n + scol] : 0.f) * inv;
         u32x4 pl[kSplit];
         split_planes8(v, pl);
         lds_u4 *d = (lds_u4 *)planes + (((row >> 5) * kSplit) * 4 + ((row >> 3) & 3)) * NC + scol;
@@ -4082,7 +4152,7 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float v = acc[mi][ni][r] + bv[mi][r];
+            float v = __builtin_fmaf(acc[mi][ni][r], s_main, bv[mi][r]);   // s_main = 1: the plain sum, bit for bit
             if constexpr (ADD)
               v += a.add[(long long)b * a.add_bs + (long long)(16 * (mt0 + mi) + 4 * kq + r) * a.add_rs +
                          (long long)(c0 + (ni < ntv ? 16 * ni + col : col)) * a.add_cs];
@@ -4159,13 +4229,6 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
 // (in-lane over the centre's n-tiles, DPP over the 16 columns of a tile; ReLU after the max, it is monotone) and only
 // [cout][centres] leaves the CU.  LDS: region A [max(cin_pad0, cout1)][128] (the gathered tile, later layer 2's
 // output) + region B [cout0][128] (+ [cout2] for 4 layers).  Shapes outside this plan run on sa_mlp_kernel.
-__device__ __forceinline__ float row16_max(float x) {  // max over the 16 lanes of a DPP row
-  x = dpp_max<0xB1>(x);   // quad_perm [1,0,3,2]
-  x = dpp_max<0x4E>(x);   // quad_perm [2,3,0,1]
-  x = fmaxf(x, dpp_mov<0x141>(x));  // row_half_mirror
-  x = fmaxf(x, dpp_mov<0x140>(x));  // row_mirror
-  return x;
-}
 
 template <int MT, int NT>
 __device__ __forceinline__ void sa2_tiles(const Ctx &c, const SaArgs &a, int l, int mt0, int nt0, const float *src,
@@ -4369,12 +4432,14 @@ __device__ __forceinline__ Frag3 sa3_request(const Ctx &c, const SaArgs &a, int 
   return f;
 }
 // REQ: request the next layer's first fragments right behind this k-loop (in flight under the epilogue and the barrier)
+// bsc = 1 / (scale of the input planes): the accumulators run in the input's units; osc = that scale / the scale of the
+// output planes (both 1 for ordinary data: range_pow2)
 template <int NT, class FIRST, bool REQ>
 __device__ __forceinline__ Frag3 sa3_hidden(const Ctx &c, const SaArgs &a, int l, int mt, int nt0, const float *src, float *dst,
-                                            const FIRST &first) {
+                                            const FIRST &first, float bsc, float osc) {
   const int col = c.lane & 15, kq = c.lane >> 4;
   f32x4 acc[1][NT];
-  const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq);
+  const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq) * bsc;
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) acc[0][ni] = bv;
   sa3_gemm<NT, FIRST>(c, a.weights + a.w_off[l], a.cin_pad[l] >> 5, mt, nt0, src, acc, first);
@@ -4383,17 +4448,17 @@ __device__ __forceinline__ Frag3 sa3_hidden(const Ctx &c, const SaArgs &a, int l
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni)
-    store_planes4(dst, 16 * mt + 4 * kq, 16 * (nt0 + ni) + col, fmaxf(acc[0][ni][0], 0.f), fmaxf(acc[0][ni][1], 0.f),
-                  fmaxf(acc[0][ni][2], 0.f), fmaxf(acc[0][ni][3], 0.f));
+    store_planes4(dst, 16 * mt + 4 * kq, 16 * (nt0 + ni) + col, fmaxf(acc[0][ni][0], 0.f) * osc, fmaxf(acc[0][ni][1], 0.f) * osc,
+                  fmaxf(acc[0][ni][2], 0.f) * osc, fmaxf(acc[0][ni][3], 0.f) * osc);
   return nxt;
 }
 // last layer: m-tile mt over all four n-tiles, max over each centre's U / 16 tiles and 16 columns, ReLU, one value per row
 template <class FIRST>
 __device__ __forceinline__ void sa3_last(const Ctx &c, const SaArgs &a, int l, int mt, const float *src, int j0, float *outb,
-                                         const FIRST &first) {
+                                         const FIRST &first, float bsc, float osc) {
   const int col = c.lane & 15, kq = c.lane >> 4;
   f32x4 acc[1][4];
-  const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq);
+  const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq) * bsc;
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) acc[0][ni] = bv;
   sa3_gemm<4, FIRST>(c, a.weights + a.w_off[l], a.cin_pad[l] >> 5, mt, 0, src, acc, first);
@@ -4408,7 +4473,7 @@ __device__ __forceinline__ void sa3_last(const Ctx &c, const SaArgs &a, int l, i
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       if (ni % tpc) continue;  // wave uniform
-      const float v = fmaxf(row16_max(m[ni]), 0.f);
+      const float v = fmaxf(row16_max(m[ni]), 0.f) * osc;
       const int jj = ni / tpc;
       if (col == 0 && j0 + jj < a.m) outb[(size_t)(16 * mt + 4 * kq + r) * a.m + j0 + jj] = v;
     }
@@ -4421,7 +4486,8 @@ __device__ __forceinline__ void sa3_last(const Ctx &c, const SaArgs &a, int l, i
 // MFMAs per call).  LAST: max over the neighbours instead of the plane stores.
 template <int KB, int NT, bool LAST>
 __device__ __forceinline__ void sa3_layer_multi(const Ctx &c, const SaArgs &a, int l, int mt, int nt0, int sub, int per,
-                                                int src_off, int dst_off, int T, int tiles_per_cloud, int total_tiles) {
+                                                int src_off, int dst_off, int T, int tiles_per_cloud, int total_tiles,
+                                                float bsc, float osc) {
   const int col = c.lane & 15, kq = c.lane >> 4, g = kq;
   const WStream wv(a.weights + a.w_off[l], c.lane);
   u32x4 af[KB][kSplit];
@@ -4429,7 +4495,7 @@ __device__ __forceinline__ void sa3_layer_multi(const Ctx &c, const SaArgs &a, i
   for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
     for (int pl = 0; pl < kSplit; ++pl) af[kb][pl] = wv.raw_at((mt * KB + kb) * kFragBytes, pl * 1024);
-  const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq);
+  const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq) * bsc;
   const int cpt = 64 / a.u, tpc = a.u >> 4;
   for (int st = 0; st < sub; ++st) {
     const lds_u4 *pl3 = (const lds_u4 *)(c.lds + st * per + src_off) + g * 64 + 16 * nt0 + col;
@@ -4449,8 +4515,8 @@ __device__ __forceinline__ void sa3_layer_multi(const Ctx &c, const SaArgs &a, i
     if constexpr (!LAST) {
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni)
-        store_planes4(c.lds + st * per + dst_off, 16 * mt + 4 * kq, 16 * (nt0 + ni) + col, fmaxf(acc[ni][0], 0.f),
-                      fmaxf(acc[ni][1], 0.f), fmaxf(acc[ni][2], 0.f), fmaxf(acc[ni][3], 0.f));
+        store_planes4(c.lds + st * per + dst_off, 16 * mt + 4 * kq, 16 * (nt0 + ni) + col, fmaxf(acc[ni][0], 0.f) * osc,
+                      fmaxf(acc[ni][1], 0.f) * osc, fmaxf(acc[ni][2], 0.f) * osc, fmaxf(acc[ni][3], 0.f) * osc);
     } else {
       static_assert(!LAST || NT == 4, "the max runs over all four n-tiles of a tile");
       const int t = T * sub + st;
@@ -4467,7 +4533,7 @@ __device__ __forceinline__ void sa3_layer_multi(const Ctx &c, const SaArgs &a, i
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
             if (ni % tpc) continue;  // wave uniform
-            const float v = fmaxf(row16_max(m[ni]), 0.f);
+            const float v = fmaxf(row16_max(m[ni]), 0.f) * osc;
             const int jj = ni / tpc;
             if (col == 0 && j0 + jj < a.m) outb[(size_t)(16 * mt + 4 * kq + r) * a.m + j0 + jj] = v;
           }
@@ -4478,11 +4544,12 @@ __device__ __forceinline__ void sa3_layer_multi(const Ctx &c, const SaArgs &a, i
 }
 template <int NT, bool LAST>
 __device__ __forceinline__ void sa3_layer_multi_kb(const Ctx &c, const SaArgs &a, int l, int mt, int nt0, int sub, int per,
-                                                   int src_off, int dst_off, int T, int tiles_per_cloud, int total_tiles) {
+                                                   int src_off, int dst_off, int T, int tiles_per_cloud, int total_tiles,
+                                                   float bsc, float osc) {
   switch (a.cin_pad[l] >> 5) {
-    case 1: sa3_layer_multi<1, NT, LAST>(c, a, l, mt, nt0, sub, per, src_off, dst_off, T, tiles_per_cloud, total_tiles); break;
-    case 2: sa3_layer_multi<2, NT, LAST>(c, a, l, mt, nt0, sub, per, src_off, dst_off, T, tiles_per_cloud, total_tiles); break;
-    default: sa3_layer_multi<4, NT, LAST>(c, a, l, mt, nt0, sub, per, src_off, dst_off, T, tiles_per_cloud, total_tiles); break;
+    case 1: sa3_layer_multi<1, NT, LAST>(c, a, l, mt, nt0, sub, per, src_off, dst_off, T, tiles_per_cloud, total_tiles, bsc, osc); break;
+    case 2: sa3_layer_multi<2, NT, LAST>(c, a, l, mt, nt0, sub, per, src_off, dst_off, T, tiles_per_cloud, total_tiles, bsc, osc); break;
+    default: sa3_layer_multi<4, NT, LAST>(c, a, l, mt, nt0, sub, per, src_off, dst_off, T, tiles_per_cloud, total_tiles, bsc, osc); break;
   }
 }
 
@@ -4529,14 +4596,37 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
       }
     }
   };
+  // Range scale of the gathered tile(s) (range_pow2): every wave publishes the largest magnitude it holds in front of a
+  // barrier the tile needs anyway, all read the eight words behind it.  m_in / s_in: of the tile(s) about to be stored.
+  float *rng = lds + (size_t)sub * per;   // [8], behind the planes (the launcher adds the room)
+  float m_in = 0.f, s_in = 1.f;
+  auto range_publish = [&]() {
+    float mx = 0.f;
+#pragma unroll
+    for (int st = 0; st < SUBMAX; ++st)
+#pragma unroll
+      for (int i = 0; i < QUADS; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(gv[st][i][e]));
+    mx = half_max(row_pair_max(row16_max(mx)));
+    if (c.lane == 0) rng[c.wave] = mx;
+  };
+  auto range_read = [&]() {
+    const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rng), r1 = *reinterpret_cast<const f32x4 *>(rng + 4);
+    const float mx = fmaxf(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])), fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
+    m_in = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
+    s_in = range_pow2(m_in);
+  };
   auto gather_store = [&]() {
+    const float inv = pow2_inv(s_in);
 #pragma unroll
     for (int st = 0; st < SUBMAX; ++st) {
       if (st < sub) {
 #pragma unroll
         for (int i = 0; i < QUADS; ++i) {
           const int rq = qg + 8 * i;
-          if (rq < nquads) store_planes4(lds + st * per, 4 * rq, col, gv[st][i][0], gv[st][i][1], gv[st][i][2], gv[st][i][3]);
+          if (rq < nquads)
+            store_planes4(lds + st * per, 4 * rq, col, gv[st][i][0] * inv, gv[st][i][1] * inv, gv[st][i][2] * inv, gv[st][i][3] * inv);
         }
       }
     }
@@ -4544,16 +4634,16 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
   Frag3 frag;   // block-0 fragments of the wave's first m-tile of the NEXT layer to run
   // The request for the next layer's first fragments sits behind this layer's (first) k-loop, in front of its stores: in
   // flight under the epilogue and the barrier.  Straight-line code: the fragments travel by value.
-  auto hidden = [&](int l, bool a_to_b) {
+  auto hidden = [&](int l, bool a_to_b, float bsc, float osc) {
     const int mtiles = a.cout[l] >> 4;
     Ctx cl = c;
     asm volatile("" : "+v"(cl.tid), "+v"(cl.lane));
     if constexpr (SUBMAX > 1) {   // weights once per layer, the tiles stream through (sa3_layer_multi)
       const int so = a_to_b ? 0 : blocks_a * kSaBlockFloats, dof = a_to_b ? blocks_a * kSaBlockFloats : 0;
       if (mtiles >= 8) {
-        for (int p = 0; p < (mtiles >> 3); ++p) sa3_layer_multi_kb<4, false>(cl, a, l, w + 8 * p, 0, sub, per, so, dof, 0, 1, 0);
-      } else if (mtiles == 4) sa3_layer_multi_kb<2, false>(cl, a, l, w & 3, 2 * (w >> 2), sub, per, so, dof, 0, 1, 0);
-      else sa3_layer_multi_kb<1, false>(cl, a, l, w & 1, w >> 1, sub, per, so, dof, 0, 1, 0);
+        for (int p = 0; p < (mtiles >> 3); ++p) sa3_layer_multi_kb<4, false>(cl, a, l, w + 8 * p, 0, sub, per, so, dof, 0, 1, 0, bsc, osc);
+      } else if (mtiles == 4) sa3_layer_multi_kb<2, false>(cl, a, l, w & 3, 2 * (w >> 2), sub, per, so, dof, 0, 1, 0, bsc, osc);
+      else sa3_layer_multi_kb<1, false>(cl, a, l, w & 1, w >> 1, sub, per, so, dof, 0, 1, 0, bsc, osc);
       return;
     }
     const Frag3 cur = frag;
@@ -4561,31 +4651,42 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
       const float *src = lds + st * per + (a_to_b ? 0 : blocks_a * kSaBlockFloats);
       float *dst = lds + st * per + (a_to_b ? blocks_a * kSaBlockFloats : 0);
       if (st == 0) {
-        if (mtiles == 8) frag = sa3_hidden<4, Frag3, true>(cl, a, l, w, 0, src, dst, cur);
+        if (mtiles == 8) frag = sa3_hidden<4, Frag3, true>(cl, a, l, w, 0, src, dst, cur, bsc, osc);
         else if (mtiles == 16) {
-          sa3_hidden<4, Frag3, false>(cl, a, l, w, 0, src, dst, cur);
-          frag = sa3_hidden<4, NoFirst, true>(cl, a, l, w + 8, 0, src, dst, NoFirst());
-        } else if (mtiles == 4) frag = sa3_hidden<2, Frag3, true>(cl, a, l, w & 3, 2 * (w >> 2), src, dst, cur);
-        else frag = sa3_hidden<1, Frag3, true>(cl, a, l, w & 1, w >> 1, src, dst, cur);
+          sa3_hidden<4, Frag3, false>(cl, a, l, w, 0, src, dst, cur, bsc, osc);
+          frag = sa3_hidden<4, NoFirst, true>(cl, a, l, w + 8, 0, src, dst, NoFirst(), bsc, osc);
+        } else if (mtiles == 4) frag = sa3_hidden<2, Frag3, true>(cl, a, l, w & 3, 2 * (w >> 2), src, dst, cur, bsc, osc);
+        else frag = sa3_hidden<1, Frag3, true>(cl, a, l, w & 1, w >> 1, src, dst, cur, bsc, osc);
       } else if constexpr (SUBMAX > 1) {
-        if (mtiles == 8) sa3_hidden<4, NoFirst, false>(cl, a, l, w, 0, src, dst, NoFirst());
+        if (mtiles == 8) sa3_hidden<4, NoFirst, false>(cl, a, l, w, 0, src, dst, NoFirst(), bsc, osc);
         else if (mtiles == 16) {
-          sa3_hidden<4, NoFirst, false>(cl, a, l, w, 0, src, dst, NoFirst());
-          sa3_hidden<4, NoFirst, false>(cl, a, l, w + 8, 0, src, dst, NoFirst());
-        } else if (mtiles == 4) sa3_hidden<2, NoFirst, false>(cl, a, l, w & 3, 2 * (w >> 2), src, dst, NoFirst());
-        else sa3_hidden<1, NoFirst, false>(cl, a, l, w & 1, w >> 1, src, dst, NoFirst());
+          sa3_hidden<4, NoFirst, false>(cl, a, l, w, 0, src, dst, NoFirst(), bsc, osc);
+          sa3_hidden<4, NoFirst, false>(cl, a, l, w + 8, 0, src, dst, NoFirst(), bsc, osc);
+        } else if (mtiles == 4) sa3_hidden<2, NoFirst, false>(cl, a, l, w & 3, 2 * (w >> 2), src, dst, NoFirst(), bsc, osc);
+        else sa3_hidden<1, NoFirst, false>(cl, a, l, w & 1, w >> 1, src, dst, NoFirst(), bsc, osc);
       }
     }
   };
   int T = blockIdx.x;
   gather_load(T);
   frag = sa3_request(c, a, 0);
+  if (a.ranged) {
+    range_publish();
+    __syncthreads();
+    range_read();
+  }
   gather_store();
   __syncthreads();
   for (; T < supers; T += gridDim.x) {
     bool a_to_b = true;
+    // scales of this tile's planes, layer by layer: the input's is measured, a hidden layer's follows from the bound
+    // |out| <= gain_r * max |in| + gain_b (true units)
+    float bnd = m_in, s_cur = s_in;
     for (int l = 0; l + 1 < a.n_layers; ++l) {
-      hidden(l, a_to_b);
+      bnd = a.gain_r[l] * bnd + a.gain_b[l];
+      const float s_nxt = a.ranged ? range_pow2(bnd) : 1.0f;
+      hidden(l, a_to_b, pow2_inv(s_cur), s_cur * pow2_inv(s_nxt));
+      s_cur = s_nxt;
       __syncthreads();
       a_to_b = !a_to_b;
     }
@@ -4593,11 +4694,13 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
     gather_load(Tn);
     {
       const int l = a.n_layers - 1, mtiles = a.cout[l] >> 4;
+      const float bsc = pow2_inv(s_cur), osc = s_cur;
       Ctx cl = c;
       asm volatile("" : "+v"(cl.tid), "+v"(cl.lane));
       if constexpr (SUBMAX > 1) {
         const int so = a_to_b ? 0 : blocks_a * kSaBlockFloats;
-        for (int mt = w; mt < mtiles; mt += 8) sa3_layer_multi_kb<4, true>(cl, a, l, mt, 0, sub, per, so, 0, T, tiles_per_cloud, total_tiles);
+        for (int mt = w; mt < mtiles; mt += 8)
+          sa3_layer_multi_kb<4, true>(cl, a, l, mt, 0, sub, per, so, 0, T, tiles_per_cloud, total_tiles, bsc, osc);
       }
       const Frag3 cur = frag;
       for (int st = 0; st < (SUBMAX > 1 ? 0 : sub); ++st) {
@@ -4607,15 +4710,17 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
         float *outb = a.out + (size_t)b * a.cout[l] * a.m;
         const float *src = lds + st * per + (a_to_b ? 0 : blocks_a * kSaBlockFloats);
         if (st == 0) {
-          if (w < mtiles) sa3_last<Frag3>(cl, a, l, w, src, j0, outb, cur);
+          if (w < mtiles) sa3_last<Frag3>(cl, a, l, w, src, j0, outb, cur, bsc, osc);
         } else {
-          if (w < mtiles) sa3_last<NoFirst>(cl, a, l, w, src, j0, outb, NoFirst());
+          if (w < mtiles) sa3_last<NoFirst>(cl, a, l, w, src, j0, outb, NoFirst(), bsc, osc);
         }
-        for (int mt = w + 8; mt < mtiles; mt += 8) sa3_last<NoFirst>(cl, a, l, mt, src, j0, outb, NoFirst());
+        for (int mt = w + 8; mt < mtiles; mt += 8) sa3_last<NoFirst>(cl, a, l, mt, src, j0, outb, NoFirst(), bsc, osc);
       }
       frag = sa3_request(c, a, 0);   // the next tile's first layer
     }
+    if (a.ranged) range_publish();   // the next tile's gathered values have long landed
     __syncthreads();  // the last layer may have been reading region A
+    if (a.ranged) range_read();
     gather_store();
     __syncthreads();
   }
@@ -4788,7 +4893,7 @@ namespace {
 int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0, const float *w, const float *bias, int b,
                      int cin, int cout, int n, int relu, const float *head_w, const float *head_b, int hout, float *y,
                      float *z, hipStream_t stream, bool split_f16 = false, const float *add = nullptr, long long add_bs = 0,
-                     long long add_rs = 0, long long add_cs = 0) {
+                     long long add_rs = 0, long long add_cs = 0, const float *front_gain = nullptr) {
   if (add && !split_f16) return GLDM_ERR_UNSUPPORTED;
   if (!x || !w || !bias || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
   if (!y && !head_w) return GLDM_ERR_INVALID_ARG;
@@ -4809,7 +4914,7 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
     // ticket.  As many units are drawn as have room for their head slot (all but the first round when there is no head).
     // Tile width: 48 points where 32-point planes already take more than half a CU's LDS (one workgroup per CU either way)
     // and the 48-point plan fits; the front tile then goes UNDER the planes (x0_in_planes).
-    const size_t cap = (size_t)160 * 1024 - 16;
+    const size_t cap = (size_t)160 * 1024 - 64;   // ticket + range words
     const int units = cout / 32;
     auto plan = [&](int ncol, bool x0_under, size_t &planes, size_t &region, int &first) {
       planes = (size_t)cin * ncol * 2 * kSplit;   // bytes: cin x ncol x kSplit f16
@@ -4830,7 +4935,7 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
     };
     size_t planes = 0, region = 0;
     if (!plan(32, false, planes, region, dyn_first)) return GLDM_ERR_UNSUPPORTED;
-    if ((planes + region + 16) * 2 > (size_t)160 * 1024 && n >= 48) {
+    if ((planes + region + 64) * 2 > (size_t)160 * 1024 && n >= 48) {
       size_t p3 = 0, r3 = 0;
       int f3 = 0;
       if (plan(48, w0 != nullptr, p3, r3, f3)) {
@@ -4838,7 +4943,7 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
       }
     }
     ticket_off = (int)((planes + region) / sizeof(float));
-    lds_bytes = planes + region + 16;
+    lds_bytes = planes + region + 64;   // ticket (16 B) + the eight range words
   }
   if (lds_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
   struct PwTag { int site; };
@@ -4857,6 +4962,13 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   a.w0 = w0; a.bias0 = b0; a.cin0 = cin0;
   a.dyn_first = dyn_first; a.ticket_off = ticket_off; a.x0_in_planes = x0_in_planes;
   a.add = add; a.add_bs = add_bs; a.add_rs = add_rs; a.add_cs = add_cs;
+  // range scales: a lone layer measures its input tile; with a layer in front the caller's gain bounds its output
+  a.rng_off = ticket_off + 4;
+  a.ranged = split_f16 && (!w0 || front_gain);
+  if (w0 && front_gain) {
+    a.gain0_r = front_gain[0]; a.gain0_b = front_gain[1];
+    if (!(a.gain0_r >= 0.f) || !(a.gain0_b >= 0.f)) return GLDM_ERR_INVALID_ARG;
+  }
   a.tiles_per_cloud = (n + 16 * nt - 1) / (16 * nt);
   a.total_tiles = b * a.tiles_per_cloud;
   const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
@@ -4917,17 +5029,17 @@ GLDM_API int gldm_pointwise_mlp_f16x2_add(const float *x, const float *w_split, 
 
 GLDM_API int gldm_pointwise_mlp2_f16x2(const float *x, const float *w0_packed, const float *bias0, int cin0,
                                         const float *w_split, const float *bias, int b, int cin, int cout, int n,
-                                        const float *head_w_packed, const float *head_bias, int hout, float *y, float *z,
-                                        gldm_stream_t stream) {
+                                        const float *head_w_packed, const float *head_bias, int hout,
+                                        const float *front_gain, float *y, float *z, gldm_stream_t stream) {
   if (!w0_packed) return GLDM_ERR_INVALID_ARG;
   return launch_pointwise(x, w0_packed, bias0, cin0, w_split, bias, b, cin, cout, n, 1, head_w_packed, head_bias,
-                          hout, y, z, reinterpret_cast<hipStream_t>(stream), true);
+                          hout, y, z, reinterpret_cast<hipStream_t>(stream), true, nullptr, 0, 0, 0, front_gain);
 }
 
 GLDM_API int gldm_sa_mlp_forward_f16x2(const float *points, const float *centers, const float *features,
                                         const int32_t *idx, const float *weights, int b, int c, int n, int m, int u,
                                         int n_layers, const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off,
-                                        const int32_t *b_off, float *out, gldm_stream_t stream) {
+                                        const int32_t *b_off, const float *range_gain, float *out, gldm_stream_t stream) {
   if (!points || !centers || !idx || !weights || !out || !cin_pad || !cout || !w3_off || !b_off || b <= 0 || c < 0 ||
       n <= 0 || m <= 0 || u <= 0)
     return GLDM_ERR_INVALID_ARG;
@@ -4936,6 +5048,12 @@ GLDM_API int gldm_sa_mlp_forward_f16x2(const float *points, const float *centers
   SaArgs a{};
   a.points = points; a.centers = centers; a.feat = c > 0 ? features : nullptr; a.idx = idx; a.weights = weights;
   a.out = out; a.c = c; a.n = n; a.m = m; a.u = u; a.n_layers = n_layers;
+  a.ranged = range_gain != nullptr;
+  for (int l = 0; l < n_layers && range_gain; ++l) {
+    a.gain_r[l] = range_gain[2 * l];
+    a.gain_b[l] = range_gain[2 * l + 1];
+    if (!(a.gain_r[l] >= 0.f) || !(a.gain_b[l] >= 0.f)) return GLDM_ERR_INVALID_ARG;
+  }
   int blocks_a = 0, blocks_b = 0;
   for (int l = 0; l < n_layers; ++l) {
     const int kb = cin_pad[l] >> 5, mt = cout[l] >> 4;
@@ -4951,7 +5069,8 @@ GLDM_API int gldm_sa_mlp_forward_f16x2(const float *points, const float *centers
   if (cin_pad[0] < 3 + c || cin_pad[0] > 32 * kSa3Quads) return GLDM_ERR_UNSUPPORTED;
   blocks_a = blocks_a > (cin_pad[0] >> 5) ? blocks_a : (cin_pad[0] >> 5);
   const size_t tile_bytes = (size_t)(blocks_a + blocks_b) * kSaBlockFloats * sizeof(float);
-  if (tile_bytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
+  constexpr size_t kRngBytes = 64;   // the eight range words behind the planes
+  if (tile_bytes + kRngBytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
   const int cpt = 64 / u, tpc = (m + cpt - 1) / cpt, total = tpc * b;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // narrow nets (32-row inputs, every K in {32, 64, 128}): the multi-tile kernel -- the layer's weights once per
@@ -4959,7 +5078,7 @@ GLDM_API int gldm_sa_mlp_forward_f16x2(const float *points, const float *centers
   // co-resident workgroups of one tile each (the kernel fits 128 registers) measured slower: 2.40 ms.
   bool kb_ok = cin_pad[0] == 32 || cin_pad[0] == 64;   // one or two row quads per gather thread
   for (int l = 0; l < n_layers; ++l) kb_ok = kb_ok && (cin_pad[l] == 32 || cin_pad[l] == 64 || cin_pad[l] == 128);
-  int sub = kb_ok ? (int)((size_t)160 * 1024 / tile_bytes) : 1;
+  int sub = kb_ok ? (int)(((size_t)160 * 1024 - kRngBytes) / tile_bytes) : 1;
   if (sub > 4) sub = 4;
   while (sub > 1 && (total + sub - 1) / sub < 2 * cu_count()) --sub;
   if (sub > 1) {
@@ -4968,19 +5087,19 @@ GLDM_API int gldm_sa_mlp_forward_f16x2(const float *points, const float *centers
     if (cin_pad[0] == 32) {
       struct Sa3mTag { int site; };
       gldm_dev::allow_dynamic_lds<Sa3mTag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<4, 1>), 160 * 1024);
-      hipLaunchKernelGGL((sa_mlp3_kernel<4, 1>), dim3(grid), dim3(512), tile_bytes * sub, s, a, blocks_a, blocks_b, sub, tpc, total);
+      hipLaunchKernelGGL((sa_mlp3_kernel<4, 1>), dim3(grid), dim3(512), tile_bytes * sub + kRngBytes, s, a, blocks_a, blocks_b, sub, tpc, total);
     } else {
       struct Sa3m2Tag { int site; };
       gldm_dev::allow_dynamic_lds<Sa3m2Tag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<4, 2>), 160 * 1024);
-      hipLaunchKernelGGL((sa_mlp3_kernel<4, 2>), dim3(grid), dim3(512), tile_bytes * sub, s, a, blocks_a, blocks_b, sub, tpc, total);
+      hipLaunchKernelGGL((sa_mlp3_kernel<4, 2>), dim3(grid), dim3(512), tile_bytes * sub + kRngBytes, s, a, blocks_a, blocks_b, sub, tpc, total);
     }
   } else {
     struct Sa3Tag { int site; };
     gldm_dev::allow_dynamic_lds<Sa3Tag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<1, kSa3Quads>), 160 * 1024);
-    const int per_cu = tile_bytes * 2 <= 160 * 1024 ? 2 : 1;
+    const int per_cu = (tile_bytes + kRngBytes) * 2 <= 160 * 1024 ? 2 : 1;
     int grid = cu_count() * per_cu;
     if (grid > total) grid = total;
-    hipLaunchKernelGGL((sa_mlp3_kernel<1, kSa3Quads>), dim3(grid), dim3(512), tile_bytes, s, a, blocks_a, blocks_b, 1, tpc, total);
+    hipLaunchKernelGGL((sa_mlp3_kernel<1, kSa3Quads>), dim3(grid), dim3(512), tile_bytes + kRngBytes, s, a, blocks_a, blocks_b, 1, tpc, total);
   }
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }

@@ -357,6 +357,21 @@ __device__ __forceinline__ f32x4 c3_mfma3(const c3_u32x4 (&a)[kC3Split], const c
 
 constexpr int kPairs = 14;  // tap pairs per 16-channel block (the last one holds tap 26 and zeros)
 
+// Range scale of a staged brick (see csrc/resnet1d.hip, "range scale of split operands"): f16 has 5 exponent bits, the
+// grid's magnitude is the data's (voxel averages of raw features).  s = 1 while 2^-8 <= m < 2^14: every bit as without it.
+__device__ __forceinline__ float c3_range_pow2(float m) {
+  int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
+  if ((e >= -8 && e < 14) || e < -100 || e > 100) return 1.0f;
+  e = e < -40 ? -40 : e;
+  return __uint_as_float((unsigned)(e - 13 + 127) << 23);   // m / s in [2^13, 2^14)
+}
+__device__ __forceinline__ float c3_pow2_inv(float s) { return __uint_as_float((254u << 23) - __float_as_uint(s)); }
+__device__ __forceinline__ float c3_wave_max(float x) {   // x >= 0: every lane ends with the wave's maximum
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+  return x;
+}
+
 // ---- split-f16 conv with the brick PRE-SPLIT in LDS --------------------------------------------------------------------
 // Splitting a lane's 8 channels of a voxel for every (tap pair, n-tile) that touches it means ~27 splits per element
 // and wave, 36 VALU instructions per 18-36 MFMAs, with the two waves of a SIMD doing it in lock step.  Here the
@@ -403,6 +418,11 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   // waiting at a barrier for the slowest wave's last reads (phase stamps: 2-5 k cycles of such waits per block, then the
   // stores, then a second barrier); one barrier per block is left.
   constexpr bool kDB = R == 24 && ZB == 24;
+  // Range scale (raw input only: an activated one is bounded by the norm's affine).  Every 16-channel block is split as
+  // x / s_run, s_run the largest power-of-two scale any block so far has asked for (c3_range_pow2 of the block's largest
+  // staged magnitude: the waves publish theirs in front of the block's first barrier); when it grows the accumulators --
+  // bias included -- are rescaled, and the epilogue multiplies them back.  Ordinary data: s_run = 1 throughout.
+  constexpr bool kRanged = !ACT;
   extern __shared__ float lds[];
   GLDM_C3_STAMP(0);
   __builtin_amdgcn_s_setprio(3);
@@ -485,11 +505,18 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   if constexpr (ACT) {
     for (int i = tid; i < 2 * cin; i += kThreads) s_coef[i] = in_coef[(size_t)b * cin * 2 + i];
   }
+  unsigned s_run_u = 0x3f800000u;   // s_run's bits, kept on the scalar side
+  float *rng = s_coef;   // [WAVES] (raw input: no coefficients there; the launcher adds the room)
   auto stage_store = [&](int cb) {
     lds_c4 *pl = pl0 + (kDB ? (cb & 1) * kSet : 0);
 #pragma unroll
     for (int q = 0; q < kRounds; ++q)
       if (s_glb[q] >= 0) {
+        if constexpr (kRanged) {
+          const float inv_run = __uint_as_float((254u << 23) - s_run_u);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) stg[q][j] *= inv_run;
+        }
         if constexpr (ACT) {
           const int h = (tid + q * kThreads) / nvox;
           const f32x4 *cf = reinterpret_cast<const f32x4 *>(s_coef + 2 * (16 * cb + 8 * h));   // (a, s) x 8 channels
@@ -511,7 +538,33 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   stage_load(0);
   GLDM_C3_STAMP(2);
   for (int cb = 0; cb < cblocks; ++cb) {
-    if (!kDB || cb == 0) __syncthreads();   // the previous block's readers are done (two sets: its planes are not touched)
+    if constexpr (kRanged) {
+      float mx = 0.f;
+#pragma unroll
+      for (int q = 0; q < kRounds; ++q)
+        if (s_glb[q] >= 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(stg[q][j]));
+        }
+      mx = c3_wave_max(mx);
+      if (lane == 0) rng[wave] = mx;
+    }
+    if (!kDB || kRanged || cb == 0) __syncthreads();   // the previous block's readers are done (two sets: its planes are not touched)
+    if constexpr (kRanged) {
+      float mx = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < WAVES; ++w8) mx = fmaxf(mx, rng[w8]);
+      const unsigned need = __builtin_amdgcn_readfirstlane(__float_as_uint(c3_range_pow2(mx)));
+      const unsigned s_new = (cb == 0 || need > s_run_u) ? need : s_run_u;   // positive floats order like their bits
+      if (s_new != s_run_u) {   // wave uniform, never taken on ordinary data
+        const float f = __uint_as_float(s_run_u) * c3_pow2_inv(__uint_as_float(s_new));
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] *= f;
+        s_run_u = s_new;
+      }
+    }
     if (cb < 3) GLDM_C3_STAMP(3 + 4 * cb);
     stage_store(cb);
     if (cb + 1 < cblocks) stage_load(cb + 1);
@@ -579,6 +632,15 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
   // ---- epilogue: per-channel partial statistics of this brick, then the stores
   __syncthreads();
   GLDM_C3_STAMP(20);
+  if constexpr (kRanged) {
+    if (s_run_u != 0x3f800000u) {
+      const float s_run = __uint_as_float(s_run_u);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] *= s_run;
+    }
+  }
   float *s_part = lds;  // [WAVES][MT * 16][2]
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
@@ -665,7 +727,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv3d_k3_fewch_sp_kernel(const
   const int b = blockIdx.y;
   x += (size_t)b * CIN * r3;
   y += (size_t)b * cout * r3;
-  // ---- the haloed brick, f32, zero outside the grid
+  // ---- the haloed brick, f32, zero outside the grid; its largest magnitude for the range scale (c3_range_pow2: the
+  // grid holds voxel averages of raw coordinates / features)
+  float mx = 0.f;
   for (int i = tid; i < CIN * nvox; i += kThreads) {
     const int ci = i / nvox, v = i - ci * nvox;
     const int ixy = v / zp, izp = v - ixy * zp;
@@ -674,7 +738,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv3d_k3_fewch_sp_kernel(const
     if ((unsigned)gx < (unsigned)r && (unsigned)gy < (unsigned)r && (unsigned)gz < (unsigned)r)
       val = x[(size_t)ci * r3 + (gx * r + gy) * r + gz];
     lds[ci * cs + v] = val;
+    mx = fmaxf(mx, fabsf(val));
   }
+  float *rng = lds + CIN * cs;   // [WAVES], behind the brick (the launcher adds the room)
+  mx = c3_wave_max(mx);
+  if (lane == 0) rng[wave] = mx;
   int vb[NTW], gvox[NTW];
 #pragma unroll
   for (int ni = 0; ni < NTW; ++ni) {
@@ -683,16 +751,24 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv3d_k3_fewch_sp_kernel(const
     vb[ni] = (ix * 6 + iy) * zp + iz;
     gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + iz;
   }
-  f32x4 acc[MT][NTW];
-#pragma unroll
-  for (int mi = 0; mi < MT; ++mi) {
-    const f32x4 bvv = *reinterpret_cast<const f32x4 *>(bias + 16 * mi + 4 * g);
-#pragma unroll
-    for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = bvv;
-  }
   const WStream wv(wp3, lane);
   const lds_f *l3 = (const lds_f *)lds;
   __syncthreads();
+  float s_in;
+  {
+    float m8 = 0.f;
+#pragma unroll
+    for (int w8 = 0; w8 < WAVES; ++w8) m8 = fmaxf(m8, rng[w8]);
+    s_in = c3_range_pow2(__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(m8))));
+  }
+  const float inv_in = c3_pow2_inv(s_in);
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const f32x4 bvv = *reinterpret_cast<const f32x4 *>(bias + 16 * mi + 4 * g) * inv_in;
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = bvv;
+  }
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     c3_u32x4 a[MT][kC3Split];
@@ -719,10 +795,18 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv3d_k3_fewch_sp_kernel(const
         for (int j = 0; j < 8; ++j) v[(ni + 1) & 1][j] = l3[vb[ni + 1] + off[j]];
       }
       c3_u32x4 b3[kC3Split];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[ni & 1][j] *= inv_in;
       c3_split(v[ni & 1], b3);
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = c3_mfma3(a[mi], b3, acc[mi][ni]);
     }
+  }
+  if (s_in != 1.0f) {   // wave uniform
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] *= s_in;
   }
   // ---- epilogue: per-channel partial statistics of this brick, then the stores (as in conv3d_k3_pl_kernel)
   __syncthreads();
@@ -1348,7 +1432,7 @@ template <int MT, int R, int ZB, int WAVES, bool ACT>
 int launch_conv_pl_act(const float *x, const float *wp3, const float *bias, int b, int cin, int cout, float *y, float *partial,
                        const float *in_coef, int out_cl, hipStream_t s) {
   const size_t lds_bytes = (size_t)(R == 24 && ZB == 24 ? 2 : 1) * kC3Split * 2 * ((36 * (ZB + 2) + 15) & ~15) * 16 +
-                           (ACT ? (size_t)2 * cin * sizeof(float) : 0);
+                           (ACT ? (size_t)2 * cin * sizeof(float) : 64 /* the waves' range words */);
   struct Tag {};
   gldm_dev::allow_dynamic_lds<Tag>(reinterpret_cast<const void *>(&conv3d_k3_pl_kernel<MT, R, ZB, WAVES, ACT>), (int)lds_bytes);
   const int bpr = R / kBrick;
@@ -1373,7 +1457,7 @@ static int conv3d_k3_f16x2_impl(const float *x, const float *in_coef, const floa
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (cin == 3 && cout == 48 && r == 24) {   // the first voxel conv: K = 81 packed into three k-blocks
     constexpr int kZp = 26, kNvox = 36 * kZp;
-    const size_t lds_bytes = (size_t)3 * (kNvox + ((kNvox & 31) == 0 ? 8 : 0)) * sizeof(float);
+    const size_t lds_bytes = (size_t)3 * (kNvox + ((kNvox & 31) == 0 ? 8 : 0)) * sizeof(float) + 64;   // + the waves' range words
     hipLaunchKernelGGL((conv3d_k3_fewch_sp_kernel<3, 24, 3, 8>), dim3(36, b), dim3(512), lds_bytes, s, x, w_split, bias, y, partial);
     return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
   }

@@ -6,7 +6,18 @@ any-shape f32-MFMA kernel (gldm_pointwise_any); since round 4 nothing here reach
 longer sets MIOPEN_FIND_MODE.  Voxel convs have no library path either (csrc/voxel_conv.hip, with a direct VALU kernel
 for shapes without an MFMA instantiation).  Never a CPU path: CPU tensors are rejected like everywhere else in this package.
 """
+import ctypes
+
 import torch
+
+
+def range_gain(w2d, bias):
+    """(largest row sum of |W|, largest |bias|) of a folded layer as a host float[2]: |W x + b| <= gain[0] max|x| + gain[1].
+    The split-f16 launches scale a hidden layer's planes into the f16 range from this bound (include/gldm.h, ABI 10)."""
+    w = w2d.detach().double().cpu()
+    r = float(w.abs().sum(dim=1).max()) if w.numel() else 0.0
+    b = float(bias.detach().double().abs().max()) if bias is not None and bias.numel() else 0.0
+    return (ctypes.c_float * 2)(r, b)
 
 
 def _need_cuda(x, name="input"):
@@ -81,9 +92,10 @@ def fused_mlp2_supported(x, cin0, cin, cout):
 def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True, front=None, split=False):
     """One fused launch: y = act(W x + b) over [B, Cin, N] (hand-written MFMA GEMM, csrc/resnet1d.hip:
     pointwise_mlp_kernel / pointwise_mlp_sp_kernel) and optionally z = Wh y + bh on the accumulators.
-    head = (packed Wh, bh, hout).  front = (packed W0, b0, cin): a ReLU layer x -> relu(W0 x + b0) in front, its output
-    kept in LDS only.  split=True: `w_packed` (and the front layer's W0) hold split-f16 fragments (the GEMMs run on the
-    f16 matrix pipe with three partial products per f32 product).
+    head = (packed Wh, bh, hout).  front = (packed W0, b0, cin[, gain]): a ReLU layer x -> relu(W0 x + b0) in front, its
+    output kept in LDS only; gain = range_gain(W0, b0) lets the split launch scale that layer's planes into the f16 range.
+    split=True: `w_packed` (and the front layer's W0) hold split-f16 fragments (the GEMMs run on the f16 matrix pipe with
+    three partial products per f32 product).
 
     Numerics depend on the path a shape takes: the split launch (hi + lo f16 operands, three products: ~2e-7 of sum|a b|
     per output, measured 1.7e-6 on a denoiser forward) and the f32-MFMA launch (exact f32 fma chain in k order) differ in
@@ -98,9 +110,14 @@ def pointwise_mlp(x, w_packed, bias, cout, relu, head=None, keep_y=True, front=N
         if front is not None:
             if not relu:
                 raise ValueError("the two-layer launch applies ReLU after both layers")
-            L.call("gldm_pointwise_mlp2_f16x2" if split else "gldm_pointwise_mlp2", L.ptr(x), L.ptr(front[0]),
-                   L.ptr(front[1]), cin, L.ptr(w_packed), L.ptr(bias), b, front[2], cout, n, *hp, L.ptr(y), L.ptr(z),
-                   L.current_stream(x.device))
+            if split:
+                gain = front[3] if len(front) > 3 else None
+                L.call("gldm_pointwise_mlp2_f16x2", L.ptr(x), L.ptr(front[0]), L.ptr(front[1]), cin, L.ptr(w_packed),
+                       L.ptr(bias), b, front[2], cout, n, *hp, ctypes.cast(gain, ctypes.c_void_p) if gain is not None else None,
+                       L.ptr(y), L.ptr(z), L.current_stream(x.device))
+            else:
+                L.call("gldm_pointwise_mlp2", L.ptr(x), L.ptr(front[0]), L.ptr(front[1]), cin, L.ptr(w_packed), L.ptr(bias),
+                       b, front[2], cout, n, *hp, L.ptr(y), L.ptr(z), L.current_stream(x.device))
         else:
             L.call("gldm_pointwise_mlp_f16x2" if split else "gldm_pointwise_mlp", L.ptr(x), L.ptr(w_packed), L.ptr(bias),
                    b, cin, cout, n, int(relu), *hp, L.ptr(y), L.ptr(z), L.current_stream(x.device))
@@ -127,23 +144,31 @@ def folded_conv_bn(conv, bn, device):
     key = params_key(src, device)
     hit = conv.__dict__.get("_gldm_folded")  # lives and dies with the module
     if hit is None or hit[0] != key:
-        from .r1d_pack import mfma_a_fragments, mfma_a_fragments_f16x2
+        from .r1d_pack import SplitRangeError, mfma_a_fragments, mfma_a_fragments_f16x2
         s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
         w = (conv.weight.reshape(conv.weight.shape[0], -1) * s.view(-1, 1)).contiguous()
         cb = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
         b = ((cb - bn.running_mean) * s + bn.bias).contiguous()
         wp = ws = None
-        if w.shape[1] % 32 == 0 and w.shape[0] % 256 == 0:
-            wp = mfma_a_fragments(w.detach().float().cpu()).to(device)
-            # split fragments: main layers of the split launch (cin % 128 == 0) and its narrow front layers (cin <= 128)
-            if split_supported(w.shape[1]) or w.shape[1] <= 128:
-                ws = mfma_a_fragments_f16x2(w.detach().float().cpu()).to(device)
-        elif w.shape[0] % 32 == 0 and w.shape[0] >= 64 and split_supported(w.shape[1]):
-            ws = mfma_a_fragments_f16x2(w.detach().float().cpu()).to(device)   # 64 .. 224 output rows: split launch only
-        hit = (key, w, b, wp, ws)
+        try:   # a folded weight beyond the f16 range (|w| >= 65504: a huge BatchNorm gain) keeps the f32-pipe kernels
+            if w.shape[1] % 32 == 0 and w.shape[0] % 256 == 0:
+                wp = mfma_a_fragments(w.detach().float().cpu()).to(device)
+                # split fragments: main layers of the split launch (cin % 128 == 0) and its narrow front layers (cin <= 128)
+                if split_supported(w.shape[1]) or w.shape[1] <= 128:
+                    ws = mfma_a_fragments_f16x2(w.detach().float().cpu()).to(device)
+            elif w.shape[0] % 32 == 0 and w.shape[0] >= 64 and split_supported(w.shape[1]):
+                ws = mfma_a_fragments_f16x2(w.detach().float().cpu()).to(device)   # 64 .. 224 output rows: split launch only
+        except SplitRangeError:
+            ws = None
+        hit = (key, w, b, wp, ws, range_gain(w, b))
         conv.__dict__["_gldm_folded"] = hit
         publish(device)
     return hit[1], hit[2], hit[3], hit[4]
+
+
+def folded_range_gain(conv):
+    """range_gain of the layer folded_conv_bn packed last (same weight version)."""
+    return conv.__dict__["_gldm_folded"][5]
 
 
 def pointwise_conv_bn_relu(x, conv, bn):
@@ -190,12 +215,15 @@ def concat_conv_bn_relu(xa, xb, conv, bn):
     key = (params_key(src, xa.device), ca, broadcast)
     hit = conv.__dict__.get("_gldm_concat")
     if hit is None or hit[0] != key:
-        from .r1d_pack import mfma_a_fragments_f16x2
+        from .r1d_pack import SplitRangeError, mfma_a_fragments_f16x2
         w, b = folded_conv_bn(conv, bn, xa.device)[:2]
         wa, wb = w[:, :ca].contiguous(), w[:, ca:].contiguous()
         wide = wb if broadcast else wa
-        hit = (key, mfma_a_fragments_f16x2(wide.detach().float().cpu()).to(xa.device), wa if broadcast else wb, b,
-               torch.zeros_like(b))
+        try:
+            w3 = mfma_a_fragments_f16x2(wide.detach().float().cpu()).to(xa.device)
+        except SplitRangeError:
+            return None   # a weight beyond the f16 range: the caller concatenates and takes the plain (f32) path
+        hit = (key, w3, wa if broadcast else wb, b, torch.zeros_like(b))
         conv.__dict__["_gldm_concat"] = hit
         publish(xa.device)
     _, w3, w_other, b, zero_b = hit

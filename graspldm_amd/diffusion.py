@@ -130,7 +130,8 @@ class GaussianDiffusion1D(nn.Module):
         noise_source="kernel" (DDPM, return_all=False): the per-step normals are drawn INSIDE the launch from a counter-based
         generator (gldm_denoise_rng) instead of from a [steps, B, 1, D] tensor -- the same distribution, not torch's
         stream; `noise_seed` defaults to one draw of torch's CPU generator (so torch.manual_seed still fixes a run) and
-        `noise_base` is the global index of this batch's first latent (sharded jobs)."""
+        `noise_base` is the global index of this batch's first latent: ranks of a sharded job that share a seed MUST pass
+        their own (distributed.shard_noise_base), or they add identical step noise to different latents."""
         device = torch.device(device if device is not None else z_cond.device)
         if device.type != "cuda":
             raise RuntimeError("sampling runs on the GPU only (graspldm_amd has no CPU path)")
@@ -142,6 +143,12 @@ class GaussianDiffusion1D(nn.Module):
         if noise_source not in ("tensor", "kernel"):
             raise ValueError(f"noise_source must be 'tensor' or 'kernel', not {noise_source!r}")
         in_kernel = noise_source == "kernel" and kind == SCHED_DDPM and step_noise is None and not return_all
+        if noise_source == "kernel" and not in_kernel and kind == SCHED_DDPM:
+            # (DDIM adds no step noise: nothing to ignore there)
+            import warnings
+            warnings.warn("noise_source='kernel' is not honoured with return_all=True or an explicit step_noise: the per-step "
+                          "normals come from torch's generator / the given tensor, so this run does NOT reproduce the "
+                          "in-kernel stream of the same seed", RuntimeWarning, stacklevel=2)
         if in_kernel and noise_seed is None:
             noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         if kind == SCHED_DDPM and step_noise is None and not in_kernel:

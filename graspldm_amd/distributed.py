@@ -30,6 +30,14 @@ def shard_step_noise(step_noise, num_grasps, lo, hi):
     return step_noise[:, lo * num_grasps:hi * num_grasps].contiguous()
 
 
+def shard_noise_base(num_grasps, lo):
+    """`noise_base` of a rank whose first cloud is `lo` (shard_bounds): the global index of its first latent.  With
+    noise_source="kernel" the step noise of latent i is a function of (seed, noise_base + local index, step) only, so ranks
+    that pass this and share a seed draw exactly the single-process run's noise (int64 on the device side: 12,800 latents
+    per rank x 8 ranks x any batch count stays far below 2^63)."""
+    return int(lo) * int(num_grasps)
+
+
 def gather_results(local_rows, per_rank_rows, total_rows, group=None):
     """local_rows [n_r, 7] (n_r <= per_rank_rows) -> [total_rows, 7] on every rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1

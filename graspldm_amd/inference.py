@@ -55,10 +55,21 @@ class _InferenceBase:
             eng = getattr(m, "_engine", None)
             if eng is not None:
                 eng.check()
+        if not bool(torch.isfinite(pc).all()):
+            # (ReLU as max(x, 0) drops a NaN where torch.relu keeps it: a NaN point would come out as plausible-looking grasps)
+            from ._lib import GldmError
+            raise GldmError("the input point cloud holds non-finite coordinates")
         metas = {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in metas.items()}
         # mean [B,6] and std [1,6] (normalize_input and the dataset both build them so) broadcast independently
         mean, std = metas["grasp_mean"], metas["grasp_std"]
         H, un, conf = pose_epilogue(tmrp, cls_logit, mean, std, num_grasps)
+        # ... and so does a pose that is not a number: the GEMMs multiply f16 pieces -- operands whose size the
+        # data sets carry range scales, and anything that still leaves the range must not reach the caller as a grasp
+        if not bool(torch.isfinite(H).all()) or (conf is not None and not bool(torch.isfinite(conf).all())):
+            from ._lib import GldmError
+            bad = int((~torch.isfinite(H.view(-1, 16)).all(dim=1)).sum())
+            raise GldmError(f"{bad} of {H.numel() // 16} generated poses are not finite (input cloud / metas out of range, "
+                            "or weights whose activations leave the f16 range: rerun under graspldm_amd.numerics.f32_only())")
         steps_H = []
         if all_steps:
             if num_pcs > 1:  # tools/inference.py:631-634

@@ -12,9 +12,10 @@ Results therefore depend, in the last bits, on the PATH a shape takes (n % 16, c
         model = build_fpc_ldm(...)      # engines pack their descriptors without the split copies
         out = model.generate_grasps(...)
 
-The switch is read where weights are packed / a launch is chosen: set it BEFORE the first forward of a module (packed plans
-are cached per weight version).  Voxel convs without an f32 instantiation and the shipped encoder's first 3 -> 48 conv keep
-their only kernel."""
+The switch is read where weights are packed / a launch is chosen; it is part of every derived-weight cache key
+(_cache.params_key), so entering or leaving it repacks the plans instead of mixing the two arithmetics.  Voxel convs
+without an f32 instantiation keep their only kernel; the shipped encoder's first 3 -> 48 conv runs its f32 form (K padded to
+27 x 16) under the switch since round 6."""
 import contextlib
 
 _F32_ONLY = False

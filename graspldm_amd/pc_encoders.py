@@ -68,7 +68,7 @@ class PVCNNEncoder(nn.Module):
                     if ws is not None and ws0 is not None and dense.split_supported(cin, conv0.weight.shape[1]):
                         # both GEMMs on the f16 matrix pipe (split-f32 operands)
                         return dense.pointwise_mlp(feats, ws, bf, cout, True, head=self._packed_head(w, b), keep_y=False,
-                                                   front=(ws0, b0, cin), split=True)[1]
+                                                   front=(ws0, b0, cin, dense.folded_range_gain(conv0)), split=True)[1]
                     return dense.pointwise_mlp(feats, wp, bf, cout, True, head=self._packed_head(w, b), keep_y=False,
                                                front=(wp0, b0, cin))[1]
                 feats = prev(feats).contiguous()

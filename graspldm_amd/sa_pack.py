@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .r1d_pack import _Buf, mfma_a_fragments, mfma_a_fragments_f16x2
+from .r1d_pack import SplitRangeError, _Buf, mfma_a_fragments, mfma_a_fragments_f16x2
 
 _OK_MTILES = (1, 2, 4, 8, 12, 16)
 
@@ -83,9 +83,11 @@ class SaMlpPlan:
             layers = self._layers.layers
             n = len(layers) // 3
             buf = _Buf()
-            cin_pad, cout, w_off, b_off = [], [], [], []
+            cin_pad, cout, w_off, b_off, gain = [], [], [], [], []
             for i in range(n):
                 w, b = fold_conv_bn(layers[3 * i], layers[3 * i + 1])
+                # |layer output| <= gain_r max|input| + gain_b: the kernel scales the hidden layers' planes from this bound
+                gain += [float(w.double().abs().sum(dim=1).max()), float(b.double().abs().max())]
                 kpad = (w.shape[1] + 31) // 32 * 32
                 rows = w.shape[0] if i == n - 1 else (w.shape[0] + 31) // 32 * 32   # hidden widths: whole plane blocks
                 wp = torch.zeros(rows, kpad)
@@ -97,7 +99,8 @@ class SaMlpPlan:
                 w_off.append(buf.add(mfma_a_fragments_f16x2(wp)))
                 b_off.append(buf.add(bp))
             arr = ctypes.c_int32 * n
-            self._split = (buf.tensor().to(self._device), arr(*cin_pad), arr(*cout), arr(*w_off), arr(*b_off))
+            self._split = (buf.tensor().to(self._device), arr(*cin_pad), arr(*cout), arr(*w_off), arr(*b_off),
+                           (ctypes.c_float * (2 * n))(*gain))
         return self._split
 
     def run(self, points, centers, features, idx):
@@ -108,13 +111,19 @@ class SaMlpPlan:
         lay = self._layers.layers
         cins = [lay[3 * i].weight.shape[1] for i in range(self.n_layers)]
         couts = [lay[3 * i].weight.shape[0] for i in range(self.n_layers)]
+        split = None
         if split_plan_ok(cins, couts, u):
-            w3, cin_pad, cout, w_off, b_off = self._split_plan()
+            try:
+                split = self._split_plan()
+            except SplitRangeError:   # a folded weight beyond the f16 range: the f32-MFMA plan below
+                split = None
+        if split is not None:
+            w3, cin_pad, cout, w_off, b_off, gain = split
             with torch.cuda.device(points.device):
                 L.call("gldm_sa_mlp_forward_f16x2", L.ptr(points), L.ptr(centers), L.ptr(features), L.ptr(idx), L.ptr(w3),
                        b, c, n, m, u, self.n_layers, ctypes.cast(cin_pad, ctypes.c_void_p), ctypes.cast(cout, ctypes.c_void_p),
-                       ctypes.cast(w_off, ctypes.c_void_p), ctypes.cast(b_off, ctypes.c_void_p), L.ptr(out),
-                       L.current_stream(points.device))
+                       ctypes.cast(w_off, ctypes.c_void_p), ctypes.cast(b_off, ctypes.c_void_p),
+                       ctypes.cast(gain, ctypes.c_void_p), L.ptr(out), L.current_stream(points.device))
             return out
         with torch.cuda.device(points.device):
             L.call("gldm_sa_mlp_forward", L.ptr(points), L.ptr(centers), L.ptr(features), L.ptr(idx), L.ptr(self.weights),

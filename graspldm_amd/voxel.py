@@ -32,7 +32,8 @@ def split_conv_supported(cin, cout, r):
     """Shapes gldm_conv3d_k3_f16x2 is built for (SPLIT_SHAPES with cin % 16 == 0, and the shipped encoder's first conv
     3 -> 48 @ 24^3 with K = 81 packed into three 32-deep blocks)."""
     if (cin, cout, r) == (3, 48, 24):
-        return True   # its f32 form pads K to 27 x 16: kept on the split kernel whatever numerics.f32_only() says
+        from .numerics import split_enabled
+        return split_enabled()   # under f32_only() its f32 form runs (K padded to 27 x 16: slower, exact f32 products)
     if cin % 16 or (cout, r) not in SPLIT_SHAPES:
         return False
     from .numerics import split_enabled
@@ -69,13 +70,19 @@ class VoxelBranchPlan:
     """Packed conv weights of one PVConv on the device (f32 fragments, or split-f16 ones where the conv has that kernel)."""
 
     def __init__(self, convs, device, r=None):
+        from .r1d_pack import SplitRangeError
         self.split = [r is not None and split_conv_supported(c.in_channels, c.out_channels, r) for c in convs]
         # shapes without an MFMA instantiation run the direct kernel on the raw nn.Conv3d weight
         self.generic = [r is not None and not conv_supported(c.out_channels, r) for c in convs]
-        self.w = [(c.weight.detach().float().contiguous() if gen else
-                   ((pack_conv3d_fewch_f16x2(c.weight) if c.in_channels < 16 else pack_conv3d_f16x2(c.weight)) if sp
-                    else pack_conv3d(c.weight))).to(device)
-                  for c, sp, gen in zip(convs, self.split, self.generic)]
+        self.w = []
+        for i, c in enumerate(convs):
+            if self.split[i]:
+                try:
+                    self.w.append((pack_conv3d_fewch_f16x2(c.weight) if c.in_channels < 16 else pack_conv3d_f16x2(c.weight)).to(device))
+                    continue
+                except SplitRangeError:   # a weight beyond the f16 range: this conv keeps an f32 kernel
+                    self.split[i] = False
+            self.w.append((c.weight.detach().float().contiguous() if self.generic[i] else pack_conv3d(c.weight)).to(device))
         self.key = None  # set by the owner (PVConv.forward) from _cache.params_key
 
 

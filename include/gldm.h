@@ -321,11 +321,17 @@ int gldm_sa_mlp_forward(const float *points /*[b,3,n]*/, const float *centers /*
  * gathered rows and hidden-layer outputs live in LDS as pre-split planes.  `weights` holds, per layer, the split-f16 A
  * fragments of [cout x cin_pad] at w3_off[l] (graspldm_amd/r1d_pack.py: mfma_a_fragments_f16x2; cin_pad a multiple of 32,
  * zero beyond the real rows) and the folded bias at b_off[l].  Shapes: cin_pad[0] <= 288, hidden widths multiples of 32
- * (32 / 64 / 128 / 256), U in {16, 32, 64}; GLDM_ERR_UNSUPPORTED otherwise (callers then use gldm_sa_mlp_forward). */
+ * (32 / 64 / 128 / 256), U in {16, 32, 64}; GLDM_ERR_UNSUPPORTED otherwise (callers then use gldm_sa_mlp_forward).
+ * `range_gain` (HOST memory, [n_layers][2] = per layer the largest row sum of |W| and the largest |bias|, BatchNorm folded;
+ * ABI 10): f16 has 5 exponent bits, so every 64-column tile is split as x / s with s a power of two taken from the tile's
+ * largest gathered magnitude, the hidden layers' planes with one taken from the bound gain_r * max|in| + gain_b, and s is
+ * folded back on the accumulators (exact; s = 1, i.e. every bit as without it, while 2^-8 <= magnitude < 2^14).  NULL: no
+ * scales -- the caller vouches for |values| < 65504 everywhere. */
 int gldm_sa_mlp_forward_f16x2(const float *points /*[b,3,n]*/, const float *centers /*[b,3,m]*/,
                                const float *features /*[b,c,n] or NULL*/, const int32_t *idx /*[b,m,u]*/,
                                const float *weights, int b, int c, int n, int m, int u, int n_layers,
                                const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off, const int32_t *b_off,
+                               const float *range_gain /*host [n_layers][2] or NULL*/,
                                float *out /*[b,cout_last,m]*/, gldm_stream_t stream);
 
 /* ref: grasp_ldm/models/modules/ext/pvcnn/modules/shared_mlp.py:6-35 (Conv1d k = 1 + eval BatchNorm folded + ReLU),
@@ -388,9 +394,15 @@ int gldm_pointwise_mlp_f16x2_add(const float *x /*[b,cin,n]*/, const float *w_sp
                                   const float *add, long long add_cloud_stride, long long add_row_stride,
                                   long long add_col_stride, int b, int cin, int cout, int n, int relu,
                                   float *y /*[b,cout,n]*/, gldm_stream_t stream);
+/* Range of the split operands (ABI 10): the one-layer launches above split every input tile as x / s, s a power of two from
+ * the tile's largest magnitude (1 while 2^-8 <= magnitude < 2^14: then every bit is as without it), and fold s back on the
+ * accumulators.  The two-layer launch below does the same for its input tile and scales the front layer's output planes by
+ * the bound front_gain[0] * max|x| + front_gain[1] (HOST memory: largest row sum of |W0|, largest |bias0|); front_gain ==
+ * NULL: no scales in that launch -- the caller vouches for |values| < 65504. */
 int gldm_pointwise_mlp2_f16x2(const float *x /*[b,cin0,n]*/, const float *w0_split, const float *bias0, int cin0,
                                const float *w_split, const float *bias /*[cout]*/, int b, int cin, int cout, int n,
                                const float *head_w_packed, const float *head_bias, int hout,
+                               const float *front_gain /*host [2] or NULL*/,
                                float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
 
 /* ---------------------------------------------------------- voxel branch of PVConv */

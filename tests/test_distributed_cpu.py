@@ -165,6 +165,45 @@ def test_bench_spawns_its_own_ranks_dry_run():
     assert rec["n_gpus"] == 2 and rec["dry_run"] and rec["gather_ok"] and rec["rows_gathered"] == 2 * 3 * 5
 
 
+def test_bench_eight_ranks_dry_run():
+    """The shape of the driver's 8-GPU run (BASELINE.json configs[3]: 8 ranks, one shard each) on gloo: eight ranks
+    rendezvous, every one contributes its rows, one JSON line comes out.  No node with 8 GPUs has been available to any
+    round: this is what makes sure the first real run cannot fail on rank bookkeeping."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2",
+                        "--clouds-per-gpu", "2", "--grasps", "3"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["dry_run"] and rec["gather_ok"] and rec["rows_gathered"] == 8 * 2 * 3
+
+
+def test_noise_base_of_the_last_rank_of_eight():
+    """BASELINE.json configs[4] on 8 GPUs: 64 clouds x 200 grasps = 12,800 latents per rank.  The in-kernel step noise of
+    latent i is a function of (seed, noise_base + local index, step): rank 7's base is its first GLOBAL latent, the bases
+    tile [0, 102400) without gap or overlap, and they match the rows shard_noise hands the same rank."""
+    from graspldm_amd.distributed import shard_noise, shard_noise_base
+    B, G, W = 8 * 64, 200, 8
+    spans = [shard_bounds(B, W, r) for r in range(W)]
+    bases = [shard_noise_base(G, lo) for lo, _, _ in spans]
+    assert bases[7] == 7 * 12800 and bases[0] == 0
+    assert all(b + (hi - lo) * G == nb for b, (lo, hi, _), nb in zip(bases, spans, bases[1:] + [B * G]))
+    x_T = torch.arange(B * G, dtype=torch.float32).view(-1, 1, 1)
+    for (lo, hi, _), base in zip(spans, bases):
+        rows = shard_noise(x_T, G, lo, hi)
+        assert rows.shape[0] == 12800 and int(rows[0, 0, 0]) == base
+    # ragged: 13 clouds over 8 ranks, the last ranks own one or no cloud; bases still tile the latents
+    spans = [shard_bounds(13, 8, r) for r in range(8)]
+    assert [shard_noise_base(5, lo) for lo, _, _ in spans] == [0, 10, 20, 30, 40, 50, 60, 65]
+    assert isinstance(shard_noise_base(200, 2 ** 40), int) and shard_noise_base(200, 2 ** 40) == 200 * 2 ** 40
+
+
 def test_bench_workload_label_follows_arguments():
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

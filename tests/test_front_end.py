@@ -74,6 +74,23 @@ def test_farthest_points_random_clouds_vs_oracle():
 
 
 @gpu
+@pytest.mark.parametrize("n", [64, 100, 512, 1000, 1024, 1400])
+def test_farthest_points_maximal_distance_ties_vs_oracle(n):
+    """np.argmax's first-index rule on exact maximal-distance ties (duplicated and symmetric points), on the one-wave
+    kernel (n <= 1024) and the workgroup kernel (n = 1400): pointcloud_helpers.py:160-217."""
+    from oracle import front_end as F
+    from graspldm_amd.pointcloud import farthest_point_indices
+    cube = np.array([[x, y, z] for x in (-1., 1.) for y in (-1., 1.) for z in (-1., 1.)], np.float32)
+    octa = np.array([[2., 0, 0], [-2, 0, 0], [0, 2, 0], [0, -2, 0], [0, 0, 2], [0, 0, -2]], np.float32)
+    dup = np.array([[0., 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [.5, .5, 1]], np.float32)
+    for base in (dup, np.concatenate([cube, octa])):
+        pc = np.tile(base, (-(-n // len(base)), 1))[:n].copy()
+        for m in sorted({min(n, 12), n // 2, n}):
+            got = farthest_point_indices(torch.from_numpy(pc).cuda(), m)[0].cpu().numpy()
+            assert np.array_equal(got, F.farthest_points(pc, m)), (n, m, len(base))
+
+
+@gpu
 def test_regularize_point_count_golden():
     from graspldm_amd.pointcloud import PointCloudHelpers as P
     g = load_golden("front_end.npz")

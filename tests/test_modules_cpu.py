@@ -316,5 +316,6 @@ def test_f32_only_switch_changes_what_is_packed_and_chosen(fpc_state_dict):
         assert all(lv.qkvn_w3 == lv.out_w3 == lv.down_w3 == lv.qkvn_wq == lv.out_wq == lv.down_wq == 0 for lv in off.lv)
         assert not voxel.split_conv_supported(48, 48, 24) and not dense.split_supported(768, 96)
         assert not split_plan_ok([131], [128, 128, 256], 64)
-        assert voxel.split_conv_supported(3, 48, 24)          # the 3-channel conv has no other MFMA form
+        assert not voxel.split_conv_supported(3, 48, 24)      # round 6: the 3-channel conv runs its f32 form too (K padded)
+        assert voxel.conv_supported(48, 24)
     assert numerics.split_enabled()

@@ -48,6 +48,37 @@ def test_fps_ties_duplicated_points(hip, cpu):
     assert torch.equal(got, cpu.furthest_point_sampling(pts, 12))
 
 
+def _tie_cloud(kind, n):
+    """Clouds whose FPS rounds end in exact maximal-distance ties (same f32 bit pattern at several indices).
+    'dup': five corner points repeated round-robin -- every round's maximum is shared by n/5 copies, some of them 512
+    apart (the reference kernel's slot rule, sampling.cu:137-160, prefers the lowest k mod 512, then the lowest k);
+    'sym': the 8 vertices of a cube and the 6 of an octahedron around the origin, repeated -- distinct points at the
+    same distance; 'grid': integer lattice points (exactly representable squared distances, many equal)."""
+    if kind == "dup":
+        base = torch.tensor([[0., 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [.5, .5, 1]])
+    elif kind == "sym":
+        cube = torch.tensor([[x, y, z] for x in (-1., 1.) for y in (-1., 1.) for z in (-1., 1.)])
+        octa = torch.tensor([[2., 0, 0], [-2, 0, 0], [0, 2, 0], [0, -2, 0], [0, 0, 2], [0, 0, -2]])
+        base = torch.cat([cube, octa])
+    else:
+        base = torch.tensor([[x, y, z] for x in range(5) for y in range(5) for z in range(5)], dtype=torch.float32)
+    rep = -(-n // base.shape[0])
+    return base.repeat(rep, 1)[:n].T.unsqueeze(0).contiguous()   # [1, 3, n]
+
+
+@pytest.mark.parametrize("kind", ["dup", "sym", "grid"])
+@pytest.mark.parametrize("n", [64, 100, 512, 1000, 1024])
+def test_fps_wave_kernel_tie_rule(hip, cpu, kind, n):
+    """Every shipped shape (n <= 1024) runs fps_wave_kernel, whose key is reduced as two 32-bit halves (distance bits,
+    then the tie word among the lanes that hold the maximal distance): exact ties must pick what sampling.cu picks."""
+    pts = _tie_cloud(kind, n)
+    for m in sorted({min(n, 12), n // 2, n}):
+        got = hip.furthest_point_sampling(pts.cuda(), m).cpu()
+        assert torch.equal(got, cpu.furthest_point_sampling(pts, m)), (kind, n, m)
+    two = torch.cat([pts, pts.flip(2)]).contiguous()   # batched: the second cloud ties at other indices
+    assert torch.equal(hip.furthest_point_sampling(two.cuda(), min(n, 40)).cpu(), cpu.furthest_point_sampling(two, min(n, 40)))
+
+
 @pytest.mark.parametrize("b,n,m,u,r", [(2, 1024, 512, 64, 0.2), (2, 512, 128, 64, 0.4), (1, 1024, 1024, 32, 0.1),
                                        (3, 100, 10, 8, 0.5), (1, 257, 33, 16, 0.3), (1, 6000, 40, 32, 0.15),
                                        (2, 64, 64, 4, 0.05), (1, 1024, 16, 128, 2.0)])
