@@ -309,7 +309,8 @@ def main():
     pcs = pcs_u.repeat(reps, 1, 1)[:B].contiguous().to(dev)
     gmean = metas_u["grasp_mean"].repeat(reps, 1)[:B].contiguous().to(dev)
     gstd = metas_u["grasp_std"].repeat(reps, 1)[:B].contiguous().to(dev)
-    x_T = torch.randn(B * G, 1, D, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    xgen = torch.Generator().manual_seed(1234 + rank)
+    x_T = torch.randn(B * G, 1, D, generator=xgen).to(dev)   # the stage records below; the timed batches draw their own
     den = ldm.diffusion_model.model
     eng = den.engine(dev)
     from graspldm_amd import _lib as L
@@ -332,8 +333,10 @@ def main():
             return one_batch()
 
     def one_batch():
-        # DDPM: the per-step noise of every latent is drawn inside sample(), on the device, every batch (part of the step)
-        (tm, lg), _ = ldm.generate_grasps(pcs, num_grasps=G, x_T=x_T, **noise_kw)
+        # x_T is drawn per batch on the CPU generator and uploaded, as sample() does (gaussian_diffusion.py:253: part of the
+        # step since round 6); DDPM: the per-step noise of every latent is drawn inside sample(), on the device, every batch
+        xb = torch.randn(B * G, 1, D, generator=xgen).pin_memory().to(dev, non_blocking=True)
+        (tm, lg), _ = ldm.generate_grasps(pcs, num_grasps=G, x_T=xb, **noise_kw)
         # the epilogue runs on the rank's OWN rows; what crosses xGMI is one all-gather of the result rows [B G, 7]
         # (the latent-level outputs the north star names: 28 bytes per grasp), nothing is repeated per rank
         H, un, conf = pose_epilogue(tm, lg, gmean, gstd, G)
@@ -571,6 +574,45 @@ def main():
                                                  decode=event_time(lambda: dec(lat1, z1, samples_per_cond=G), 5) * 1e3),
                                   note="latency of a single cloud: the denoise launch is 2 tiles on 2 of 256 CUs, "
                                        "i.e. the per-step critical path of one workgroup"))
+          if args.scheduler == "ddim" and N == 1024 and not ppc:
+              # ---- the whole step with EXACT f32 products (numerics.f32_only(): denoiser / decoder on the sample-major f32-MFMA
+              # engine, encoder GEMMs and voxel convs on their f32-pipe kernels): the reference's own arithmetic, end to end,
+              # next to the headline's split-f16 products -- same weights, clouds and x_T
+              from graspldm_amd import numerics
+
+              def whole(model):
+                  (tm_, lg_), _ = model.generate_grasps(pcs, num_grasps=G, x_T=x_T)
+                  return pose_epilogue(tm_, lg_, gmean, gstd, G)[0]
+              H_split = whole(ldm)
+              with numerics.f32_only():
+                  ldm32 = build_fpc_ldm(n_points=N, scheduler=args.scheduler, device=dev)
+                  ldm32.set_inference_timesteps(S)
+                  H_f32 = whole(ldm32)
+                  t_f32 = event_time(lambda: whole(ldm32), 2, lead=0)
+                  ldm32.check_engines()
+              dH = (H_split - H_f32).abs()
+              kernels.append(dict(kernel="whole step with exact f32 products (graspldm_amd.numerics.f32_only(): every GEMM on the f32 "
+                                         "matrix pipe, k-ordered fma chains)", bound="mfma", avg_ms=t_f32 * 1e3, unit="grasps/s",
+                                  grasps_per_s=B * G / t_f32, headline_over_this=(B * G / t_f32) and grasps_per_s / world / (B * G / t_f32),
+                                  max_abs_pose_diff_vs_headline=float(dH.max()), mean_abs_pose_diff_vs_headline=float(dH.mean()),
+                                  note="one batch at a time on one stream (no pipelining); the pose difference is between two "
+                                       "summation orders, both within the 1e-4 bar of the reference's vectors (tests/test_models_gpu.py)"))
+              del ldm32
+              # ---- the same experiment conditioned by the set-abstraction encoder family (north star: FPS / ball query /
+              # grouped SA MLPs conditioning the VAE): PVCNN2Encoder in its repaired form at half width / half resolution
+              # (the reference's encoder benchmark setting); parity: tests/test_models_gpu.py::
+              # test_ldm_end_to_end_with_the_set_abstraction_encoder
+              ldm_sa = build_fpc_ldm(n_points=N, scheduler=args.scheduler, device=dev, encoder="PVCNN2Encoder", encoder_scale=(0.5, 0.5))
+              ldm_sa.set_inference_timesteps(S)
+              whole(ldm_sa)
+              t_sa_all = event_time(lambda: whole(ldm_sa), 3)
+              t_sa_enc = event_time(lambda: ldm_sa.vae_model.encode_pc(pcs), 3)
+              ldm_sa.check_engines()
+              kernels.append(dict(kernel="whole step conditioned by PVCNN2Encoder (set abstraction + PVConv + feature propagation, "
+                                         "scale_channels 0.5, scale_voxel_resolution 0.5)", bound="mfma", avg_ms=t_sa_all * 1e3,
+                                  unit="grasps/s", grasps_per_s=B * G / t_sa_all, stages_ms=dict(encode=t_sa_enc * 1e3),
+                                  note="one batch at a time on one stream; denoise and decode launches are the headline's"))
+              del ldm_sa
         # ---- CPU baseline: the torch-CPU oracle on this box's host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.scheduler == "ddim" and not ppc:
@@ -636,9 +678,9 @@ def main():
                                experiment=args.experiment, clouds_per_gpu=B, grasps_per_cloud=G, points=N, ddim_steps=S,
                                encoder="PVCNNEncoder (shipped %s config)" % args.experiment, parallelism=f"cloud-sharded x{world}",
                                weights="synthetic recipe seed 0", streams=args.streams,
-                               inputs=f"{uniq} distinct synthetic clouds per rank tiled to {B} (resident in HBM); x_T drawn once on the "
-                                      "CPU generator and passed in (the reference draws it inside sample(), gaussian_diffusion.py:253: "
-                                      f"{B * G * D * 4} bytes per batch, not in the timed region)"
+                               inputs=f"{uniq} distinct synthetic clouds per rank tiled to {B} (resident in HBM); x_T drawn per batch on the "
+                                      "CPU generator and uploaded inside the timed step, as the reference's sample() does "
+                                      f"(gaussian_diffusion.py:253: {B * G * D * 4} bytes per batch)"
                                       + (("; DDPM per-step noise drawn inside the fused launch (counter-based generator)" if noise_kw else
                                           "; DDPM per-step noise drawn on the device inside every timed batch") if args.scheduler == "ddpm" else "")),
                    roofline=roof, cpu_baseline=cpu, kernels=kernels)

@@ -388,79 +388,116 @@ def create_pointnet_components(blocks, in_channels, with_se=False, normalize=Tru
     return layers, in_channels, concat
 
 
+# The two builders below are table driven: the block tables of a backbone (PVCNN2.sa_blocks / fp_blocks, PointNet2SSG's)
+# are first turned into a PLAN -- plain data: per stage the (cin, cout, voxel resolution) of every conv block that exists
+# and the arguments of its pooling / propagation module -- and the modules are then made from the plan.  The plan decides
+# the nesting of the state_dict keys (a stage with one block is that block, with several an nn.Sequential), so it must
+# agree with the reference's construction (ext/pvcnn/utils.py:97-247) -- including that, after the first stage, only the
+# FIRST conv block of a multi-block stage exists (utils.py:142) -- and tests/golden/schema_pvcnn2.json /
+# schema_pointnet2_ssg.json (captured from the reference's modules) check exactly that through strict loads.
+def _scale_widths(widths, r):
+    return [_scale_widths(w, r) if isinstance(w, (list, tuple)) else int(r * w) for w in widths]
+
+
+def _pool_width(widths):
+    """Output channels of a pooling module: the last width of its one MLP, or of every branch of a multi-scale one."""
+    return sum(w[-1] for w in widths) if isinstance(widths[0], list) else widths[-1]
+
+
+def sa_plan(sa_blocks, extra_feature_channels, embed_dim=0, use_attention=False, width_multiplier=1,
+            voxel_resolution_multiplier=1):
+    """-> (stages, sa_in_channels, out_channels, num_centers).  stages[i] = dict(convs=[dict(cin, cout, resolution | None,
+    attention)], pool=dict(num_centers | None, radius, num_neighbors, in_channels, out_channels))."""
+    width, stages, stage_inputs = extra_feature_channels + 3, [], []
+    features = extra_feature_channels
+    centers = None
+    for i, (conv_cfg, (centers, radius, neighbors, pool_widths)) in enumerate(sa_blocks):
+        stage_inputs.append(width)
+        convs = []
+        if conv_cfg is not None:
+            cout, count, vres = conv_cfg
+            cout = int(width_multiplier * cout)
+            existing = count if i == 0 else min(count, 1)          # utils.py:139-143
+            for j in range(existing):
+                convs.append(dict(cin=(width if j == 0 else cout) + (embed_dim if i > 0 else 0), cout=cout,
+                                  resolution=None if vres is None else int(voxel_resolution_multiplier * vres),
+                                  attention=bool(use_attention and i % 2 == 1 and j == 0)))
+            if count > 0:
+                width = features = cout
+        pool = dict(num_centers=centers, radius=radius, num_neighbors=neighbors,
+                    in_channels=features + (embed_dim if (conv_cfg is None or conv_cfg[1] == 0) else 0),
+                    out_channels=_scale_widths(pool_widths, width_multiplier))
+        stages.append(dict(convs=convs, pool=pool))
+        width = features = _pool_width(pool["out_channels"])
+    return stages, stage_inputs, width, 1 if centers is None else centers
+
+
+def _conv_block(spec, **pvconv_kw):
+    if spec["resolution"] is None:
+        return SharedMLP(spec["cin"], spec["cout"])
+    return PVConv(spec["cin"], spec["cout"], kernel_size=3, resolution=spec["resolution"],
+                  use_attention=spec.get("attention", False), **pvconv_kw)
+
+
+def _stage_module(blocks):
+    return blocks[0] if len(blocks) == 1 else nn.Sequential(*blocks)
+
+
 def create_pointnet2_sa_components(sa_blocks, extra_feature_channels, embed_dim=0, use_attention=False, dropout=0.1,
                                    with_se=False, voxelization_normalize=True, eps=0, width_multiplier=1,
                                    voxel_resolution_multiplier=1):
-    """utils.py:97-182.  Keeps the reference's quirk that, after the first stage, only the
-    first PVConv of a multi-block stage is instantiated (the `elif k == 0` at :142)."""
-    r, vr = width_multiplier, voxel_resolution_multiplier
-    in_channels = extra_feature_channels + 3
-    sa_layers, sa_in_channels = [], []
-    stage = 0
-    num_centers = None
-    for conv_cfg, sa_cfg in sa_blocks:
-        k = 0
-        sa_in_channels.append(in_channels)
-        blocks = []
-        if conv_cfg is not None:
-            oc, num_blocks, vres = conv_cfg
-            oc = int(r * oc)
-            for p in range(num_blocks):
-                attention = (stage + 1) % 2 == 0 and use_attention and p == 0
-                if vres is None:
-                    make = SharedMLP
-                else:
-                    make = functools.partial(PVConv, kernel_size=3, resolution=int(vr * vres),
-                                             use_attention=attention, dropout=dropout, with_se=with_se,
-                                             with_se_relu=True, normalize=voxelization_normalize, eps=eps)
-                if stage == 0:
-                    blocks.append(make(in_channels, oc))
-                elif k == 0:
-                    blocks.append(make(in_channels + embed_dim, oc))
-                in_channels = oc
-                k += 1
-            extra_feature_channels = in_channels
-        num_centers, radius, num_neighbors, ocs = sa_cfg
-        ocs = [[int(r * o) for o in oc] if isinstance(oc, (list, tuple)) else int(r * oc) for oc in ocs]
-        if num_centers is None:
-            make = PointNetAModule
+    """utils.py:97-182 -> (sa_layers, sa_in_channels, channels_sa_features, num_centers), via sa_plan."""
+    stages, stage_inputs, _, centers = sa_plan(sa_blocks, extra_feature_channels, embed_dim, use_attention,
+                                               width_multiplier, voxel_resolution_multiplier)
+    layers, width = [], None
+    for st in stages:
+        blocks = [_conv_block(c, dropout=dropout, with_se=with_se, with_se_relu=True, normalize=voxelization_normalize, eps=eps)
+                  for c in st["convs"]]
+        pool = st["pool"]
+        if pool["num_centers"] is None:
+            blocks.append(PointNetAModule(in_channels=pool["in_channels"], out_channels=pool["out_channels"],
+                                          include_coordinates=True))
         else:
-            make = functools.partial(PointNetSAModule, num_centers=num_centers, radius=radius,
-                                     num_neighbors=num_neighbors)
-        blocks.append(make(in_channels=extra_feature_channels + (embed_dim if k == 0 else 0), out_channels=ocs,
-                           include_coordinates=True))
-        stage += 1
-        in_channels = extra_feature_channels = blocks[-1].out_channels
-        sa_layers.append(blocks[0] if len(blocks) == 1 else nn.Sequential(*blocks))
-    return sa_layers, sa_in_channels, in_channels, 1 if num_centers is None else num_centers
+            blocks.append(PointNetSAModule(num_centers=pool["num_centers"], radius=pool["radius"],
+                                           num_neighbors=pool["num_neighbors"], in_channels=pool["in_channels"],
+                                           out_channels=pool["out_channels"], include_coordinates=True))
+        width = blocks[-1].out_channels          # the module knows its own output width (sum over its MLP branches)
+        layers.append(_stage_module(blocks))
+    return layers, stage_inputs, width, centers
+
+
+def fp_plan(fp_blocks, in_channels, sa_in_channels, embed_dim=0, width_multiplier=1, voxel_resolution_multiplier=1):
+    """-> (stages, out_channels).  stages[i] = dict(fp=dict(in_channels, out_channels), convs=[dict(cin, cout, resolution)])."""
+    stages, width = [], in_channels
+    skips = list(reversed(sa_in_channels))                     # stage i propagates onto the input of SA stage -1 - i
+    for (fp_widths, conv_cfg), skip in zip(fp_blocks, skips):
+        outs = tuple(_scale_widths(fp_widths, width_multiplier))
+        stage = dict(fp=dict(in_channels=width + skip + embed_dim, out_channels=outs), convs=[])
+        width = outs[-1]
+        if conv_cfg is not None:
+            cout, count, vres = conv_cfg
+            cout = int(width_multiplier * cout)
+            for _ in range(count):
+                stage["convs"].append(dict(cin=width, cout=cout,
+                                           resolution=None if vres is None else int(voxel_resolution_multiplier * vres)))
+                width = cout
+        stages.append(stage)
+    return stages, width
 
 
 def create_pointnet2_fp_modules(fp_blocks, in_channels, sa_in_channels, embed_dim=0, use_attention=False, dropout=0.1,
                                 with_se=False, normalize=True, eps=0, width_multiplier=1,
                                 voxel_resolution_multiplier=1):
-    """utils.py:185-247"""
-    r, vr = width_multiplier, voxel_resolution_multiplier
-    fp_layers = []
-    for fp_idx, (fp_cfg, conv_cfg) in enumerate(fp_blocks):
-        blocks = []
-        ocs = tuple(int(r * oc) for oc in fp_cfg)
-        blocks.append(PointNetFPModule(in_channels=in_channels + sa_in_channels[-1 - fp_idx] + embed_dim,
-                                       out_channels=ocs))
-        in_channels = ocs[-1]
-        if conv_cfg is not None:
-            oc, num_blocks, vres = conv_cfg
-            oc = int(r * oc)
-            for _ in range(num_blocks):
-                if vres is None:
-                    make = SharedMLP
-                else:
-                    make = functools.partial(PVConv, kernel_size=3, resolution=int(vr * vres), use_attention=False,
-                                             dropout=dropout, with_se=with_se, with_se_relu=True,
-                                             normalize=normalize, eps=eps)
-                blocks.append(make(in_channels, oc))
-                in_channels = oc
-        fp_layers.append(blocks[0] if len(blocks) == 1 else nn.Sequential(*blocks))
-    return fp_layers, in_channels
+    """utils.py:185-247 -> (fp_layers, out_channels), via fp_plan (attention inside the propagation stages is off in every
+    configuration this package builds; PVConv rejects use_attention=True itself)."""
+    stages, width = fp_plan(fp_blocks, in_channels, sa_in_channels, embed_dim, width_multiplier, voxel_resolution_multiplier)
+    layers = []
+    for st in stages:
+        blocks = [PointNetFPModule(in_channels=st["fp"]["in_channels"], out_channels=st["fp"]["out_channels"])]
+        blocks += [_conv_block(c, dropout=dropout, with_se=with_se, with_se_relu=True, normalize=normalize, eps=eps)
+                   for c in st["convs"]]
+        layers.append(_stage_module(blocks))
+    return layers, width
 
 
 # -------------------------------------------------------------------- backbones

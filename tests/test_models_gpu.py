@@ -758,6 +758,46 @@ def test_voxel_conv_without_mfma_instantiation_runs_the_direct_kernel():
         assert out.shape == (2, cout, 256) and _err(out, exp) < 2e-5, (cout, r, _err(out, exp))
 
 
+def test_ldm_end_to_end_with_the_set_abstraction_encoder():
+    """GraspLatentDDM.generate_grasps conditioned by the SET-ABSTRACTION encoder family (north star: FPS / ball query /
+    grouped set-abstraction MLPs conditioning the VAE): PVCNN2Encoder in its repaired form.  Backbone weights = the golden's,
+    which test_g8_pvcnn2_golden pins to the reference's own PVCNN2 graph (checked again here on the golden cloud); the
+    expectation continues from the backbone's features on the CPU: the encoder head in f64 (pc_encoders.py:104-111), then
+    the oracle's 100 DDIM steps and decoder (grasp_ldm.py:189-233).  Poses 1e-4."""
+    import torch.nn.functional as F
+    from graspldm_amd.pipeline import build_fpc_ldm
+    from graspldm_amd.synthetic import synthetic_batch, synthetic_state_dict
+    from oracle import torch_ref as R
+    g = load_golden("pvcnn2.npz")
+    ldm = build_fpc_ldm(encoder="PVCNN2Encoder")
+    enc = ldm.vae_model.encoder.pc_encoder
+    enc.pvcnn_modules.load_state_dict(synthetic_state_dict(load_schema("schema_pvcnn2.json"), seed=4), strict=True)
+    ldm = ldm.cuda().eval()
+    ldm.set_inference_timesteps(100)
+    G = 8
+    extra, _ = synthetic_batch(1, 1024)
+    pc = torch.cat([g["coords"].transpose(1, 2), extra]).contiguous()     # [2, N, 3]: the golden cloud and a synthetic one
+    x_T = torch.randn(2 * G, 1, 4, generator=torch.Generator().manual_seed(3))
+    (tm, lg), _ = ldm.generate_grasps(pc.cuda(), num_grasps=G, x_T=x_T)
+    ldm.check_engines()
+    with torch.no_grad():
+        feat = enc.pvcnn_modules(pc.transpose(1, 2).contiguous().cuda())
+        z_hip = enc(pc.cuda())
+    assert _err(feat[:1, :, ::16], g["out"]) < 1e-4                       # the reference's backbone
+    sd = {k: v.detach().cpu() for k, v in ldm.state_dict().items()}
+    p = "vae_model.encoder.pc_encoder."
+    h = F.conv1d(feat.cpu().double(), sd[p + "conv_downscale.weight"].double(), sd[p + "conv_downscale.bias"].double())
+    h = F.conv1d(h, sd[p + "out_layer.0.weight"].double(), sd[p + "out_layer.0.bias"].double())
+    z = F.linear(h, sd[p + "out_layer.1.weight"].double(), sd[p + "out_layer.1.bias"].double()).float()
+    assert z.shape == (2, 3, 64) and _err(z_hip, z) < 5e-5, _err(z_hip, z)
+    zr = z.repeat_interleave(G, dim=0)
+    sched = R.make_scheduler("ddim")
+    sched.set_timesteps(100)
+    x, _ = R.sample_latents(sd, "diffusion_model.model.", zr, sched, 4, x_T=x_T)
+    etm, elg = R.decoder_forward(sd, "vae_model.decoder.", x.squeeze(-2), zr)
+    assert tm.shape == (2 * G, 6) and _err(tm, etm) < 1e-4 and _err(lg, elg) < 1e-4, (_err(tm, etm), _err(lg, elg))
+
+
 def test_pvcnn2_encoder_default_constructor_runs():
     """The registry encoder as it is default-constructed (scale_channels 0.25, scale_voxel_resolution 0.75: PVConv
     resolutions 24, 12 and 6 -- 6 is not a multiple of the voxel kernels' 4 x 4 x r brick) builds and runs."""

@@ -4,6 +4,7 @@ FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; both the raw bytes and
 FETCH_SIZE (exact for 16-B/lane streaming reads only: MI355X_MICROARCH.md, HBM) are written."""
 import csv, glob, json, os, re, sys
 root = sys.argv[1]
+kMinClockUs = 20.0   # shortest launch for which GRBM_GUI_ACTIVE / duration is read as a clock
 
 
 def short(name):
@@ -39,8 +40,11 @@ for kn, k in kern.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k and k["GRBM_GUI_ACTIVE"] > 0:
         # busy cycles summed over 1024 SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs
         k["mfma_busy_frac"] = (k["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (k["GRBM_GUI_ACTIVE"] / 8.0)
-    if "GRBM_GUI_ACTIVE" in k and k.get("avg_us", 0) > 0:
-        k["effective_clock_ghz"] = k["GRBM_GUI_ACTIVE"] / 8.0 / k["avg_us"] / 1e3   # active cycles of an XCD / duration
+    if "GRBM_GUI_ACTIVE" in k and k.get("avg_us", 0) >= kMinClockUs:
+        # active cycles of an XCD / duration: a clock only for launches much longer than what GRBM_GUI_ACTIVE also counts
+        # around a dispatch (command processor, cache invalidation: several us) -- a 5 us kernel "ran at 5.5 GHz" this way.
+        # Below kMinClockUs the field is left out and the table prints n/a.
+        k["effective_clock_ghz"] = k["GRBM_GUI_ACTIVE"] / 8.0 / k["avg_us"] / 1e3
     if "SQ_WAVE_CYCLES" in k and "SQ_WAIT_ANY" in k and k["SQ_WAVE_CYCLES"] > 0:
         # the three are disjoint shares of the wave cycles (MI355X_MICROARCH.md, SQ counters)
         k["wait_any_frac"] = k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"]
@@ -58,7 +62,8 @@ for kn, k in rows:
         continue
     print(f"{kn:70s} calls {k['calls']:4d} avg {k['avg_us']:10.1f} us  {k['total_pct']:5.1f} %  fetch(raw) "
           f"{k.get('fetch_bytes_raw', 0) / 1e6:9.1f} MB write {k.get('write_bytes', 0) / 1e6:9.1f} MB  mfma busy "
-          f"{k.get('mfma_busy_frac', float('nan')):.3f} clock {k.get('effective_clock_ghz', float('nan')):.2f} GHz"
+          f"{k.get('mfma_busy_frac', float('nan')):.3f} clock "
+          + (f"{k['effective_clock_ghz']:.2f} GHz" if "effective_clock_ghz" in k else f"n/a (< {kMinClockUs:.0f} us)")
           + (f"  wait {k['wait_any_frac']:.2f} stall {k['wait_inst_frac']:.2f} issue {k['active_inst_frac']:.2f}" if "wait_any_frac" in k else "")
           + (f"  lds busy {k.get('lds_busy_frac', float('nan')):.2f} conflict {k['lds_conflict_frac']:.2f}" if "lds_conflict_frac" in k else "")
           + (f"  l2 hit {k['l2_hit_frac']:.2f}" if "l2_hit_frac" in k else ""))
