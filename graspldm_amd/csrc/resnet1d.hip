@@ -3427,6 +3427,11 @@ struct SaArgs {
   // |bias| (BatchNorm folded), from the packer: |layer output| <= gain_r * max |input| + gain_b
   int ranged;
   float gain_r[4], gain_b[4];
+  // split-f16 kernel, first layer hoisted (gldm_sa_mlp_forward_f16x2_pre): pre [b][n][c1] = W1b f + b1 per POINT (one
+  // pointwise GEMM per cloud instead of one per (centre, neighbour) pair: every point sits in ~16 balls), wa_off: float
+  // index in `weights` of W1a [c1][4] (the coordinate columns x, y, z, 0).  The MFMA layers are then layers 2.. of the module.
+  const float *pre;
+  int c1, wa_off;
 };
 
 __global__ __launch_bounds__(Geo<64>::kThreads, 2) void sa_mlp_kernel(const SaArgs a) {
@@ -3775,6 +3780,7 @@ struct PwArgs {
   // eight per-wave range words in the LDS plan.  ranged == 0: operands are split as they are.
   int ranged, rng_off;
   float gain0_r, gain0_b;
+  int y_point_major;   // split-f16 kernel: y is [b, n, cout] (a lane's four consecutive rows of a column: one 16-byte store)
 };
 
 __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
@@ -4158,7 +4164,12 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
                          (long long)(c0 + (ni < ntv ? 16 * ni + col : col)) * a.add_cs];
             acc[mi][ni][r] = a.relu ? fmaxf(v, 0.f) : v;
           }
-        if (a.y) {
+        if (a.y && a.y_point_major) {
+          float *yb = a.y + ((size_t)b * a.n + c0 + col) * a.cout + 16 * (mt0 + mi) + 4 * kq;
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni)
+            if (ni < ntv) *reinterpret_cast<f32x4 *>(yb + (size_t)16 * ni * a.cout) = acc[mi][ni];
+        } else if (a.y) {
           float *yb = a.y + ((size_t)b * a.cout + 16 * (mt0 + mi) + 4 * kq) * a.n + c0 + col;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -4453,9 +4464,16 @@ __device__ __forceinline__ Frag3 sa3_hidden(const Ctx &c, const SaArgs &a, int l
   return nxt;
 }
 // last layer: m-tile mt over all four n-tiles, max over each centre's U / 16 tiles and 16 columns, ReLU, one value per row
-template <class FIRST>
+// STAGED (the single-tile kernels): the pooled values are not stored here.  A workgroup walks RUNS of consecutive tiles,
+// i.e. 8 consecutive centres of a cloud; the pooled value of (row, centre s of the run) goes to stage[row][s] in LDS and,
+// at the end of the run, all threads write the rows' 32-byte runs (sa3_flush) -- where the unstaged form wrote every (row,
+// centre) as a 4-byte store of its own into its own 32-byte sector (268 MB of HBM writes per launch at SSG-SA2 for a
+// 33.5 MB tensor).  LDS, not registers, carries the run: values kept in registers across tiles were spilled to scratch, and
+// a scratch reload queues behind the next tile's gather in the in-order vmcnt (measured: 1.02 -> 1.26 ms).
+constexpr int kSaRun = 8;   // centres per staged run
+template <class FIRST, bool STAGED = false>
 __device__ __forceinline__ void sa3_last(const Ctx &c, const SaArgs &a, int l, int mt, const float *src, int j0, float *outb,
-                                         const FIRST &first, float bsc, float osc) {
+                                         const FIRST &first, float bsc, float osc, float *stage = nullptr, int slot0 = 0) {
   const int col = c.lane & 15, kq = c.lane >> 4;
   f32x4 acc[1][4];
   const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.weights + a.b_off[l] + 16 * mt + 4 * kq) * bsc;
@@ -4475,7 +4493,27 @@ __device__ __forceinline__ void sa3_last(const Ctx &c, const SaArgs &a, int l, i
       if (ni % tpc) continue;  // wave uniform
       const float v = fmaxf(row16_max(m[ni]), 0.f) * osc;
       const int jj = ni / tpc;
-      if (col == 0 && j0 + jj < a.m) outb[(size_t)(16 * mt + 4 * kq + r) * a.m + j0 + jj] = v;
+      if constexpr (STAGED) {
+        if (col == 0 && j0 + jj < a.m) ((lds_f *)stage)[(16 * mt + 4 * kq + r) * kSaRun + slot0 + jj] = v;
+      } else {
+        if (col == 0 && j0 + jj < a.m) outb[(size_t)(16 * mt + 4 * kq + r) * a.m + j0 + jj] = v;
+      }
+    }
+  }
+}
+// the staged run -> out[b][row][jbase .. jbase + count) for every row of the last layer: thread = (row, half of the run)
+__device__ __forceinline__ void sa3_flush(const SaArgs &a, const float *stage, int tid, int b, int jbase, int count) {
+  const int rows = a.cout[a.n_layers - 1];
+  for (int i = tid; i < 2 * rows; i += 512) {
+    const int row = i >> 1, h4 = 4 * (i & 1), left = count - h4;
+    if (left <= 0) continue;
+    const f32x4 v = *reinterpret_cast<const lds_f4 *>((const lds_f *)stage + row * kSaRun + h4);
+    float *o = a.out + ((size_t)b * rows + row) * a.m + jbase + h4;
+    if (left >= 4 && (((size_t)o & 15) == 0)) *reinterpret_cast<f32x4 *>(o) = v;
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < left) o[e] = v[e];
     }
   }
 }
@@ -4558,8 +4596,14 @@ __device__ __forceinline__ void sa3_layer_multi_kb(const Ctx &c, const SaArgs &a
 // workgroup then takes `sub` consecutive tiles at once -- their planes side by side in LDS, every layer swept over all of
 // them between two barriers, the weight fragments of the later ones coming from L1.  QUADS: row quads a gather thread
 // holds per tile (9 covers 288 input rows; the multi-tile form takes 32-row inputs: one quad).
-template <int SUBMAX, int QUADS>
-__global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blocks_a, int blocks_b, int sub,
+// PRE: the module's first layer is not a GEMM here.  W1 [x - c; f] = W1a (x - c) + W1b f, and W1b f + b1 depends on the
+// POINT only: the caller computes it once per cloud (a.pre), the gather threads fetch a neighbour's 4 rows of it instead of
+// 4 feature rows, add the three coordinate products and apply the ReLU -- the tile that goes into LDS is the first
+// layer's OUTPUT.  One k-loop, one plane-writing epilogue and one barrier per tile less, 29 % fewer MFMAs at SSG-SA2.
+// (The second launch bound is waves per SIMD: 4 = two co-resident workgroups, i.e. 128 registers.  The hoisted form with
+// up to four row quads per gather thread fits them; the general one holds nine quads and runs one workgroup per CU.)
+template <int SUBMAX, int QUADS, bool PRE = false>
+__global__ __launch_bounds__(512, (PRE && QUADS <= 4) ? 4 : 2) void sa_mlp3_kernel(const SaArgs a, int blocks_a, int blocks_b, int sub,
                                                          int tiles_per_cloud, int total_tiles) {
   extern __shared__ float lds[];
   Ctx c{a.weights, lds, (int)threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)threadIdx.x & 63,
@@ -4570,6 +4614,7 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
   const int nquads = a.cin_pad[0] >> 2;
   const int supers = (total_tiles + sub - 1) / sub;
   float gv[SUBMAX][QUADS][4];
+  float dxyz[SUBMAX][PRE ? 4 : 1];   // PRE: the column's x - c (3) and its live mask
   auto gather_load = [&](int T) {
 #pragma unroll
     for (int st = 0; st < SUBMAX; ++st) {
@@ -4582,6 +4627,24 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
       const int32_t *idx = a.idx + ((size_t)b * a.m + j0) * a.u;
       const int id = live ? idx[col] : 0;
       const int jc = live ? j0 + jj : 0, cmax = a.c > 0 ? a.c - 1 : 0;
+      if constexpr (PRE) {
+        // pre is POINT-major, [b][n][c1]: a neighbour's rows are one run of c1 floats, a thread's row quad one 16-byte load
+        // (channel-major, the 4-byte gathers of a tile were 8192 cache-line requests: the texture addresser, not the
+        // matrix pipe, bounded the kernel -- a layer less changed nothing)
+        const f32x4 *prow = reinterpret_cast<const f32x4 *>(a.pre + ((size_t)b * a.n + id) * a.c1);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) dxyz[st][e] = pts[e * a.n + id] - ctr[e * a.m + jc];
+        dxyz[st][3] = live ? 1.0f : 0.0f;
+        const int qmax = (a.c1 >> 2) - 1;
+#pragma unroll
+        for (int i = 0; i < QUADS; ++i) {
+          const int rq = qg + 8 * i;
+          const f32x4 v4 = prow[rq < qmax ? rq : qmax];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gv[st][i][e] = v4[e];
+        }
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < QUADS; ++i) {
         const int rq = qg + 8 * i;   // rows 4 rq .. 4 rq + 3: [x y z f0] for quad 0, f[4 rq - 3 ..] after it
@@ -4592,6 +4655,30 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
           if (ch < 3) v = pts[ch * a.n + id] - ctr[ch * a.m + jc];
           else { const int f = ch - 3; v = feat[(size_t)(f < cmax ? f : cmax) * a.n + id]; v = f < a.c ? v : 0.f; }
           gv[st][i][e] = live ? v : 0.f;
+        }
+      }
+    }
+  };
+  // PRE: gv holds the neighbours' rows of W1b f + b1; add W1a (x - c), ReLU -> the first layer's output (dead columns and
+  // rows beyond c1: zero).  W1a's rows are wave uniform (a wave's threads share their row quads).
+  auto gather_finish = [&]() {
+    if constexpr (PRE) {
+      const f32x4 *wa = reinterpret_cast<const f32x4 *>(a.weights + a.wa_off);
+#pragma unroll
+      for (int i = 0; i < QUADS; ++i) {
+        const int rq = qg + 8 * i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 4 * rq + e;
+          const f32x4 w4 = wa[row < a.c1 ? row : 0];
+#pragma unroll
+          for (int st = 0; st < SUBMAX; ++st) {
+            float h = gv[st][i][e];
+            h = __builtin_fmaf(w4[0], dxyz[st][0], h);
+            h = __builtin_fmaf(w4[1], dxyz[st][1], h);
+            h = __builtin_fmaf(w4[2], dxyz[st][2], h);
+            gv[st][i][e] = row < a.c1 ? fmaxf(h, 0.f) * dxyz[st][3] : 0.f;
+          }
         }
       }
     }
@@ -4667,9 +4754,25 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
       }
     }
   };
-  int T = blockIdx.x;
+  // Tile order.  SUBMAX > 1: workgroup w takes super-tiles w, w + grid, ...  SUBMAX == 1: RUNS of consecutive tiles = 8
+  // consecutive centres of a cloud, so that the pooled rows leave as 32-byte runs (SaOutStage); the runs are dealt
+  // w, w + grid, ... in an order that gives the workgroups of one XCD (blockIdx % 8: the dispatcher's round robin)
+  // neighbouring runs: at any time the chip works on ~32 clouds and an XCD on four of them, whose features stay in its L2.
+  // (Measured and dropped: one contiguous range of 64 tiles per workgroup, 16-centre runs -- every workgroup on a cloud of
+  // its own, 256 clouds live at once: 1.02 -> 1.31 ms at SSG-SA2, the gathers miss L2.)
+  constexpr bool kRuns = SUBMAX == 1;
+  const int grid = gridDim.x;
+  const int run = !kRuns ? 1 : (supers < 8 * grid ? 1 : (cpt >= kSaRun ? 1 : kSaRun / cpt));   // small launches: a tile per workgroup at a time
+  const int w8 = !kRuns ? (int)blockIdx.x
+                        : ((grid & 7) == 0 ? ((int)blockIdx.x & 7) * (grid >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x);
+  auto tile_of = [&](int q) { return (w8 + (q / run) * grid) * run + q % run; };   // this workgroup's q-th (super-)tile
+  int q = 0, T = tile_of(0);
+  if (T >= supers) return;   // (whole workgroup: no barrier has been reached yet)
+  float *stage = rng + 16;   // [rows of the last layer][kSaRun] (kRuns; the launcher adds the room)
+  int st_count = 0, st_b = 0, st_jbase = 0;
   gather_load(T);
   frag = sa3_request(c, a, 0);
+  gather_finish();
   if (a.ranged) {
     range_publish();
     __syncthreads();
@@ -4677,7 +4780,7 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
   }
   gather_store();
   __syncthreads();
-  for (; T < supers; T += gridDim.x) {
+  for (; T < supers; T = tile_of(++q)) {
     bool a_to_b = true;
     // scales of this tile's planes, layer by layer: the input's is measured, a hidden layer's follows from the bound
     // |out| <= gain_r * max |in| + gain_b (true units)
@@ -4690,7 +4793,7 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
       __syncthreads();
       a_to_b = !a_to_b;
     }
-    const int Tn = T + (int)gridDim.x < supers ? T + (int)gridDim.x : T;
+    const int Tq = tile_of(q + 1), Tn = Tq < supers ? Tq : T;
     gather_load(Tn);
     {
       const int l = a.n_layers - 1, mtiles = a.cout[l] >> 4;
@@ -4709,17 +4812,39 @@ __global__ __launch_bounds__(512, 2) void sa_mlp3_kernel(const SaArgs a, int blo
         const int b = t / tiles_per_cloud, j0 = (t - b * tiles_per_cloud) * cpt;
         float *outb = a.out + (size_t)b * a.cout[l] * a.m;
         const float *src = lds + st * per + (a_to_b ? 0 : blocks_a * kSaBlockFloats);
+        if constexpr (kRuns) {
+          const int live = a.m - j0 < cpt ? a.m - j0 : cpt;          // centres of this tile that exist
+          if (st_count == 0) { st_b = b; st_jbase = j0; }
+          if (w < mtiles) sa3_last<Frag3, true>(cl, a, l, w, src, j0, outb, cur, bsc, osc, stage, st_count);
+          for (int mt = w + 8; mt < mtiles; mt += 8) sa3_last<NoFirst, true>(cl, a, l, mt, src, j0, outb, NoFirst(), bsc, osc, stage, st_count);
+          st_count += live;
+        } else {
         if (st == 0) {
           if (w < mtiles) sa3_last<Frag3>(cl, a, l, w, src, j0, outb, cur, bsc, osc);
         } else {
           if (w < mtiles) sa3_last<NoFirst>(cl, a, l, w, src, j0, outb, NoFirst(), bsc, osc);
         }
         for (int mt = w + 8; mt < mtiles; mt += 8) sa3_last<NoFirst>(cl, a, l, mt, src, j0, outb, NoFirst(), bsc, osc);
+        }
       }
       frag = sa3_request(c, a, 0);   // the next tile's first layer
     }
-    if (a.ranged) range_publish();   // the next tile's gathered values have long landed
+    gather_finish();                 // the next tile's gathered values have long landed
+    if (a.ranged) range_publish();
     __syncthreads();  // the last layer may have been reading region A
+    if constexpr (kRuns) {
+      // the run ends here unless the next tile continues it (same cloud, the next centres, room in the stage)
+      bool more = Tq < supers;
+      if (more) {
+        const int bn = Tq / tiles_per_cloud, jn = (Tq - bn * tiles_per_cloud) * cpt;
+        const int liven = a.m - jn < cpt ? a.m - jn : cpt;
+        more = bn == st_b && jn == st_jbase + st_count && st_count + liven <= kSaRun;
+      }
+      if (!more) {
+        sa3_flush(a, stage, c.tid, st_b, st_jbase, st_count);
+        st_count = 0;
+      }
+    }
     if (a.ranged) range_read();
     gather_store();
     __syncthreads();
@@ -4893,7 +5018,8 @@ namespace {
 int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0, const float *w, const float *bias, int b,
                      int cin, int cout, int n, int relu, const float *head_w, const float *head_b, int hout, float *y,
                      float *z, hipStream_t stream, bool split_f16 = false, const float *add = nullptr, long long add_bs = 0,
-                     long long add_rs = 0, long long add_cs = 0, const float *front_gain = nullptr) {
+                     long long add_rs = 0, long long add_cs = 0, const float *front_gain = nullptr, bool y_point_major = false) {
+  if (y_point_major && (!split_f16 || !y)) return GLDM_ERR_UNSUPPORTED;
   if (add && !split_f16) return GLDM_ERR_UNSUPPORTED;
   if (!x || !w || !bias || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
   if (!y && !head_w) return GLDM_ERR_INVALID_ARG;
@@ -4963,6 +5089,7 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   a.dyn_first = dyn_first; a.ticket_off = ticket_off; a.x0_in_planes = x0_in_planes;
   a.add = add; a.add_bs = add_bs; a.add_rs = add_rs; a.add_cs = add_cs;
   // range scales: a lone layer measures its input tile; with a layer in front the caller's gain bounds its output
+  a.y_point_major = y_point_major ? 1 : 0;
   a.rng_off = ticket_off + 4;
   a.ranged = split_f16 && (!w0 || front_gain);
   if (w0 && front_gain) {
@@ -5019,6 +5146,12 @@ GLDM_API int gldm_pointwise_mlp_f16x2(const float *x, const float *w_split, cons
                           y, z, reinterpret_cast<hipStream_t>(stream), true);
 }
 
+GLDM_API int gldm_pointwise_mlp_f16x2_pm(const float *x, const float *w_split, const float *bias, int b, int cin, int cout,
+                                          int n, int relu, float *y_point_major, gldm_stream_t stream) {
+  return launch_pointwise(x, nullptr, nullptr, 0, w_split, bias, b, cin, cout, n, relu, nullptr, nullptr, 0, y_point_major,
+                          nullptr, reinterpret_cast<hipStream_t>(stream), true, nullptr, 0, 0, 0, nullptr, true);
+}
+
 GLDM_API int gldm_pointwise_mlp_f16x2_add(const float *x, const float *w_split, const float *bias, const float *add,
                                            long long add_cloud_stride, long long add_row_stride, long long add_col_stride, int b,
                                            int cin, int cout, int n, int relu, float *y, gldm_stream_t stream) {
@@ -5036,19 +5169,23 @@ GLDM_API int gldm_pointwise_mlp2_f16x2(const float *x, const float *w0_packed, c
                           hout, y, z, reinterpret_cast<hipStream_t>(stream), true, nullptr, 0, 0, 0, front_gain);
 }
 
-GLDM_API int gldm_sa_mlp_forward_f16x2(const float *points, const float *centers, const float *features,
-                                        const int32_t *idx, const float *weights, int b, int c, int n, int m, int u,
-                                        int n_layers, const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off,
-                                        const int32_t *b_off, const float *range_gain, float *out, gldm_stream_t stream) {
+namespace {
+// pre != nullptr: the first layer hoisted (sa_mlp3_kernel<.., PRE>): `features` unused, c = 0, cin_pad[0] = rows of pre
+int launch_sa3(const float *points, const float *centers, const float *features, const float *pre, int wa_off,
+               const int32_t *idx, const float *weights, int b, int c, int n, int m, int u,
+               int n_layers, const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off,
+               const int32_t *b_off, const float *range_gain, float *out, gldm_stream_t stream) {
   if (!points || !centers || !idx || !weights || !out || !cin_pad || !cout || !w3_off || !b_off || b <= 0 || c < 0 ||
       n <= 0 || m <= 0 || u <= 0)
     return GLDM_ERR_INVALID_ARG;
   if (c > 0 && !features) return GLDM_ERR_INVALID_ARG;
+  if (pre && (c != 0 || wa_off < 0 || (wa_off & 3))) return GLDM_ERR_INVALID_ARG;
   if (n_layers < 1 || n_layers > 4 || !(u == 16 || u == 32 || u == 64)) return GLDM_ERR_UNSUPPORTED;
   SaArgs a{};
   a.points = points; a.centers = centers; a.feat = c > 0 ? features : nullptr; a.idx = idx; a.weights = weights;
   a.out = out; a.c = c; a.n = n; a.m = m; a.u = u; a.n_layers = n_layers;
   a.ranged = range_gain != nullptr;
+  a.pre = pre; a.c1 = pre ? cin_pad[0] : 0; a.wa_off = wa_off;
   for (int l = 0; l < n_layers && range_gain; ++l) {
     a.gain_r[l] = range_gain[2 * l];
     a.gain_b[l] = range_gain[2 * l + 1];
@@ -5066,17 +5203,19 @@ GLDM_API int gldm_sa_mlp_forward_f16x2(const float *points, const float *centers
     }
     a.cin_pad[l] = cin_pad[l]; a.cout[l] = cout[l]; a.w_off[l] = w3_off[l]; a.b_off[l] = b_off[l];
   }
-  if (cin_pad[0] < 3 + c || cin_pad[0] > 32 * kSa3Quads) return GLDM_ERR_UNSUPPORTED;
+  if (!pre && (cin_pad[0] < 3 + c || cin_pad[0] > 32 * kSa3Quads)) return GLDM_ERR_UNSUPPORTED;
+  if (pre && cin_pad[0] > 256) return GLDM_ERR_UNSUPPORTED;
   blocks_a = blocks_a > (cin_pad[0] >> 5) ? blocks_a : (cin_pad[0] >> 5);
   const size_t tile_bytes = (size_t)(blocks_a + blocks_b) * kSaBlockFloats * sizeof(float);
-  constexpr size_t kRngBytes = 64;   // the eight range words behind the planes
+  // behind the planes: the eight range words and (single-tile kernels) the staged output rows of a run
+  const size_t kRngBytes = 64 + (size_t)cout[n_layers - 1] * kSaRun * sizeof(float);
   if (tile_bytes + kRngBytes > 160 * 1024) return GLDM_ERR_UNSUPPORTED;
   const int cpt = 64 / u, tpc = (m + cpt - 1) / cpt, total = tpc * b;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // narrow nets (32-row inputs, every K in {32, 64, 128}): the multi-tile kernel -- the layer's weights once per
   // workgroup pass, `sub` tiles' planes side by side in LDS (SSG SA1: three 48 KiB tiles, 2.52 -> 2.07 ms).  Two
   // co-resident workgroups of one tile each (the kernel fits 128 registers) measured slower: 2.40 ms.
-  bool kb_ok = cin_pad[0] == 32 || cin_pad[0] == 64;   // one or two row quads per gather thread
+  bool kb_ok = !pre && (cin_pad[0] == 32 || cin_pad[0] == 64);   // one or two row quads per gather thread
   for (int l = 0; l < n_layers; ++l) kb_ok = kb_ok && (cin_pad[l] == 32 || cin_pad[l] == 64 || cin_pad[l] == 128);
   int sub = kb_ok ? (int)(((size_t)160 * 1024 - kRngBytes) / tile_bytes) : 1;
   if (sub > 4) sub = 4;
@@ -5094,15 +5233,44 @@ GLDM_API int gldm_sa_mlp_forward_f16x2(const float *points, const float *centers
       hipLaunchKernelGGL((sa_mlp3_kernel<4, 2>), dim3(grid), dim3(512), tile_bytes * sub + kRngBytes, s, a, blocks_a, blocks_b, sub, tpc, total);
     }
   } else {
-    struct Sa3Tag { int site; };
-    gldm_dev::allow_dynamic_lds<Sa3Tag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<1, kSa3Quads>), 160 * 1024);
     const int per_cu = (tile_bytes + kRngBytes) * 2 <= 160 * 1024 ? 2 : 1;
     int grid = cu_count() * per_cu;
     if (grid > total) grid = total;
-    hipLaunchKernelGGL((sa_mlp3_kernel<1, kSa3Quads>), dim3(grid), dim3(512), tile_bytes + kRngBytes, s, a, blocks_a, blocks_b, 1, tpc, total);
+    if (pre && cin_pad[0] <= 128) {
+      struct Sa3Pre4Tag { int site; };
+      gldm_dev::allow_dynamic_lds<Sa3Pre4Tag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<1, 4, true>), 160 * 1024);
+      hipLaunchKernelGGL((sa_mlp3_kernel<1, 4, true>), dim3(grid), dim3(512), tile_bytes + kRngBytes, s, a, blocks_a, blocks_b, 1, tpc, total);
+    } else if (pre) {
+      struct Sa3PreTag { int site; };
+      gldm_dev::allow_dynamic_lds<Sa3PreTag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<1, 8, true>), 160 * 1024);
+      hipLaunchKernelGGL((sa_mlp3_kernel<1, 8, true>), dim3(grid), dim3(512), tile_bytes + kRngBytes, s, a, blocks_a, blocks_b, 1, tpc, total);
+    } else {
+      struct Sa3Tag { int site; };
+      gldm_dev::allow_dynamic_lds<Sa3Tag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<1, kSa3Quads>), 160 * 1024);
+      hipLaunchKernelGGL((sa_mlp3_kernel<1, kSa3Quads>), dim3(grid), dim3(512), tile_bytes + kRngBytes, s, a, blocks_a, blocks_b, 1, tpc, total);
+    }
   }
   return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
 }
+}  // namespace
+
+GLDM_API int gldm_sa_mlp_forward_f16x2(const float *points, const float *centers, const float *features,
+                                        const int32_t *idx, const float *weights, int b, int c, int n, int m, int u,
+                                        int n_layers, const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off,
+                                        const int32_t *b_off, const float *range_gain, float *out, gldm_stream_t stream) {
+  return launch_sa3(points, centers, features, nullptr, 0, idx, weights, b, c, n, m, u, n_layers, cin_pad, cout, w3_off, b_off,
+                    range_gain, out, stream);
+}
+
+GLDM_API int gldm_sa_mlp_forward_f16x2_pre(const float *points, const float *centers, const float *pre, const int32_t *idx,
+                                            const float *weights, int wa_off, int b, int n, int m, int u, int n_layers,
+                                            const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off,
+                                            const int32_t *b_off, const float *range_gain, float *out, gldm_stream_t stream) {
+  if (!pre) return GLDM_ERR_INVALID_ARG;
+  return launch_sa3(points, centers, nullptr, pre, wa_off, idx, weights, b, 0, n, m, u, n_layers, cin_pad, cout, w3_off, b_off,
+                    range_gain, out, stream);
+}
+
 
 GLDM_API int gldm_sa_mlp_forward(const float *points, const float *centers, const float *features,
                                  const int32_t *idx, const float *weights, int b, int c, int n, int m, int u,

@@ -1480,7 +1480,9 @@ static int conv3d_k3_f16x2_impl(const float *x, const float *in_coef, const floa
 #endif
   // (4 x 4 x 12 half bricks at 24^3 -- <3, 24, 12, 4>: 48 KiB of planes, two co-resident workgroups of 4 waves -- measured
   // 2.12 ms against 2.05 for the full-z brick: the kernel's 220 registers allow two waves per SIMD either way, and the
-  // halves pay a z halo and the weight stream twice.  Kept as an instantiable option, not used.)
+  // halves pay a z halo and the weight stream twice.  Kept as an instantiable option, not used.  Round 6, with three f16
+  // products instead of six bf16 ones: A/B of the whole encoder on one box 4.69 / 4.72 ms (full brick) against 4.63 / 4.84
+  // (halves) -- inside the run-to-run spread, still not used.)
   if (cout == 48 && r == 24) return launch_conv_pl<3, 24, 24, 8>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
   if (cout == 96 && r == 12) return launch_conv_pl<6, 12, 12, 4>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
   // PVCNN2's power-of-two shapes (round 5; f32-MFMA kernels before): <MT, R, ZB, WAVES>

@@ -56,6 +56,8 @@ class SaMlpPlan:
         layers = shared_mlp.layers
         n = len(layers) // 3
         self._split = None
+        self._pre = None
+        self._pre_ws = None
         self._layers = shared_mlp
         buf = _Buf()
         cin_pad, cout, w_off, b_off = [], [], [], []
@@ -103,6 +105,65 @@ class SaMlpPlan:
                            (ctypes.c_float * (2 * n))(*gain))
         return self._split
 
+    def _pre_plan(self):
+        """The split plan with the module's FIRST layer hoisted out of the (centre, neighbour) pairs
+        (gldm_sa_mlp_forward_f16x2_pre): W1 [x - c; f] + b1 = W1a (x - c) + (W1b f + b1).  Returns (weights with W1a
+        [c1p][4] behind the layer tables, tables of layers 2.., gains, wa_off, W1b [c1p, C] and b1 [c1p] on the device,
+        c1p) -- c1p = the first layer's width padded to whole 32-row plane blocks (zero rows)."""
+        if self._pre is None:
+            layers = self._layers.layers
+            n = len(layers) // 3
+            buf = _Buf()
+            cin_pad, cout, w_off, b_off, gain = [], [], [], [], []
+            w1, b1 = fold_conv_bn(layers[0], layers[1])
+            c1 = w1.shape[0]
+            c1p = (c1 + 31) // 32 * 32
+            for i in range(1, n):
+                w, b = fold_conv_bn(layers[3 * i], layers[3 * i + 1])
+                gain += [float(w.double().abs().sum(dim=1).max()), float(b.double().abs().max())]
+                kpad = (w.shape[1] + 31) // 32 * 32
+                rows = w.shape[0] if i == n - 1 else (w.shape[0] + 31) // 32 * 32
+                wp = torch.zeros(rows, kpad)
+                wp[: w.shape[0], : w.shape[1]] = w.cpu()
+                bp = torch.zeros(rows)
+                bp[: w.shape[0]] = b.cpu()
+                cin_pad.append(kpad)
+                cout.append(rows)
+                w_off.append(buf.add(mfma_a_fragments_f16x2(wp)))
+                b_off.append(buf.add(bp))
+            wa = torch.zeros(c1p, 4)
+            wa[:c1, :3] = w1[:, :3].cpu()
+            wa_off = buf.add(wa.reshape(-1))
+            w1b = torch.zeros(c1p, w1.shape[1] - 3)
+            w1b[:c1] = w1[:, 3:].cpu()
+            b1p = torch.zeros(c1p)
+            b1p[:c1] = b1.cpu()
+            arr = ctypes.c_int32 * (n - 1)
+            self._pre = (buf.tensor().to(self._device), arr(*cin_pad), arr(*cout), arr(*w_off), arr(*b_off),
+                         (ctypes.c_float * (2 * (n - 1)))(*gain), int(wa_off), w1b.to(self._device), b1p.to(self._device), c1p)
+        return self._pre
+
+    def _first_layer_per_point(self, features, w1b, b1p):
+        """pre [B, N, c1p] (POINT-major) = W1b f + b1: the split-f16 pointwise launch writing that layout where its shape
+        set allows, else the any-shape kernel and a transposing copy."""
+        from . import dense
+        x = features.contiguous().float()
+        c1p, cin = w1b.shape
+        if dense.split_mlp_supported(x, cin, c1p):
+            if self._pre_ws is None:
+                try:
+                    self._pre_ws = mfma_a_fragments_f16x2(w1b.detach().float().cpu()).to(x.device)
+                except SplitRangeError:
+                    self._pre_ws = False
+            if self._pre_ws is not False:
+                b, _, n = x.shape
+                y = torch.empty((b, n, c1p), dtype=torch.float32, device=x.device)
+                with torch.cuda.device(x.device):
+                    L.call("gldm_pointwise_mlp_f16x2_pm", L.ptr(x), L.ptr(self._pre_ws), L.ptr(b1p), b, cin, c1p, n, 0, L.ptr(y),
+                           L.current_stream(x.device))
+                return y
+        return dense._gemm_bias_act(x, w1b, b1p, False).transpose(1, 2).contiguous()
+
     def run(self, points, centers, features, idx):
         b, _, n = points.shape
         m, u = idx.shape[1], idx.shape[2]
@@ -111,6 +172,22 @@ class SaMlpPlan:
         lay = self._layers.layers
         cins = [lay[3 * i].weight.shape[1] for i in range(self.n_layers)]
         couts = [lay[3 * i].weight.shape[0] for i in range(self.n_layers)]
+        # first layer per POINT instead of per (centre, neighbour) pair: whenever there are features to hoist and a layer
+        # behind it (every point sits in m u / n balls on average: worth it from 2 upwards)
+        if c > 0 and self.n_layers >= 2 and m * u >= 2 * n and couts[0] <= 256 and split_plan_ok(couts[:1] + couts[1:-1], couts[1:], u):
+            try:
+                w3, cin_pad, cout, w_off, b_off, gain, wa_off, w1b, b1p, c1p = self._pre_plan()
+            except SplitRangeError:
+                w3 = None
+            if w3 is not None:
+                pre = self._first_layer_per_point(features, w1b, b1p)
+                with torch.cuda.device(points.device):
+                    L.call("gldm_sa_mlp_forward_f16x2_pre", L.ptr(points), L.ptr(centers), L.ptr(pre), L.ptr(idx), L.ptr(w3),
+                           wa_off, b, n, m, u, self.n_layers - 1, ctypes.cast(cin_pad, ctypes.c_void_p),
+                           ctypes.cast(cout, ctypes.c_void_p), ctypes.cast(w_off, ctypes.c_void_p),
+                           ctypes.cast(b_off, ctypes.c_void_p), ctypes.cast(gain, ctypes.c_void_p), L.ptr(out),
+                           L.current_stream(points.device))
+                return out
         split = None
         if split_plan_ok(cins, couts, u):
             try:

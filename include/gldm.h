@@ -334,6 +334,22 @@ int gldm_sa_mlp_forward_f16x2(const float *points /*[b,3,n]*/, const float *cent
                                const float *range_gain /*host [n_layers][2] or NULL*/,
                                float *out /*[b,cout_last,m]*/, gldm_stream_t stream);
 
+/* The same launch with the module's FIRST layer hoisted out of the (centre, neighbour) pairs (ABI 10).  Its input is the
+ * concatenation [x - centre; f] (ball_query.py:21-33), so  W1 [x - c; f] + b1 = W1a (x - c) + (W1b f + b1)  and the second
+ * term depends on the point only: the caller computes pre = W1b f + b1 once per cloud, POINT-major [b, n, c1]
+ * (gldm_pointwise_mlp_f16x2_pm; every point sits in ~m u / n balls, 16 at SSG-SA2: a neighbour's rows are then one run of
+ * c1 floats and a gather thread's four rows one 16-byte load), the gather fetches a neighbour's rows of `pre` instead of its
+ * features, adds the three coordinate products (W1a [c1][4] = columns x, y, z, 0 at float index wa_off of `weights`) and
+ * applies the ReLU.  The layer tables describe layers 2.. of the module (cin_pad[0] = c1 = rows of pre, a multiple of 32;
+ * rows the module does not have carry zero weights and zero pre).  Same arithmetic for layers 2.., the first layer's
+ * products are f32 (VALU) + the caller's GEMM: results differ from gldm_sa_mlp_forward_f16x2 in the last bits. */
+int gldm_sa_mlp_forward_f16x2_pre(const float *points /*[b,3,n]*/, const float *centers /*[b,3,m]*/,
+                                   const float *pre /*[b,n,c1]*/, const int32_t *idx /*[b,m,u]*/, const float *weights,
+                                   int wa_off, int b, int n, int m, int u, int n_layers,
+                                   const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off, const int32_t *b_off,
+                                   const float *range_gain /*host [n_layers][2] or NULL*/,
+                                   float *out /*[b,cout_last,m]*/, gldm_stream_t stream);
+
 /* ref: grasp_ldm/models/modules/ext/pvcnn/modules/shared_mlp.py:6-35 (Conv1d k = 1 + eval BatchNorm folded + ReLU),
  * one layer, in the native [b, c, n] layout: y = act(W x + bias).  `w_packed` = the folded weight [cout, cin] in MFMA
  * A-fragment order (graspldm_amd/r1d_pack.py: mfma_a_fragments).  Optional fused head on the accumulators:
@@ -390,6 +406,10 @@ int gldm_pointwise_mlp_f16x2(const float *x /*[b,cin,n]*/, const float *w_split,
  * (cout * n, n, 1).  It serves layers whose input is a concatenation (pointnet.py:117-135 PointNetFPModule, :11-46
  * PointNetAModule): W [x1; x2] = W1 x1 + W2 x2, the wide part here, the other part (three coordinate rows, or one centre's
  * feature vector broadcast to every point) as the addend, and the concatenated tensor is never built. */
+/* gldm_pointwise_mlp_f16x2 writing y POINT-major, [b, n, cout] (a lane's four consecutive output rows of a point: one
+ * 16-byte store): the layout gldm_sa_mlp_forward_f16x2_pre gathers from. */
+int gldm_pointwise_mlp_f16x2_pm(const float *x /*[b,cin,n]*/, const float *w_split, const float *bias /*[cout]*/, int b, int cin,
+                                 int cout, int n, int relu, float *y_point_major /*[b,n,cout]*/, gldm_stream_t stream);
 int gldm_pointwise_mlp_f16x2_add(const float *x /*[b,cin,n]*/, const float *w_split, const float *bias /*[cout]*/,
                                   const float *add, long long add_cloud_stride, long long add_row_stride,
                                   long long add_col_stride, int b, int cin, int cout, int n, int relu,
