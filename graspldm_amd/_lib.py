@@ -64,6 +64,7 @@ _SIGNATURES = {
     "gldm_pointwise_any": [_vp, _vp, _vp, _i, _i, _i, ctypes.c_longlong, _i, _vp, _vp],
     "gldm_linear_rows": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp_f16x2": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "gldm_row_max": [_vp, _ll, _i, _vp, _vp],
     "gldm_pointwise_mlp_f16x2_pm": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp_f16x2_add": [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _vp],
     "gldm_pointwise_mlp2_f16x2": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],

@@ -787,6 +787,44 @@ int ilog2_ceil(int v) {
 
 GLDM_API int gldm_abi_version(void) { return 10; }
 
+// ---------------------------------------------------------------- row max --
+// out[row] = max over n of x[row][0..n): the global pooling of PointNetAModule (pointnet.py:40-44, `.max(dim=-1)`) over
+// [b * c] rows.  One wave per row, 16-byte loads where the row allows, DPP-free shuffle reduction (a row is a few hundred
+// floats: the launch is one pass over x).  NaN propagates as in torch.max (a NaN in the row -> NaN).
+namespace {
+__global__ __launch_bounds__(256) void row_max_kernel(const float *__restrict__ x, long long rows, int n, float *__restrict__ out) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float *p = x + row * n;
+  float m = -__builtin_inff();
+  bool nan = false;
+  if ((n & 3) == 0 && (((size_t)p & 15) == 0)) {
+    for (int i = lane; i < (n >> 2); i += 64) {
+      const float4 v = reinterpret_cast<const float4 *>(p)[i];
+      nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+      m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+  } else {
+    for (int i = lane; i < n; i += 64) {
+      const float v = p[i];
+      nan |= v != v;
+      m = fmaxf(m, v);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+  const bool any_nan = __ballot(nan) != 0ull;
+  if (lane == 0) out[row] = any_nan ? __builtin_nanf("") : m;
+}
+}  // namespace
+
+GLDM_API int gldm_row_max(const float *x, long long rows, int n, float *out, gldm_stream_t stream) {
+  if (!x || !out || rows <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(row_max_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, rows, n, out);
+  return hipGetLastError() == hipSuccess ? GLDM_OK : GLDM_ERR_LAUNCH;
+}
+
 GLDM_API const char *gldm_status_string(int status) {
   switch (status) {
     case GLDM_OK: return "ok";

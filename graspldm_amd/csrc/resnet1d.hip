@@ -3184,14 +3184,29 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
   // 32-column engines take the loop below) and requests the NEXT step's time-embedding value a step ahead, so that the
   // step prologue is three SiLUs and an LDS store instead of a chain of L2 round trips.
   constexpr int kMaxR = 4;
-  const bool g_fast = S * E <= GG::kThreads && R <= kMaxR && !a.sample_t;
-  float ce_reg[kMaxR] = {0.f, 0.f, 0.f, 0.f}, se_reg = 0.f, te_next = 0.f;
+  // 64-column engines (the step program travels in the kernel arguments: the LDS tape region holds three scalars at its
+  // end): the cond rows wait there, [r][thread], instead of in registers -- four values alive across the whole op tape were
+  // spilled to scratch and reloaded every step.  (More rows than fit there: the general loop below.)
+#if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_EXP_LDS_TAPE)
+  constexpr bool kCeLds = false;   // (that experiment reads the step program from the region)
+#else
+  constexpr bool kCeLds = PM;
+#endif
+  const bool g_fast = S * E <= GG::kThreads && R <= kMaxR && !a.sample_t && (!kCeLds || R * S * E <= 1020);
+  lds_f *ce_l = (lds_f *)(lds + GG::kMiscTape);
+  float ce_reg[kCeLds ? 1 : kMaxR] = {}, se_reg = 0.f, te_next = 0.f;
   if (g_fast && tid_s < S * E) {
     const int s = tid_s / E, e = tid_s - s * E;
     const int gi = min(samp0 + min(s, nsamp - 1), a.n_samples - 1);
     const float *ce = a.cemb + ((size_t)(gi / a.samples_per_cond) * R) * E + e;
+    if constexpr (kCeLds) {
 #pragma unroll
-    for (int r = 0; r < kMaxR; ++r) ce_reg[r] = ce[(r < R ? r : 0) * E];
+      for (int r = 0; r < kMaxR; ++r)
+        if (r < R) ce_l[r * S * E + tid_s] = ce[r * E];
+    } else {
+#pragma unroll
+      for (int r = 0; r < kMaxR; ++r) ce_reg[r] = ce[(r < R ? r : 0) * E];
+    }
     if (a.semb) se_reg = a.semb[(size_t)gi * E + e];  // latent_emb += cls_emb (class_conditioned_resnet.py:99-101)
     if (a.temb) te_next = a.temb[(size_t)a.timesteps[s0] * E + e];
   }
@@ -3208,8 +3223,13 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
         const float te = te_next + se_reg;
         if (a.temb) te_next = a.temb[(size_t)a.timesteps[step + 1 < s1 ? step + 1 : step] * E + (tid_o % E)];
         float g = 0.f;
+        if constexpr (kCeLds) {   // (a thread reads back what it wrote itself: no barrier)
 #pragma unroll
-        for (int r = 0; r < kMaxR; ++r) g += r < R ? silu(te + ce_reg[r]) : 0.f;
+          for (int r = 0; r < kMaxR; ++r) g += r < R ? silu(te + ce_l[(r < R ? r : 0) * S * E + tid_o]) : 0.f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < kMaxR; ++r) g += r < R ? silu(te + ce_reg[r]) : 0.f;
+        }
         G[tid_o] = g;
       }
     } else if (!GLDM_SKIP(c, 32))
@@ -3341,7 +3361,8 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     }
   } else {
     // heads: rows 0..5 tmrp, row 6 class logit; input = the L-vector of each sample
-    const int nh = d.n_head;
+    int nh = d.n_head;
+    asm volatile("" : "+s"(nh));   // opaque here: the reciprocal of the division below was computed at kernel entry and spilled
     if (tid_e < S * nh) {
       const int s = tid_e / nh, r = tid_e - s * nh;
       const int gi = samp0 + s;

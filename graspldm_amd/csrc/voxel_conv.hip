@@ -443,13 +443,12 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
                                 // half): with hs a multiple of 16 units the two sets fall on disjoint banks
 
   // fragment read base of (n-tile, lane column): voxel (0,0,0)-tap of the column, this lane's channel half
-  int vb[NTW], gvox[NTW];
+  int vb[NTW];
 #pragma unroll
   for (int ni = 0; ni < NTW; ++ni) {
     const int o = 16 * (wave * NTW + ni) + col;
     const int iz = o % ZB, ixy = o / ZB, ix = ixy >> 2, iy = ixy & 3;
     vb[ni] = (ix * 6 + iy) * zp + iz + (kq & 1) * hs;
-    gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + bz0 + iz;
   }
   f32x4 acc[MT][NTW];
 #pragma unroll
@@ -676,6 +675,19 @@ __global__ __launch_bounds__(64 * WAVES, (ZB * 16 / WAVES / 16 >= 6) ? 1 : 2) vo
     } else {   // the slot was zeroed by the launcher; two addends: order independent
       atomicAdd(p, s);
       atomicAdd(p + 1, s2);
+    }
+  }
+  // the output voxels of (n-tile, lane column), derived here from an opaque copy of the lane id: computed in front of
+  // the block loop they were NTW more registers alive across it (one instantiation spilled)
+  int gvox[NTW];
+  {
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) {
+      const int o = 16 * (wave * NTW + ni) + (lane_o & 15);
+      const int iz = o % ZB, ixy = o / ZB, ix = ixy >> 2, iy = ixy & 3;
+      gvox[ni] = ((bx0 + ix) * r + by0 + iy) * r + bz0 + iz;
     }
   }
   if (out_cl) {
@@ -1404,7 +1416,6 @@ static int conv3d_k3_impl(const float *x, const float *w_packed, const float *bi
   GLDM_CONV_CASE(2, 8);   // 32 ch @ 32^3  (PVCNN2)
   GLDM_CONV_CASE(4, 4);   // 64 ch @ 16^3
   GLDM_CONV_CASE(8, 2);   // 128 ch @ 8^3
-  GLDM_CONV_CASE(4, 8);   // 64 ch @ 32^3
   // half-width / half-resolution variants (the reference's encoder benchmark runs PVCNN / PVCNN2 at 0.5 / 0.5)
   GLDM_CONV_CASE(2, 4);   // 32 ch @ 16^3
   GLDM_CONV_CASE(4, 2);   // 64 ch @ 8^3
@@ -1413,6 +1424,9 @@ static int conv3d_k3_impl(const float *x, const float *w_packed, const float *bi
   GLDM_CONV_CASE(4, 1);   // 64 ch @ 4^3
   GLDM_CONV_CASE(8, 1);   // 128 ch @ 4^3
 #undef GLDM_CONV_CASE
+  // 64 ch @ 32^3 (PVCNN2 at full width under numerics.f32_only(): the split kernel serves it otherwise): 4 m-tiles x 8
+  // n-tiles of accumulators spilled 58-70 registers as one launch -- two launches of the 32-channel instantiation instead
+  if (mt == 4 && ntw == 8) return launch_conv_halves<2, 8>(x, w_packed, bias, b, cin, cout, r, y, partial, s, out_cl);
   if (mt == 16 && ntw == 2) return launch_conv_halves<8, 2>(x, w_packed, bias, b, cin, cout, r, y, partial, s, out_cl);  // 256 ch @ 8^3
   if (mt == 8 && ntw == 4) return launch_conv_halves<4, 4>(x, w_packed, bias, b, cin, cout, r, y, partial, s, out_cl);   // 128 ch @ 16^3
   return GLDM_ERR_UNSUPPORTED;

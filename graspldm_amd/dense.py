@@ -190,12 +190,13 @@ def pointwise_conv_bn_relu(x, conv, bn):
 def concat_conv_bn_relu(xa, xb, conv, bn):
     """relu(BN_eval(conv(cat([xa, xb], dim=1)))) of a k = 1 conv WITHOUT building the concatenation:
     W [xa; xb] = Wa xa + Wb xb.  The wide part runs as the split-f16 launch with the other part as its addend
-    (gldm_pointwise_mlp_f16x2_add).  Two shapes of the PointNet++-style backbones (pointnet.py:11-46, 117-135):
+    (gldm_pointwise_mlp_f16x2_add).  Three shapes of the PointNet++-style backbones (pointnet.py:11-46, 117-135):
       * xa [B, Ca, N] wide (Ca % 128 == 0), xb [B, Cb, N] a few rows (Cb in SMALL_CIN: coordinates / raw features):
         addend = Wb xb + b from the lane-per-point kernel, a [B, Cout, N] tensor;
       * xa [B, Ca, 1] ONE centre's features that nearest-neighbour interpolation would broadcast to every point,
-        xb [B, Cb, N] wide (Cb % 128 == 0): addend = Wa xa, a per-cloud bias [B, Cout].
-    Returns None when neither applies (the caller concatenates and takes the plain path)."""
+        xb [B, Cb, N] wide (Cb % 128 == 0): addend = Wa xa, a per-cloud bias [B, Cout];
+      * both wide (Ca % 128 == 0 and Cb % 128 == 0): addend = Wb xb + b from a split launch of its own.
+    Returns None when none applies (the caller concatenates and takes the plain path)."""
     from . import _lib as L
     if not (xa.is_cuda and xb.is_cuda and xa.ndim == 3 and xb.ndim == 3 and xa.dtype == torch.float32 and xb.dtype == torch.float32):
         return None
@@ -208,11 +209,14 @@ def concat_conv_bn_relu(xa, xb, conv, bn):
     if not broadcast and na != n:
         return None
     wide_c = cb if broadcast else ca
-    if not split_supported(wide_c) or (not broadcast and cb not in SMALL_CIN):
+    # third form: BOTH parts wide (a feature-propagation layer joining two 128 / 256-channel tensors, PointNet2SSG's
+    # 256 + 128 -> 256): Wb xb as a split launch of its own, then Wa xa with it as the addend
+    both_wide = not broadcast and cb >= 128 and ca >= 128 and split_supported(ca) and split_supported(cb)
+    if not split_supported(wide_c) or (not broadcast and cb not in SMALL_CIN and not both_wide):
         return None
     from ._cache import params_key, publish
     src = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv.bias] if conv.bias is not None else [])
-    key = (params_key(src, xa.device), ca, broadcast)
+    key = (params_key(src, xa.device), ca, broadcast, both_wide)
     hit = conv.__dict__.get("_gldm_concat")
     if hit is None or hit[0] != key:
         from .r1d_pack import SplitRangeError, mfma_a_fragments_f16x2
@@ -221,9 +225,10 @@ def concat_conv_bn_relu(xa, xb, conv, bn):
         wide = wb if broadcast else wa
         try:
             w3 = mfma_a_fragments_f16x2(wide.detach().float().cpu()).to(xa.device)
+            w_other = wa if broadcast else (mfma_a_fragments_f16x2(wb.detach().float().cpu()).to(xa.device) if both_wide else wb)
         except SplitRangeError:
             return None   # a weight beyond the f16 range: the caller concatenates and takes the plain (f32) path
-        hit = (key, w3, wa if broadcast else wb, b, torch.zeros_like(b))
+        hit = (key, w3, w_other, b, torch.zeros_like(b))
         conv.__dict__["_gldm_concat"] = hit
         publish(xa.device)
     _, w3, w_other, b, zero_b = hit
@@ -232,6 +237,9 @@ def concat_conv_bn_relu(xa, xb, conv, bn):
         # Wa xa for every cloud at once: [1, Ca, B] columns = clouds
         g = _gemm_bias_act(xa[:, :, 0].t().contiguous().unsqueeze(0), w_other, None, False)[0].t().contiguous()   # [B, Cout]
         xw, add, strides, bias = xb.contiguous(), g, (cout, 1, 0), b
+    elif both_wide:
+        add = pointwise_mlp(xb.contiguous(), w_other, b, cout, False, split=True)[0]                             # [B, Cout, N] = Wb xb + b
+        xw, strides, bias = xa.contiguous(), (cout * n, n, 1), zero_b
     else:
         add = _gemm_bias_act(xb.contiguous(), w_other, b, False)                                                   # [B, Cout, N]
         xw, strides, bias = xa.contiguous(), (cout * n, n, 1), zero_b
@@ -239,6 +247,18 @@ def concat_conv_bn_relu(xa, xb, conv, bn):
         L.call("gldm_pointwise_mlp_f16x2_add", L.ptr(xw), L.ptr(w3), L.ptr(bias), L.ptr(add), *strides, bsz, wide_c, cout, n, 1,
                L.ptr(y), L.current_stream(xa.device))
     return y
+
+
+def row_max(x):
+    """[B, C, N] -> [B, C, 1] = x.max(dim=-1, keepdim=True).values (PointNetAModule's global pooling), one launch."""
+    from . import _lib as L
+    _need_cuda(x)
+    xf = x.contiguous().float()
+    b, c, n = xf.shape
+    out = torch.empty((b, c, 1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("gldm_row_max", L.ptr(xf), b * c, n, L.ptr(out), L.current_stream(x.device))
+    return out
 
 
 def linear(x, lin):

@@ -183,7 +183,7 @@ class PointNetAModule(nn.Module):
                 x = mlp(features)
             else:
                 x = _rest_of(mlp, x)
-            outs.append(x.max(dim=-1, keepdim=True).values)
+            outs.append(dense.row_max(x))
         return (torch.cat(outs, dim=1) if len(outs) > 1 else outs[0]), new_coords
 
 

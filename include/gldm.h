@@ -425,6 +425,10 @@ int gldm_pointwise_mlp2_f16x2(const float *x /*[b,cin0,n]*/, const float *w0_spl
                                const float *front_gain /*host [2] or NULL*/,
                                float *y /*[b,cout,n] or NULL*/, float *z /*[b,hout,n] or NULL*/, gldm_stream_t stream);
 
+/* ref: grasp_ldm/models/modules/ext/pvcnn/modules/pointnet.py:40-44 (PointNetAModule: `features.max(dim=-1)`, the global
+ * pooling over a cloud's centres).  out[row] = max over x[row][0..n) for rows = b * c; NaN propagates as in torch.max. */
+int gldm_row_max(const float *x /*[rows,n]*/, long long rows, int n, float *out /*[rows]*/, gldm_stream_t stream);
+
 /* ---------------------------------------------------------- voxel branch of PVConv */
 
 /* ref: grasp_ldm/models/modules/ext/pvcnn/modules/pvconv.py:48-66 (nn.Conv3d k=3 p=1 on the

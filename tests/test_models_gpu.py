@@ -618,7 +618,7 @@ def test_pointwise_mlp_split_f16(b, cin0, cin, cout, n, hout):
 
 
 @pytest.mark.parametrize("b,ca,na,cb,n,cout", [(3, 128, 1024, 3, 1024, 128), (2, 256, 128, 3, 128, 256), (4, 1024, 1, 256, 128, 256),
-                                               (2, 128, 64, 6, 64, 64)])
+                                               (2, 128, 64, 6, 64, 64), (2, 256, 512, 128, 512, 256), (3, 128, 96, 128, 96, 64)])
 def test_first_layer_of_a_concatenation_without_the_concatenation(b, ca, na, cb, n, cout):
     """dense.concat_conv_bn_relu: relu(BN(conv(cat([xa, xb])))) as the split-f16 launch over the wide part with the other
     part as its addend (gldm_pointwise_mlp_f16x2_add) -- a few coordinate rows as a [B, Cout, N] tensor, or ONE centre's
@@ -829,6 +829,21 @@ def test_pointwise_any_kernel(b, cin, cout, n, relu):
     y2 = torch.empty_like(y)
     L.call("gldm_pointwise_any", L.ptr(xd), L.ptr(wd), None, b, cin, cout, n, 0, L.ptr(y2), L.current_stream())
     assert _err(y2, torch.einsum("oc,bcn->bon", w.double(), x.double()).float()) < 3e-6 * (1 + exp.abs().max().item())
+
+
+@pytest.mark.parametrize("b,c,n", [(3, 1024, 128), (2, 7, 33), (1, 1, 1), (4, 256, 4096)])
+def test_row_max_kernel(b, c, n):
+    """gldm_row_max = x.max(dim=-1, keepdim=True).values (PointNetAModule's global pooling, pointnet.py:40-44): exact, NaN
+    propagating like torch.max."""
+    from graspldm_amd import dense
+    g = torch.Generator().manual_seed(b + c + n)
+    x = torch.randn(b, c, n, generator=g)
+    x[0, 0, n // 2] = 1e30
+    if c > 1:
+        x[-1, 1, 0] = float("nan")
+    got = dense.row_max(x.cuda()).cpu()
+    exp = x.max(dim=-1, keepdim=True).values
+    assert got.shape == exp.shape and torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(exp, nan=-7.0))
 
 
 def test_dense_layers_make_no_library_call():
