@@ -4013,7 +4013,11 @@ __device__ long long g_pw_stamp[64];
 // serves three n-tiles -- with three f16 products per block the kernel is bound by the CU's L2 rate (5 MB of fragments per
 // tile at 52 B/clk = 96 k cycles against 59 k of MFMAs at 32 points), so bytes per POINT are what counts.  n % 16 == 0: a
 // cloud's last tile holds 1-3 whole n-tiles (`ntv`); the others are computed on zeros and never stored.
-template <bool ADD, int NT>
+// MU: m-tiles per unit of output rows (2; 1 for layers of fewer than 256 rows, whose 4-7 two-tile units left waves idle:
+// the 128-row feature-propagation layers and the set-abstraction first layer per point)
+// (Tried for MU = 1: a 128-register bound, two workgroups per CU -- these launches are short tiles whose staging -> barrier
+// -> k-loop -> store chain is latency -- 96 spilled registers: the ring of four A sets and two B sets does not fit.)
+template <bool ADD, int NT, int MU = 2>
 __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a) {
   constexpr int NC = 16 * NT;
   extern __shared__ float lds[];
@@ -4117,11 +4121,11 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
     // unit off an LDS ticket instead; the unit after the current one is drawn before the current k-loop so that its
     // first weight fragments are requested from inside that loop (the ring of four A sets never drains), and the B
     // planes of block k + 1 are read in front of the MFMAs of block k.
-    const int units = mtiles >> 1;
-    u32x4 af[4][2][kSplit];
+    const int units = mtiles / MU;
+    u32x4 af[4][MU][kSplit];
     auto load_a = [&](int buf, int mt0, int kb) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MU; ++mi)
 #pragma unroll
         for (int pl = 0; pl < kSplit; ++pl) af[buf][mi][pl] = wv.raw_at(((mt0 + mi) * kb32 + kb) * kFragBytes, pl * 1024);
     };
@@ -4143,16 +4147,16 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
     const int dyn_first = a.dyn_first;
     int unit = wave;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load_a(u, 2 * (unit < units ? unit : 0), u);   // a wave without a unit requests unit 0's (unused)
+    for (int u = 0; u < 4; ++u) load_a(u, MU * (unit < units ? unit : 0), u);   // a wave without a unit requests unit 0's (unused)
     load_b(0, 0);
     while (unit < units) {
-      const int mt0 = 2 * unit;
+      const int mt0 = MU * unit;
       const int nxt = unit + 8 < dyn_first ? unit + 8 : draw();
-      const int mtn = 2 * (nxt < units ? nxt : unit);   // past the end: harmless re-reads of this unit's fragments
+      const int mtn = MU * (nxt < units ? nxt : unit);   // past the end: harmless re-reads of this unit's fragments
       // bias and head fragments of this unit: requested now, used behind the k-loop (the bias is added last)
-      f32x4 acc[2][NT], bv[2], ah[2];
+      f32x4 acc[MU][NT], bv[MU], ah[MU];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < MU; ++mi) {
         bv[mi] = *reinterpret_cast<const f32x4 *>(a.bias + 16 * (mt0 + mi) + 4 * kq);
         ah[mi] = hw[(size_t)(a.head_w ? mt0 + mi : 0) * 64];
 #pragma unroll
@@ -4166,7 +4170,7 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
           load_b((u + 1) & 1, kb + 1 < kb32 ? kb + 1 : 0);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+          for (int mi = 0; mi < MU; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma_split(af[u][mi], bs[u & 1][ni], acc[mi][ni]);
           __builtin_amdgcn_sched_barrier(0);
@@ -4174,7 +4178,7 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
         }
       }
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < MU; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
@@ -4205,7 +4209,7 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) zu[ni] = drawn ? f32x4{0.f, 0.f, 0.f, 0.f} : zacc[ni];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MU; ++mi) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -4636,7 +4640,21 @@ __global__ __launch_bounds__(512, (PRE && QUADS <= 4) ? 4 : 2) void sa_mlp3_kern
   const int supers = (total_tiles + sub - 1) / sub;
   float gv[SUBMAX][QUADS][4];
   float dxyz[SUBMAX][PRE ? 4 : 1];   // PRE: the column's x - c (3) and its live mask
-  auto gather_load = [&](int T) {
+  // The neighbour index of a column is requested a tile ahead of the gather that dereferences it (idx_request at the end
+  // of the previous gather_load): read where it is used, every tile began with an exposed round trip for the index in
+  // front of the gather's own.
+  int id_pf[SUBMAX];
+  auto idx_request = [&](int T) {
+#pragma unroll
+    for (int st = 0; st < SUBMAX; ++st) {
+      const int t0 = T * sub + (st < sub ? st : 0);
+      const int t = t0 < total_tiles ? t0 : total_tiles - 1;
+      const int b = t / tiles_per_cloud, tile = t - b * tiles_per_cloud, j0 = tile * cpt, jj = col / a.u;
+      const bool live = j0 + jj < a.m;
+      id_pf[st] = (a.idx + ((size_t)b * a.m + j0) * a.u)[live ? col : 0];
+    }
+  };
+  auto gather_load = [&](int T) {   // idx_request(T) went before
 #pragma unroll
     for (int st = 0; st < SUBMAX; ++st) {
       const int t0 = T * sub + (st < sub ? st : 0);
@@ -4645,8 +4663,7 @@ __global__ __launch_bounds__(512, (PRE && QUADS <= 4) ? 4 : 2) void sa_mlp3_kern
       const bool live = j0 + jj < a.m;
       const float *pts = a.points + (size_t)b * 3 * a.n, *ctr = a.centers + (size_t)b * 3 * a.m;
       const float *feat = a.feat ? a.feat + (size_t)b * a.c * a.n : a.points;
-      const int32_t *idx = a.idx + ((size_t)b * a.m + j0) * a.u;
-      const int id = live ? idx[col] : 0;
+      const int id = live ? id_pf[st] : 0;
       const int jc = live ? j0 + jj : 0, cmax = a.c > 0 ? a.c - 1 : 0;
       if constexpr (PRE) {
         // pre is POINT-major, [b][n][c1]: a neighbour's rows are one run of c1 floats, a thread's row quad one 16-byte load
@@ -4791,7 +4808,12 @@ __global__ __launch_bounds__(512, (PRE && QUADS <= 4) ? 4 : 2) void sa_mlp3_kern
   if (T >= supers) return;   // (whole workgroup: no barrier has been reached yet)
   float *stage = rng + 16;   // [rows of the last layer][kSaRun] (kRuns; the launcher adds the room)
   int st_count = 0, st_b = 0, st_jbase = 0;
+  idx_request(T);
   gather_load(T);
+  {
+    const int T1 = tile_of(1);
+    idx_request(T1 < supers ? T1 : T);
+  }
   frag = sa3_request(c, a, 0);
   gather_finish();
   if (a.ranged) {
@@ -4816,6 +4838,10 @@ __global__ __launch_bounds__(512, (PRE && QUADS <= 4) ? 4 : 2) void sa_mlp3_kern
     }
     const int Tq = tile_of(q + 1), Tn = Tq < supers ? Tq : T;
     gather_load(Tn);
+    {
+      const int T2 = tile_of(q + 2);
+      idx_request(T2 < supers ? T2 : Tn);   // for the gather of the tile after next
+    }
     {
       const int l = a.n_layers - 1, mtiles = a.cout[l] >> 4;
       const float bsc = pow2_inv(s_cur), osc = s_cur;
@@ -5047,7 +5073,11 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   if (head_w && (!z || hout <= 0 || hout > 16)) return GLDM_ERR_INVALID_ARG;
   // k-blocks in pairs, 32-point tiles; output rows: 2 m-tiles x 8 waves per round on the f32 kernel, units of two m-tiles on
   // the split one (fewer than eight units -- 64 .. 224 output rows -- leave waves without a unit idle)
-  if ((cin & 31) || (split_f16 ? (n & 15) : (n & 31)) || (split_f16 ? (cout & 31) : (cout & 255))) return GLDM_ERR_UNSUPPORTED;
+  // the split launch hands out its output rows in units of two m-tiles, or of one where two would leave waves idle (fewer
+  // than 256 rows, no front layer / head): then any multiple of 16 rows
+  // (narrow inputs only: 32-point planes within half a CU's LDS, i.e. the 32-point tile form stays)
+  const int mu = (split_f16 && !w0 && !head_w && cout < 256 && ((size_t)cin * 32 * 2 * kSplit + 64) * 2 <= (size_t)160 * 1024) ? 1 : 2;
+  if ((cin & 31) || (split_f16 ? (n & 15) : (n & 31)) || (split_f16 ? (cout & (16 * mu - 1)) : (cout & 255))) return GLDM_ERR_UNSUPPORTED;
   if ((w0 || head_w) && (cout & 255)) return GLDM_ERR_UNSUPPORTED;   // front layer / head: whole rounds of units only
   if (w0 && (!b0 || cin0 <= 0 || (cin0 & 31) || (cin & 255))) return GLDM_ERR_UNSUPPORTED;
   size_t lds_bytes = ((size_t)cin * 32 + 8 * 16 * 32 + (w0 ? (size_t)cin0 * 32 : 0)) * sizeof(float);
@@ -5062,7 +5092,7 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
     // Tile width: 48 points where 32-point planes already take more than half a CU's LDS (one workgroup per CU either way)
     // and the 48-point plan fits; the front tile then goes UNDER the planes (x0_in_planes).
     const size_t cap = (size_t)160 * 1024 - 64;   // ticket + range words
-    const int units = cout / 32;
+    const int units = cout / (16 * mu);
     auto plan = [&](int ncol, bool x0_under, size_t &planes, size_t &region, int &first) {
       planes = (size_t)cin * ncol * 2 * kSplit;   // bytes: cin x ncol x kSplit f16
       region = (w0 && !x0_under) ? (size_t)cin0 * ncol * sizeof(float) : 0;
@@ -5098,7 +5128,12 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   struct PwBfAddTag { int site; };
   struct PwBf3Tag { int site; };
   struct PwBfAdd3Tag { int site; };
-  if (split_f16 && add && nt == 3) gldm_dev::allow_dynamic_lds<PwBfAdd3Tag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<true, 3>), 160 * 1024);
+  struct PwBf1Tag { int site; };
+  struct PwBfAdd1Tag { int site; };
+  if (split_f16 && mu == 1 && nt == 2) {
+    if (add) gldm_dev::allow_dynamic_lds<PwBfAdd1Tag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<true, 2, 1>), 160 * 1024);
+    else gldm_dev::allow_dynamic_lds<PwBf1Tag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<false, 2, 1>), 160 * 1024);
+  } else if (split_f16 && add && nt == 3) gldm_dev::allow_dynamic_lds<PwBfAdd3Tag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<true, 3>), 160 * 1024);
   else if (split_f16 && nt == 3) gldm_dev::allow_dynamic_lds<PwBf3Tag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<false, 3>), 160 * 1024);
   else if (split_f16 && add) gldm_dev::allow_dynamic_lds<PwBfAddTag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<true, 2>), 160 * 1024);
   else if (split_f16) gldm_dev::allow_dynamic_lds<PwBfTag>(reinterpret_cast<const void *>(&pointwise_mlp_sp_kernel<false, 2>), 160 * 1024);
@@ -5122,7 +5157,10 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
   int grid = cu_count() * per_cu;
   if (grid > a.total_tiles) grid = a.total_tiles;
-  if (split_f16 && add && nt == 3) hipLaunchKernelGGL((pointwise_mlp_sp_kernel<true, 3>), dim3(grid), dim3(512), lds_bytes, stream, a);
+  if (split_f16 && mu == 1 && nt == 2) {
+    if (add) hipLaunchKernelGGL((pointwise_mlp_sp_kernel<true, 2, 1>), dim3(grid), dim3(512), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((pointwise_mlp_sp_kernel<false, 2, 1>), dim3(grid), dim3(512), lds_bytes, stream, a);
+  } else if (split_f16 && add && nt == 3) hipLaunchKernelGGL((pointwise_mlp_sp_kernel<true, 3>), dim3(grid), dim3(512), lds_bytes, stream, a);
   else if (split_f16 && nt == 3) hipLaunchKernelGGL((pointwise_mlp_sp_kernel<false, 3>), dim3(grid), dim3(512), lds_bytes, stream, a);
   else if (split_f16 && add) hipLaunchKernelGGL((pointwise_mlp_sp_kernel<true, 2>), dim3(grid), dim3(512), lds_bytes, stream, a);
   else if (split_f16) hipLaunchKernelGGL((pointwise_mlp_sp_kernel<false, 2>), dim3(grid), dim3(512), lds_bytes, stream, a);
