@@ -70,7 +70,7 @@ _SIGNATURES = {
     "gldm_pointwise_mlp2_f16x2": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "gldm_sa_mlp_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "gldm_sa_mlp_forward_f16x2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "gldm_sa_mlp_forward_f16x2_pre": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gldm_sa_mlp_forward_f16x2_pre": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 
 

@@ -3453,6 +3453,7 @@ struct SaArgs {
   // index in `weights` of W1a [c1][4] (the coordinate columns x, y, z, 0).  The MFMA layers are then layers 2.. of the module.
   const float *pre;
   int c1, wa_off;
+  int pre_bcast;   // pre is ONE row [c1] for every point (a module without features: the row is the folded bias b1)
 };
 
 __global__ __launch_bounds__(Geo<64>::kThreads, 2) void sa_mlp_kernel(const SaArgs a) {
@@ -4083,29 +4084,69 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
     } else {
       // stage + split: item = (8-channel group, column)
       const float *xb = a.x + (size_t)b * a.cin * a.n + c0;
-      float inv = 1.0f;
-      if (a.ranged) {   // a first pass over the tile for its largest magnitude (the second one then reads it from L2 / L1)
-        float mx = 0.f;
-        for (int i = tid; i < (a.cin >> 3) * NC; i += 512) {
-          const int kg = i / NC, scol = i - kg * NC, row = 8 * kg;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(scol < 16 * ntv ? xb[(size_t)(row + j) * a.n + scol] : 0.f));
-        }
-        range_publish(mx);
-        __syncthreads();
-        s_main = range_pow2(range_read());
-        inv = pow2_inv(s_main);
-      }
-      for (int i = tid; i < (a.cin >> 3) * NC; i += 512) {
+      // The tile's range scale needs its largest magnitude before anything is split.  Up to kHold items per thread (cin <=
+      // 256 at 32 points: the feature-propagation and per-point layers of the set-abstraction backbones) the staged values
+      // wait in registers across the exchange barrier: ONE pass over the input.  Wider tiles take a first pass for the maximum
+      // and read the tile again (from L2): measured on the feature-propagation layers of PointNet2SSG, the two-pass form alone
+      // cost 60-90 % of a launch.
+      constexpr int kHold = 2;
+      const int items = (a.cin >> 3) * NC;
+      auto stage_store = [&](int i, float (&v)[8], float inv) {
         const int kg = i / NC, scol = i - kg * NC, row = 8 * kg;
-        float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (scol < 16 * ntv ? xb[(size_t)(row + j) * a.n + scol] : 0.f) * inv;
+        for (int j = 0; j < 8; ++j) v[j] *= inv;
         u32x4 pl[kSplit];
         split_planes8(v, pl);
         lds_u4 *d = (lds_u4 *)planes + (((row >> 5) * kSplit) * 4 + ((row >> 3) & 3)) * NC + scol;
         d[0] = pl[0];
         d[4 * NC] = pl[1];
+      };
+      auto stage_load = [&](int i, float (&v)[8]) {
+        const int kg = i / NC, scol = i - kg * NC, row = 8 * kg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = scol < 16 * ntv ? xb[(size_t)(row + j) * a.n + scol] : 0.f;
+      };
+      if (NT == 2 && a.ranged && items <= kHold * 512) {   // (48-point tiles exist for inputs of 640 rows and more only)
+        float hv[kHold][8];
+        float mx = 0.f;
+#pragma unroll
+        for (int q = 0; q < kHold; ++q) {
+          const int i = tid + 512 * q;
+          if (i < items) {
+            stage_load(i, hv[q]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(hv[q][j]));
+          }
+        }
+        range_publish(mx);
+        __syncthreads();
+        s_main = range_pow2(range_read());
+        const float inv = pow2_inv(s_main);
+#pragma unroll
+        for (int q = 0; q < kHold; ++q) {
+          const int i = tid + 512 * q;
+          if (i < items) stage_store(i, hv[q], inv);
+        }
+      } else {
+        float inv = 1.0f;
+        if (a.ranged) {
+          float mx = 0.f;
+          for (int i = tid; i < items; i += 512) {
+            float v[8];
+            stage_load(i, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(v[j]));
+          }
+          range_publish(mx);
+          __syncthreads();
+          s_main = range_pow2(range_read());
+          inv = pow2_inv(s_main);
+        }
+        for (int i = tid; i < items; i += 512) {
+          float v[8];
+          stage_load(i, v);
+          stage_store(i, v, inv);
+        }
       }
     }
     GLDM_PW_STAMP(2);
@@ -4669,7 +4710,7 @@ __global__ __launch_bounds__(512, (PRE && QUADS <= 4) ? 4 : 2) void sa_mlp3_kern
         // pre is POINT-major, [b][n][c1]: a neighbour's rows are one run of c1 floats, a thread's row quad one 16-byte load
         // (channel-major, the 4-byte gathers of a tile were 8192 cache-line requests: the texture addresser, not the
         // matrix pipe, bounded the kernel -- a layer less changed nothing)
-        const f32x4 *prow = reinterpret_cast<const f32x4 *>(a.pre + ((size_t)b * a.n + id) * a.c1);
+        const f32x4 *prow = reinterpret_cast<const f32x4 *>(a.pre + (a.pre_bcast ? (size_t)0 : ((size_t)b * a.n + id) * a.c1));
 #pragma unroll
         for (int e = 0; e < 3; ++e) dxyz[st][e] = pts[e * a.n + id] - ctr[e * a.m + jc];
         dxyz[st][3] = live ? 1.0f : 0.0f;
@@ -5230,7 +5271,7 @@ GLDM_API int gldm_pointwise_mlp2_f16x2(const float *x, const float *w0_packed, c
 
 namespace {
 // pre != nullptr: the first layer hoisted (sa_mlp3_kernel<.., PRE>): `features` unused, c = 0, cin_pad[0] = rows of pre
-int launch_sa3(const float *points, const float *centers, const float *features, const float *pre, int wa_off,
+int launch_sa3(const float *points, const float *centers, const float *features, const float *pre, int wa_off, int pre_bcast,
                const int32_t *idx, const float *weights, int b, int c, int n, int m, int u,
                int n_layers, const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off,
                const int32_t *b_off, const float *range_gain, float *out, gldm_stream_t stream) {
@@ -5244,7 +5285,7 @@ int launch_sa3(const float *points, const float *centers, const float *features,
   a.points = points; a.centers = centers; a.feat = c > 0 ? features : nullptr; a.idx = idx; a.weights = weights;
   a.out = out; a.c = c; a.n = n; a.m = m; a.u = u; a.n_layers = n_layers;
   a.ranged = range_gain != nullptr;
-  a.pre = pre; a.c1 = pre ? cin_pad[0] : 0; a.wa_off = wa_off;
+  a.pre = pre; a.c1 = pre ? cin_pad[0] : 0; a.wa_off = wa_off; a.pre_bcast = pre_bcast ? 1 : 0;
   for (int l = 0; l < n_layers && range_gain; ++l) {
     a.gain_r[l] = range_gain[2 * l];
     a.gain_b[l] = range_gain[2 * l + 1];
@@ -5278,10 +5319,14 @@ int launch_sa3(const float *points, const float *centers, const float *features,
   for (int l = 0; l < n_layers; ++l) kb_ok = kb_ok && (cin_pad[l] == 32 || cin_pad[l] == 64 || cin_pad[l] == 128);
   int sub = kb_ok ? (int)(((size_t)160 * 1024 - kRngBytes) / tile_bytes) : 1;
   if (sub > 4) sub = 4;
+  // two workgroups of two tiles each rather than one of four where LDS allows (the kernel fits 128 registers): the phases of
+  // one overlap the other's (SSG-SA1 at 256 clouds: 1.55 -> 1.47 ms)
+  if (sub > 2 && (tile_bytes * 2 + kRngBytes) * 2 <= (size_t)160 * 1024) sub = 2;
   while (sub > 1 && (total + sub - 1) / sub < 2 * cu_count()) --sub;
   if (sub > 1) {
     const int supers = (total + sub - 1) / sub;
-    const int grid = supers < cu_count() ? supers : cu_count();
+    const int per_cu_m = (tile_bytes * sub + kRngBytes) * 2 <= (size_t)160 * 1024 ? 2 : 1;
+    const int grid = supers < cu_count() * per_cu_m ? supers : cu_count() * per_cu_m;
     if (cin_pad[0] == 32) {
       struct Sa3mTag { int site; };
       gldm_dev::allow_dynamic_lds<Sa3mTag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<4, 1>), 160 * 1024);
@@ -5317,17 +5362,17 @@ GLDM_API int gldm_sa_mlp_forward_f16x2(const float *points, const float *centers
                                         const int32_t *idx, const float *weights, int b, int c, int n, int m, int u,
                                         int n_layers, const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off,
                                         const int32_t *b_off, const float *range_gain, float *out, gldm_stream_t stream) {
-  return launch_sa3(points, centers, features, nullptr, 0, idx, weights, b, c, n, m, u, n_layers, cin_pad, cout, w3_off, b_off,
+  return launch_sa3(points, centers, features, nullptr, 0, 0, idx, weights, b, c, n, m, u, n_layers, cin_pad, cout, w3_off, b_off,
                     range_gain, out, stream);
 }
 
-GLDM_API int gldm_sa_mlp_forward_f16x2_pre(const float *points, const float *centers, const float *pre, const int32_t *idx,
-                                            const float *weights, int wa_off, int b, int n, int m, int u, int n_layers,
+GLDM_API int gldm_sa_mlp_forward_f16x2_pre(const float *points, const float *centers, const float *pre, int pre_broadcast,
+                                            const int32_t *idx, const float *weights, int wa_off, int b, int n, int m, int u, int n_layers,
                                             const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off,
                                             const int32_t *b_off, const float *range_gain, float *out, gldm_stream_t stream) {
   if (!pre) return GLDM_ERR_INVALID_ARG;
-  return launch_sa3(points, centers, nullptr, pre, wa_off, idx, weights, b, 0, n, m, u, n_layers, cin_pad, cout, w3_off, b_off,
-                    range_gain, out, stream);
+  return launch_sa3(points, centers, nullptr, pre, wa_off, pre_broadcast, idx, weights, b, 0, n, m, u, n_layers, cin_pad, cout, w3_off,
+                    b_off, range_gain, out, stream);
 }
 
 

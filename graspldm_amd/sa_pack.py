@@ -9,6 +9,9 @@ from . import _lib as L
 from .r1d_pack import SplitRangeError, _Buf, mfma_a_fragments, mfma_a_fragments_f16x2
 
 _OK_MTILES = (1, 2, 4, 8, 12, 16)
+# modules without features (first layer = three coordinate products + bias): on the VALU of the gather threads (the hoisted
+# form with a broadcast row) instead of a K = 32 block of the matrix pipe -- set by measurement, see DESIGN.md
+PRE_WITHOUT_FEATURES = False   # SSG-SA1 (3 -> 64 -> 64 -> 128, 512 centres x 64): 1.81 ms hoisted against 1.56 ms in the multi-tile form
 
 
 def fold_conv_bn(conv, bn):
@@ -174,15 +177,16 @@ class SaMlpPlan:
         couts = [lay[3 * i].weight.shape[0] for i in range(self.n_layers)]
         # first layer per POINT instead of per (centre, neighbour) pair: whenever there are features to hoist and a layer
         # behind it (every point sits in m u / n balls on average: worth it from 2 upwards)
-        if c > 0 and self.n_layers >= 2 and m * u >= 2 * n and couts[0] <= 256 and split_plan_ok(couts[:1] + couts[1:-1], couts[1:], u):
+        hoist = (c > 0 and m * u >= 2 * n) or (c == 0 and PRE_WITHOUT_FEATURES)
+        if hoist and self.n_layers >= 2 and couts[0] <= 256 and split_plan_ok(couts[:1] + couts[1:-1], couts[1:], u):
             try:
                 w3, cin_pad, cout, w_off, b_off, gain, wa_off, w1b, b1p, c1p = self._pre_plan()
             except SplitRangeError:
                 w3 = None
             if w3 is not None:
-                pre = self._first_layer_per_point(features, w1b, b1p)
+                pre = self._first_layer_per_point(features, w1b, b1p) if c > 0 else b1p   # no features: the row b1 for every point
                 with torch.cuda.device(points.device):
-                    L.call("gldm_sa_mlp_forward_f16x2_pre", L.ptr(points), L.ptr(centers), L.ptr(pre), L.ptr(idx), L.ptr(w3),
+                    L.call("gldm_sa_mlp_forward_f16x2_pre", L.ptr(points), L.ptr(centers), L.ptr(pre), 0 if c > 0 else 1, L.ptr(idx), L.ptr(w3),
                            wa_off, b, n, m, u, self.n_layers - 1, ctypes.cast(cin_pad, ctypes.c_void_p),
                            ctypes.cast(cout, ctypes.c_void_p), ctypes.cast(w_off, ctypes.c_void_p),
                            ctypes.cast(b_off, ctypes.c_void_p), ctypes.cast(gain, ctypes.c_void_p), L.ptr(out),

@@ -341,10 +341,12 @@ int gldm_sa_mlp_forward_f16x2(const float *points /*[b,3,n]*/, const float *cent
  * c1 floats and a gather thread's four rows one 16-byte load), the gather fetches a neighbour's rows of `pre` instead of its
  * features, adds the three coordinate products (W1a [c1][4] = columns x, y, z, 0 at float index wa_off of `weights`) and
  * applies the ReLU.  The layer tables describe layers 2.. of the module (cin_pad[0] = c1 = rows of pre, a multiple of 32;
- * rows the module does not have carry zero weights and zero pre).  Same arithmetic for layers 2.., the first layer's
+ * rows the module does not have carry zero weights and zero pre).  pre_broadcast != 0: a module WITHOUT features -- its first
+ * layer is W1a (x - c) + b1, `pre` is the one row b1 [c1] shared by every point.  Same arithmetic for layers 2.., the first layer's
  * products are f32 (VALU) + the caller's GEMM: results differ from gldm_sa_mlp_forward_f16x2 in the last bits. */
 int gldm_sa_mlp_forward_f16x2_pre(const float *points /*[b,3,n]*/, const float *centers /*[b,3,m]*/,
-                                   const float *pre /*[b,n,c1]*/, const int32_t *idx /*[b,m,u]*/, const float *weights,
+                                   const float *pre /*[b,n,c1]; [c1] with pre_broadcast*/, int pre_broadcast,
+                                   const int32_t *idx /*[b,m,u]*/, const float *weights,
                                    int wa_off, int b, int n, int m, int u, int n_layers,
                                    const int32_t *cin_pad, const int32_t *cout, const int32_t *w3_off, const int32_t *b_off,
                                    const float *range_gain /*host [n_layers][2] or NULL*/,
