@@ -548,14 +548,19 @@ def main():
           fsa()
           t_fsa = event_time(fsa, 10)
           sa_flop = B * 2 * Ms * Us * (131 * 128 + 128 * 128 + 128 * 256)
-          sa_exec = B * 2 * Ms * Us * (160 * 128 + 128 * 128 + 128 * 256)   # input rows padded 131 -> 160 (five 32-channel blocks)
-          kernels.append(dict(kernel="sa_mlp3_kernel (SSG SA2 fused gather + MLP 131-128-128-256 + max, 64-column tiles on split-f16 planes)",
+          # executed on the matrix pipe since round 6: the first layer's feature part once per POINT (N x 128 x 128), layers
+          # 2 and 3 per (centre, neighbour) pair; its three coordinate products run on the VALU of the gather threads
+          sa_exec = B * 2 * (Ns * 128 * 128 + Ms * Us * (128 * 128 + 128 * 256))
+          kernels.append(dict(kernel="SSG SA2 set-abstraction MLP 131-128-128-256 + max: pointwise_mlp_sp_kernel<false, 2, 1> (first layer per "
+                                     "point, point-major) + sa_mlp3_kernel<1, 4, true> (gather + layers 2-3 + max, 64-column tiles on split-f16 planes)",
                               bound="mfma", avg_ms=t_fsa * 1e3, achieved=sa_flop / t_fsa / 1e12, peak=PEAK_SPLIT_TFLOPS,
                               unit="TFLOP/s", frac=sa_flop / t_fsa / 1e12 / PEAK_SPLIT_TFLOPS,
                               executed_frac=SPLIT_PRODUCTS * sa_exec / t_fsa / 1e12 / PEAK_F16_MFMA_TFLOPS,
                               hbm_bytes_avoided=B * 4 * (Cs + 3) * Ms * Us,
-                              note="gldm_sa_mlp_forward_f16x2: GEMMs as three f16 partial products per f32 product (round 3: "
-                                   "sa_mlp2_kernel on the f32 matrix pipe, 2.79 ms = 0.63 of its peak)"))
+                              note="both launches timed together; algorithmic FLOP = the module as the reference evaluates it (every "
+                                   "layer per (centre, neighbour) pair).  gldm_pointwise_mlp_f16x2_pm + gldm_sa_mlp_forward_f16x2_pre: "
+                                   "W1 [x - c; f] = W1a (x - c) + W1b f, the second term once per point (round 5, all three layers per "
+                                   "pair in one launch: 1.49-1.56 ms = 0.22)"))
           # ---- BASELINE.json configs[1]: ONE object (B = 1, G grasps), latency per stage and end to end
           if args.scheduler == "ddim":
               pc1, x1 = pcs[:1].contiguous(), x_T[:G].contiguous()
