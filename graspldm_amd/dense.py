@@ -226,16 +226,23 @@ def concat_conv_bn_relu(xa, xb, conv, bn):
         try:
             w3 = mfma_a_fragments_f16x2(wide.detach().float().cpu()).to(xa.device)
             w_other = wa if broadcast else (mfma_a_fragments_f16x2(wb.detach().float().cpu()).to(xa.device) if both_wide else wb)
+            # broadcast form: Wa xa over the clouds is itself a wide GEMM ([1, Ca, B] columns = clouds) where Ca allows
+            wa3 = mfma_a_fragments_f16x2(wa.detach().float().cpu()).to(xa.device) if broadcast and split_supported(ca) else None
         except SplitRangeError:
             return None   # a weight beyond the f16 range: the caller concatenates and takes the plain (f32) path
-        hit = (key, w3, w_other, b, torch.zeros_like(b))
+        hit = (key, w3, w_other, b, torch.zeros_like(b), wa3)
         conv.__dict__["_gldm_concat"] = hit
         publish(xa.device)
-    _, w3, w_other, b, zero_b = hit
+    _, w3, w_other, b, zero_b, wa3 = hit
     y = torch.empty((bsz, cout, n), dtype=torch.float32, device=xa.device)
     if broadcast:
-        # Wa xa for every cloud at once: [1, Ca, B] columns = clouds
-        g = _gemm_bias_act(xa[:, :, 0].t().contiguous().unsqueeze(0), w_other, None, False)[0].t().contiguous()   # [B, Cout]
+        # Wa xa for every cloud at once: [1, Ca, B] columns = clouds (the split launch where the cloud count is a multiple of
+        # 32 and Ca of 128, else the any-shape kernel)
+        x1 = xa[:, :, 0].t().contiguous().unsqueeze(0)
+        if wa3 is not None and split_mlp_supported(x1, ca, cout):
+            g = pointwise_mlp(x1, wa3, zero_b, cout, False, split=True)[0][0].t().contiguous()                      # [B, Cout]
+        else:
+            g = _gemm_bias_act(x1, w_other, None, False)[0].t().contiguous()
         xw, add, strides, bias = xb.contiguous(), g, (cout, 1, 0), b
     elif both_wide:
         add = pointwise_mlp(xb.contiguous(), w_other, b, cout, False, split=True)[0]                             # [B, Cout, N] = Wb xb + b

@@ -618,7 +618,8 @@ def test_pointwise_mlp_split_f16(b, cin0, cin, cout, n, hout):
 
 
 @pytest.mark.parametrize("b,ca,na,cb,n,cout", [(3, 128, 1024, 3, 1024, 128), (2, 256, 128, 3, 128, 256), (4, 1024, 1, 256, 128, 256),
-                                               (2, 128, 64, 6, 64, 64), (2, 256, 512, 128, 512, 256), (3, 128, 96, 128, 96, 64)])
+                                               (2, 128, 64, 6, 64, 64), (2, 256, 512, 128, 512, 256), (3, 128, 96, 128, 96, 64),
+                                               (32, 1024, 1, 256, 64, 256)])
 def test_first_layer_of_a_concatenation_without_the_concatenation(b, ca, na, cb, n, cout):
     """dense.concat_conv_bn_relu: relu(BN(conv(cat([xa, xb])))) as the split-f16 launch over the wide part with the other
     part as its addend (gldm_pointwise_mlp_f16x2_add) -- a few coordinate rows as a [B, Cout, N] tensor, or ONE centre's
