@@ -65,3 +65,27 @@ def test_backend_rejects_cpu_tensors_like_the_reference():
     from graspldm_amd.backend import _backend
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         _backend.ball_query(torch.zeros(1, 3, 4), torch.zeros(1, 3, 8), 0.1, 2)
+
+
+def test_dpp_hazard_scan_flags_a_close_write(tmp_path):
+    """tools/isa/dpp_hazard_scan.py (part of tools/isa/lint.sh): a VALU write one wait state in front of a DPP read of the
+    same register is reported, the same pair behind an `s_nop 1` is not."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = tmp_path / "bad.s"
+    bad.write_text("0000000000001000 <my_kernel>:\n"
+                   "\tv_add_f32_e32 v5, v1, v2                                 // 000000001000: 020A0501\n"
+                   "\tv_max_f32_dpp v6, v5, v5 row_ror:4 row_mask:0xf bank_mask:0xf // 000000001004: 160C0AFA\n"
+                   "\ts_endpgm\n")
+    good = tmp_path / "good.s"
+    good.write_text("0000000000001000 <my_kernel>:\n"
+                    "\tv_add_f32_e32 v5, v1, v2\n\ts_nop 1\n"
+                    "\tv_max_f32_dpp v6, v5, v5 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+                    "\tv_mov_b32_e32 v9, v1\n\tv_mov_b32_e32 v10, v1\n\tv_mov_b32_e32 v11, v1\n"
+                    "\tv_mov_b32_dpp v7, v9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_endpgm\n")
+    scan = os.path.join(root, "tools", "isa", "dpp_hazard_scan.py")
+    r = subprocess.run([sys.executable, scan, str(bad), "my_kernel"], capture_output=True, text=True)
+    assert r.returncode == 1 and "1 VALU-write" in r.stdout, r.stdout
+    r = subprocess.run([sys.executable, scan, str(good), "my_kernel"], capture_output=True, text=True)
+    assert r.returncode == 0 and "2 DPP instructions, 0 VALU-write" in r.stdout, r.stdout
