@@ -111,7 +111,7 @@ class _HipBackend:
         b, c, n = features.shape
         r = int(resolution)
         dev = features.device
-        ind = torch.zeros((b, n), dtype=torch.int32, device=dev)
+        ind = torch.empty((b, n), dtype=torch.int32, device=dev)   # every point's entry is written (a fill launch before)
         out = torch.empty((b, c, r ** 3), dtype=torch.float32, device=dev)  # every voxel is written by the C entry point
         cnt = torch.empty((b, r ** 3), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
