@@ -5315,19 +5315,25 @@ int launch_sa3(const float *points, const float *centers, const float *features,
   // narrow nets (32-row inputs, every K in {32, 64, 128}): the multi-tile kernel -- the layer's weights once per
   // workgroup pass, `sub` tiles' planes side by side in LDS (SSG SA1: three 48 KiB tiles, 2.52 -> 2.07 ms).  Two
   // co-resident workgroups of one tile each (the kernel fits 128 registers) measured slower: 2.40 ms.
-  bool kb_ok = !pre && (cin_pad[0] == 32 || cin_pad[0] == 64);   // one or two row quads per gather thread
+  // one or two row quads per gather thread; the hoisted form (pre): the multi-tile kernel with two tiles per pass
+  bool kb_ok = cin_pad[0] == 32 || cin_pad[0] == 64;
   for (int l = 0; l < n_layers; ++l) kb_ok = kb_ok && (cin_pad[l] == 32 || cin_pad[l] == 64 || cin_pad[l] == 128);
   int sub = kb_ok ? (int)(((size_t)160 * 1024 - kRngBytes) / tile_bytes) : 1;
   if (sub > 4) sub = 4;
   // two workgroups of two tiles each rather than one of four where LDS allows (the kernel fits 128 registers): the phases of
   // one overlap the other's (SSG-SA1 at 256 clouds: 1.55 -> 1.47 ms)
   if (sub > 2 && (tile_bytes * 2 + kRngBytes) * 2 <= (size_t)160 * 1024) sub = 2;
+  if (pre && sub > 2) sub = 2;
   while (sub > 1 && (total + sub - 1) / sub < 2 * cu_count()) --sub;
   if (sub > 1) {
     const int supers = (total + sub - 1) / sub;
     const int per_cu_m = (tile_bytes * sub + kRngBytes) * 2 <= (size_t)160 * 1024 ? 2 : 1;
     const int grid = supers < cu_count() * per_cu_m ? supers : cu_count() * per_cu_m;
-    if (cin_pad[0] == 32) {
+    if (pre) {
+      struct Sa3mPreTag { int site; };
+      gldm_dev::allow_dynamic_lds<Sa3mPreTag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<2, 2, true>), 160 * 1024);
+      hipLaunchKernelGGL((sa_mlp3_kernel<2, 2, true>), dim3(grid), dim3(512), tile_bytes * sub + kRngBytes, s, a, blocks_a, blocks_b, sub, tpc, total);
+    } else if (cin_pad[0] == 32) {
       struct Sa3mTag { int site; };
       gldm_dev::allow_dynamic_lds<Sa3mTag>(reinterpret_cast<const void *>(&sa_mlp3_kernel<4, 1>), 160 * 1024);
       hipLaunchKernelGGL((sa_mlp3_kernel<4, 1>), dim3(grid), dim3(512), tile_bytes * sub + kRngBytes, s, a, blocks_a, blocks_b, sub, tpc, total);

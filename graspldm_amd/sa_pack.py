@@ -11,7 +11,9 @@ from .r1d_pack import SplitRangeError, _Buf, mfma_a_fragments, mfma_a_fragments_
 _OK_MTILES = (1, 2, 4, 8, 12, 16)
 # modules without features (first layer = three coordinate products + bias): on the VALU of the gather threads (the hoisted
 # form with a broadcast row) instead of a K = 32 block of the matrix pipe -- set by measurement, see DESIGN.md
-PRE_WITHOUT_FEATURES = False   # SSG-SA1 (3 -> 64 -> 64 -> 128, 512 centres x 64): 1.81 ms hoisted against 1.56 ms in the multi-tile form
+# SSG-SA1 (3 -> 64 -> 64 -> 128, 512 centres x 64 at 256 clouds): hoisted in the single-tile kernel 1.81 ms, first layer on the
+# matrix pipe in the multi-tile kernel 1.47 ms, hoisted in the multi-tile kernel (two tiles per pass) 1.22 ms
+PRE_WITHOUT_FEATURES = True
 
 
 def fold_conv_bn(conv, bn):
