@@ -3803,6 +3803,8 @@ struct PwArgs {
   int ranged, rng_off;
   float gain0_r, gain0_b;
   int y_point_major;   // split-f16 kernel: y is [b, n, cout] (a lane's four consecutive rows of a column: one 16-byte store)
+  int cin_rows;        // split-f16 kernel without a front layer: rows x really has (cin = that padded to whole 128-deep trips
+                       // of the weight ring: the planes of the rows beyond are zero, like the weights' columns there)
 };
 
 __global__ __launch_bounds__(512, 2) void pointwise_mlp_kernel(const PwArgs a) {
@@ -4083,7 +4085,7 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
       }
     } else {
       // stage + split: item = (8-channel group, column)
-      const float *xb = a.x + (size_t)b * a.cin * a.n + c0;
+      const float *xb = a.x + (size_t)b * a.cin_rows * a.n + c0;
       // The tile's range scale needs its largest magnitude before anything is split.  Up to kHold items per thread (cin <=
       // 256 at 32 points: the feature-propagation and per-point layers of the set-abstraction backbones) the staged values
       // wait in registers across the exchange barrier: ONE pass over the input.  Wider tiles take a first pass for the maximum
@@ -4103,8 +4105,9 @@ __global__ __launch_bounds__(512, 2) void pointwise_mlp_sp_kernel(const PwArgs a
       };
       auto stage_load = [&](int i, float (&v)[8]) {
         const int kg = i / NC, scol = i - kg * NC, row = 8 * kg;
+        const bool in = scol < 16 * ntv && row < a.cin_rows;   // (cin_rows % 8 == 0: whole groups)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = scol < 16 * ntv ? xb[(size_t)(row + j) * a.n + scol] : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = in ? xb[(size_t)(row + j) * a.n + scol] : 0.f;
       };
       if (NT == 2 && a.ranged && items <= kHold * 512) {   // (48-point tiles exist for inputs of 640 rows and more only)
         float hv[kHold][8];
@@ -5104,11 +5107,15 @@ GLDM_API int gldm_pose_epilogue(const float *tmrp, const float *logit, const flo
 
 namespace {
 int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0, const float *w, const float *bias, int b,
-                     int cin, int cout, int n, int relu, const float *head_w, const float *head_b, int hout, float *y,
+                     int cin_arg, int cout, int n, int relu, const float *head_w, const float *head_b, int hout, float *y,
                      float *z, hipStream_t stream, bool split_f16 = false, const float *add = nullptr, long long add_bs = 0,
                      long long add_rs = 0, long long add_cs = 0, const float *front_gain = nullptr, bool y_point_major = false) {
   if (y_point_major && (!split_f16 || !y)) return GLDM_ERR_UNSUPPORTED;
   if (add && !split_f16) return GLDM_ERR_UNSUPPORTED;
+  // The split launch without a front layer takes any multiple of 8 input rows: K is padded to whole 128-deep trips of its
+  // weight ring (the caller's fragments carry zero columns there: r1d_pack.mfma_a_fragments_f16x2 of the padded matrix)
+  const int cin_rows = cin_arg;
+  const int cin = (split_f16 && !w0 && cin_arg > 0 && (cin_arg & 7) == 0) ? (cin_arg + 127) & ~127 : cin_arg;
   if (!x || !w || !bias || b <= 0 || cin <= 0 || cout <= 0 || n <= 0) return GLDM_ERR_INVALID_ARG;
   if (!y && !head_w) return GLDM_ERR_INVALID_ARG;
   if (head_w && (!z || hout <= 0 || hout > 16)) return GLDM_ERR_INVALID_ARG;
@@ -5187,6 +5194,7 @@ int launch_pointwise(const float *x, const float *w0, const float *b0, int cin0,
   a.add = add; a.add_bs = add_bs; a.add_rs = add_rs; a.add_cs = add_cs;
   // range scales: a lone layer measures its input tile; with a layer in front the caller's gain bounds its output
   a.y_point_major = y_point_major ? 1 : 0;
+  a.cin_rows = cin_rows;
   a.rng_off = ticket_off + 4;
   a.ranged = split_f16 && (!w0 || front_gain);
   if (w0 && front_gain) {

@@ -64,11 +64,29 @@ def pack_head(wh):
     return mfma_a_fragments(w)
 
 
+SPLIT_PAD_MIN_CIN = 32   # narrowest input the split launch takes with K padded to 128 (below: the lane-per-point kernel)
+
+
 def split_supported(cin, cin0=0):
     """The split-f16 form of the fused launch (gldm_pointwise_mlp*_f16x2): A ring of four 32-deep blocks, the tile
-    as planes (48 floats per channel) + the front layer's f32 tile (split once per wave into registers: cin0 <= 96)."""
+    as planes (48 floats per channel) + the front layer's f32 tile (split once per wave into registers: cin0 <= 96).
+    Without a front layer any multiple of 8 input rows from 32 up: K is zero-padded to whole trips of the ring
+    (split_fragments)."""
     from .numerics import split_enabled
-    return split_enabled() and cin % 128 == 0 and cin0 % 32 == 0 and cin0 <= 96 and 4 * (48 * cin + 32 * cin0) + 16 <= 160 * 1024
+    kpad = (cin + 127) // 128 * 128
+    ok_k = cin % 128 == 0 or (cin0 == 0 and cin % 8 == 0 and cin >= SPLIT_PAD_MIN_CIN)
+    return split_enabled() and ok_k and cin0 % 32 == 0 and cin0 <= 96 and 4 * (48 * kpad + 32 * cin0) + 16 <= 160 * 1024
+
+
+def split_fragments(w2d):
+    """Split-f16 A fragments of [M, K] with K zero-padded to a multiple of 128 (the K gldm_pointwise_mlp_f16x2 walks)."""
+    from .r1d_pack import mfma_a_fragments_f16x2
+    w = w2d.detach().float().cpu()
+    k = w.shape[1]
+    kp = (k + 127) // 128 * 128
+    if kp != k:
+        w = torch.cat([w, torch.zeros(w.shape[0], kp - k)], dim=1)
+    return mfma_a_fragments_f16x2(w)
 
 
 def fused_mlp_supported(x, cin, cout):
@@ -79,8 +97,8 @@ def fused_mlp_supported(x, cin, cout):
 def split_mlp_supported(x, cin, cout):
     """The split-f16 launch on its own (gldm_pointwise_mlp_f16x2): output rows in units of 32 (fewer than 256 leave waves
     idle, still several times the any-shape kernel's rate: the 128-row feature-propagation layers of PointNet++ / PVCNN2)."""
-    return (x.ndim == 3 and x.is_contiguous() and cout % 32 == 0 and cout >= 64 and x.shape[-1] % 32 == 0
-            and split_supported(cin))
+    rows_ok = cout >= 64 and (cout % 32 == 0 or (cout < 256 and cout % 16 == 0))
+    return x.ndim == 3 and x.is_contiguous() and rows_ok and x.shape[-1] % 32 == 0 and split_supported(cin)
 
 
 def fused_mlp2_supported(x, cin0, cin, cout):
@@ -156,8 +174,8 @@ def folded_conv_bn(conv, bn, device):
                 # split fragments: main layers of the split launch (cin % 128 == 0) and its narrow front layers (cin <= 128)
                 if split_supported(w.shape[1]) or w.shape[1] <= 128:
                     ws = mfma_a_fragments_f16x2(w.detach().float().cpu()).to(device)
-            elif w.shape[0] % 32 == 0 and w.shape[0] >= 64 and split_supported(w.shape[1]):
-                ws = mfma_a_fragments_f16x2(w.detach().float().cpu()).to(device)   # 64 .. 224 output rows: split launch only
+            elif w.shape[0] % 16 == 0 and w.shape[0] >= 64 and split_supported(w.shape[1]):
+                ws = split_fragments(w).to(device)   # 64 .. 240 output rows / K padded to the ring: split launch only
         except SplitRangeError:
             ws = None
         hit = (key, w, b, wp, ws, range_gain(w, b))
@@ -179,7 +197,7 @@ def pointwise_conv_bn_relu(x, conv, bn):
     w, b, wp, ws = folded_conv_bn(conv, bn, x.device)
     x = x.float()
     if wp is not None and fused_mlp_supported(x, w.shape[1], w.shape[0]):
-        if ws is not None and split_supported(w.shape[1]):   # (narrow layers keep split fragments as FRONT layers only)
+        if ws is not None and w.shape[1] % 128 == 0 and split_supported(w.shape[1]):   # (narrow layers keep UNPADDED fragments, as front layers)
             return pointwise_mlp(x, ws, b, w.shape[0], True, split=True)[0]
         return pointwise_mlp(x, wp, b, w.shape[0], True)[0]
     if wp is None and ws is not None and split_mlp_supported(x, w.shape[1], w.shape[0]):
@@ -224,10 +242,10 @@ def concat_conv_bn_relu(xa, xb, conv, bn):
         wa, wb = w[:, :ca].contiguous(), w[:, ca:].contiguous()
         wide = wb if broadcast else wa
         try:
-            w3 = mfma_a_fragments_f16x2(wide.detach().float().cpu()).to(xa.device)
-            w_other = wa if broadcast else (mfma_a_fragments_f16x2(wb.detach().float().cpu()).to(xa.device) if both_wide else wb)
+            w3 = split_fragments(wide).to(xa.device)
+            w_other = wa if broadcast else (split_fragments(wb).to(xa.device) if both_wide else wb)
             # broadcast form: Wa xa over the clouds is itself a wide GEMM ([1, Ca, B] columns = clouds) where Ca allows
-            wa3 = mfma_a_fragments_f16x2(wa.detach().float().cpu()).to(xa.device) if broadcast and split_supported(ca) else None
+            wa3 = split_fragments(wa).to(xa.device) if broadcast and split_supported(ca) else None
         except SplitRangeError:
             return None   # a weight beyond the f16 range: the caller concatenates and takes the plain (f32) path
         hit = (key, w3, w_other, b, torch.zeros_like(b), wa3)

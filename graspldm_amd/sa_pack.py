@@ -157,7 +157,7 @@ class SaMlpPlan:
         if dense.split_mlp_supported(x, cin, c1p):
             if self._pre_ws is None:
                 try:
-                    self._pre_ws = mfma_a_fragments_f16x2(w1b.detach().float().cpu()).to(x.device)
+                    self._pre_ws = dense.split_fragments(w1b).to(x.device)
                 except SplitRangeError:
                     self._pre_ws = False
             if self._pre_ws is not False:

@@ -398,6 +398,8 @@ int gldm_linear_rows(const float *x /*[rows,n]*/, const float *w /*[nout,n]*/, c
  * too (cin0 % 32 == 0, cin0 <= 96; its f32 input tile is split once per wave into registers); `head_w_packed` stays f32
  * fragments.  cin % 128 == 0, cout % 32 == 0 (with a front layer or a head: % 256; fewer than 256 output rows leave waves
  * idle), n % 32 == 0, 4 (48 cin + 32 cin0) + 16 <= 160 KiB. */
+/* (ABI 10: without a front layer cin may be any multiple of 8 -- `w_split` then holds the fragments of W zero-padded to a
+ * multiple of 128 columns, the K the launch walks; cout any multiple of 16 below 256 rows, of 32 from there.) */
 int gldm_pointwise_mlp_f16x2(const float *x /*[b,cin,n]*/, const float *w_split, const float *bias /*[cout]*/,
                               int b, int cin, int cout, int n, int relu,
                               const float *head_w_packed, const float *head_bias, int hout,

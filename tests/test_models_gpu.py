@@ -577,7 +577,11 @@ def test_pointwise_mlp_two_layers_one_launch(b, cin0, cin, cout, n, hout):
                                                     (2, 0, 128, 256, 64, 0), (1, 0, 768, 1536, 96, 3),
                                                     (5, 0, 128, 256, 2048, 0), (5, 32, 256, 256, 2048, 0),
                                                     (3, 0, 128, 128, 1024, 0), (2, 0, 256, 128, 512, 0), (1, 0, 128, 64, 32, 0),
-                                                    (2, 0, 256, 224, 64, 0)])
+                                                    (2, 0, 256, 224, 64, 0),
+                                                    # round 6: K zero-padded to the ring's 128 (cin 48 / 64 / 320), units of
+                                                    # one m-tile below 256 rows (cout 96 / 80 / 240)
+                                                    (3, 0, 48, 96, 1024, 0), (2, 0, 64, 128, 512, 0), (1, 0, 320, 80, 96, 0),
+                                                    (2, 0, 64, 240, 64, 0)])
 def test_pointwise_mlp_split_f16(b, cin0, cin, cout, n, hout):
     """gldm_pointwise_mlp_f16x2 / gldm_pointwise_mlp2_f16x2 (both layers on the bf16 matrix pipe, every f32 operand
     split exactly into three bf16 numbers; units of output rows handed out to the waves at run time) against a torch-CPU
@@ -605,14 +609,15 @@ def test_pointwise_mlp_split_f16(b, cin0, cin, cout, n, hout):
         z_ref = (torch.einsum("oc,bcn->bon", wh.double(), y_ref) + bh.double().view(1, -1, 1)).float()
         head = (dense.pack_head(wh).cuda(), bh.cuda(), hout)
     assert dense.split_supported(cin, cin0)
-    y, z = dense.pointwise_mlp(x.cuda(), mfma_a_fragments_f16x2(w1).cuda(), b1.cuda(), cout, True, head=head, keep_y=True,
+    w1s = (dense.split_fragments(w1) if cin0 == 0 else mfma_a_fragments_f16x2(w1)).cuda()   # (K padded where cin % 128 != 0)
+    y, z = dense.pointwise_mlp(x.cuda(), w1s, b1.cuda(), cout, True, head=head, keep_y=True,
                                front=front, split=True)
     assert _err(y, y_ref.float()) < 2e-5 * max(1.0, y_ref.abs().max().item())
     if hout:
         assert _err(z, z_ref) < 2e-5 * max(1.0, z_ref.abs().max().item())
         # the head sum does not depend on which wave drew which unit of output rows: bitwise repeatable
         for _ in range(3):
-            _, z2 = dense.pointwise_mlp(x.cuda(), mfma_a_fragments_f16x2(w1).cuda(), b1.cuda(), cout, True, head=head,
+            _, z2 = dense.pointwise_mlp(x.cuda(), w1s, b1.cuda(), cout, True, head=head,
                                         keep_y=False, front=front, split=True)
             assert torch.equal(z2, z)
 
