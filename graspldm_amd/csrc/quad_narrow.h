@@ -77,8 +77,21 @@ __device__ __forceinline__ float pos_max(float v) { return dpp_max<0x128>(dpp_ma
 #define GLDM_DPP8_OPERANDS                                                                                             \
   : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])            \
   : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7])
-__device__ __forceinline__ void pos_max8(const float (&x)[8], float (&r)[8]) {   // r[i] = max over the sample's four positions of x[i]
-  asm(GLDM_DPP8("max") GLDM_DPP8_OPERANDS);
+// x[i] = max over the sample's four positions of x[i], IN PLACE -- on purpose: its callers hand it copies of accumulators.
+// Nobody checks hazards inside an asm statement, and a matrix instruction's result may be read by the VALU only 7-11 wait
+// states after it issued: an asm block must never take accumulators as operands as they leave the matrix pipe.  (Until round 6
+// this was r[i] = max(x[i]) with the copies coalesced away: in the 4-channel level's attention the first v_max_f32_dpp read a
+// k accumulator 3 wait states behind its v_mfma_f32_16x16x4_f32 -- a stale maximum now and then, which softmax's shift
+// invariance turns into last-bit noise: tools/isa/dpp_hazard_scan.py, second check.)  The copy is the compiler's v_mov, placed
+// behind the wait states it inserts itself.
+#define GLDM_DPP8_STAGE1I(op, i) "v_" op "_f32_dpp %" #i ", %" #i ", %" #i " row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void pos_max8(float (&x)[8]) {
+  asm("s_nop 1\n\t"
+      GLDM_DPP8_STAGE1I("max", 0) GLDM_DPP8_STAGE1I("max", 1) GLDM_DPP8_STAGE1I("max", 2) GLDM_DPP8_STAGE1I("max", 3)
+      GLDM_DPP8_STAGE1I("max", 4) GLDM_DPP8_STAGE1I("max", 5) GLDM_DPP8_STAGE1I("max", 6) GLDM_DPP8_STAGE1I("max", 7)
+      GLDM_DPP8_STAGE2("max", 0) GLDM_DPP8_STAGE2("max", 1) GLDM_DPP8_STAGE2("max", 2) GLDM_DPP8_STAGE2("max", 3)
+      GLDM_DPP8_STAGE2("max", 4) GLDM_DPP8_STAGE2("max", 5) GLDM_DPP8_STAGE2("max", 6) GLDM_DPP8_STAGE2("max", 7)
+      : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
 }
 __device__ __forceinline__ void pos_sum8(const float (&x)[8], float (&r)[8]) {   // r[i] = sum over the sample's four positions of x[i]
   asm(GLDM_DPP8("add") GLDM_DPP8_OPERANDS);
@@ -172,6 +185,13 @@ constexpr int kQSpinMax = 1 << 20; // every wait is bounded (a healthy one is a 
 __host__ __device__ constexpr int qslot_floats(int s) { return (s < 16 ? PG<4>::kH : PG<4>::kX + 4 * PG<4>::kBlockFloats) + (s & 15) * 512; }
 static_assert(PG<4>::kH + 16 * 512 <= PG<4>::kX && PG<4>::kX + 4 * PG<4>::kBlockFloats + 16 * 512 <= 512 * 64, "slot regions");
 typedef __attribute__((address_space(3))) int lds_i;
+// A weight stream as the ring sees it: its length, the (matrix, byte offsets) of fragment n, the LDS slots.  QStream4: the
+// chain of this file; quad16_narrow.h defines the one of the 16-position nets.
+struct QStream4 {
+  static constexpr int kEnd = kQNEnd, kGroups = kQGroups;
+  static constexpr QOff off(int n) { return qstream_off(n); }
+  __host__ __device__ static constexpr int slot_floats(int s) { return qslot_floats(s); }
+};
 
 struct QRing {
   u32x4 s[kQR][2];
@@ -189,9 +209,9 @@ __device__ __forceinline__ int lds_poll(const lds_i *p) {
 // request stream fragment n from its LDS slot into its registers.  At a group's first fragment: the group must have landed --
 // checked on a word read one group earlier (straight-line code: the reads in flight stay in flight), with a polling loop
 // only if that said "not yet".
-template <int N>
+template <int N, class ST = QStream4>
 __device__ __forceinline__ void qring_load(QRing &ring) {
-  if constexpr (N < kQNEnd) {
+  if constexpr (N < ST::kEnd) {
     if constexpr (N % kQG == 0) {
       constexpr int g = N / kQG;
 #if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_QEXP_DUP)   // timing experiment (wrong results): nobody loads, nobody waits; stale slots are read
@@ -206,18 +226,18 @@ __device__ __forceinline__ void qring_load(QRing &ring) {
 #endif
         }
       }
-      if constexpr (g + 1 < kQGroups) ring.flag = *(volatile lds_i *)(ring.sync + ((g + 1) & 7));
+      if constexpr (g + 1 < ST::kGroups) ring.flag = *(volatile lds_i *)(ring.sync + ((g + 1) & 7));
     }
 #if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_QEXP_NOLOAD)   // timing experiment (wrong results): fragments are never read
     if (N >= kQR) return;
 #endif
-    const lds_u4 *slot = (const lds_u4 *)(ring.lds + qslot_floats(N % kQS)) + ring.lane;
+    const lds_u4 *slot = (const lds_u4 *)(ring.lds + ST::slot_floats(N % kQS)) + ring.lane;
     ring.s[N % kQR][0] = slot[0];
     ring.s[N % kQR][1] = slot[64];
   }
 }
 // acc += (stream fragment N) * B, then refill the registers; behind a group's last fragment: tell the loaders
-template <int N>
+template <int N, class ST = QStream4>
 __device__ __forceinline__ f32x4 qring_mfma(QRing &ring, const u32x4 (&b)[kSplit], f32x4 acc) {
 #if defined(GLDM_DEBUG_KNOBS) && defined(GLDM_QEXP_NOMFMA)   // timing experiment (wrong results): no matrix instruction
   acc[0] += __uint_as_float(ring.s[N % kQR][0][0] ^ b[0][0]);
@@ -227,7 +247,7 @@ __device__ __forceinline__ f32x4 qring_mfma(QRing &ring, const u32x4 (&b)[kSplit
   if constexpr (N % kQG == kQG - 1) ring.sync[16 + 64 * ring.quad + ring.lane] = N / kQG + 1;
   // refill the registers of the PREVIOUS fragment: this one's are still being read by the MFMAs just issued (a load into
   // them waits for the matrix pipe to have taken its operands)
-  if constexpr (N >= 1) qring_load<N - 1 + kQR>(ring);
+  if constexpr (N >= 1) qring_load<N - 1 + kQR, ST>(ring);
   return acc;
 }
 
@@ -252,12 +272,13 @@ __device__ __forceinline__ void quad_build_table(const gldm_r1d_desc &d, int *qt
     qtab[2 * n + 1] = base + o.b;
   }
 }
+template <class ST = QStream4>
 __device__ __forceinline__ void quad_loader(const Ctx &c) {
   using GG = Geo<64>;
   lds_i *sync = (lds_i *)(c.lds + GG::kMiscQ);
   const lds_i *qtab = (const lds_i *)(c.lds + GG::kMiscQTab);
   const char *wb = reinterpret_cast<const char *>(c.w) + c.lane * 16;
-  for (int g = c.wave - 4; g < kQGroups; g += 4) {
+  for (int g = c.wave - 4; g < ST::kGroups; g += 4) {
     if (g >= 8) {   // the slots still hold group g - 8: every quad must be done with it
       for (int spin = 0; spin < kQSpinMax; ++spin) {
         const int d0 = lds_poll(sync + 16), d1 = lds_poll(sync + 80), d2 = lds_poll(sync + 144), d3 = lds_poll(sync + 208);
@@ -271,7 +292,7 @@ __device__ __forceinline__ void quad_loader(const Ctx &c) {
       const int n = g * kQG + f;
       const int oa = __builtin_amdgcn_readfirstlane(qtab[2 * n]), ob = __builtin_amdgcn_readfirstlane(qtab[2 * n + 1]);
       const int sl = s0 + f;
-      float *slot = c.lds + (sl < 16 ? PG<4>::kH : PG<4>::kX + 4 * PG<4>::kBlockFloats) + (sl & 15) * 512;
+      float *slot = c.lds + ST::slot_floats(sl);
       __builtin_amdgcn_global_load_lds((glob_void *)(wb + oa), (lds_void *)slot, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((glob_void *)(wb + ob), (lds_void *)(slot + 256), 16, 0, 0);
     }
@@ -282,7 +303,8 @@ __device__ __forceinline__ void quad_loader(const Ctx &c) {
 
 // A k = 3 conv over the quad's one n-tile at stream position N0: acc[mi] += W[m-tile mi, (tap, channel)] * taps(xp).
 // xp[kb]: the input's fragment planes; the taps are row shifts by 4 lanes.
-template <int N0, int MT, int KB>
+// SH: lanes between neighbouring positions of a sample (4: this file's columns = 4 * position + sample; 1: quad16_narrow.h)
+template <int N0, int MT, int KB, int SH = 4, class ST = QStream4>
 __device__ __forceinline__ void qconv3(QRing &ring, const u32x4 (&xp)[KB][kSplit], f32x4 (&acc)[MT]) {
   using std::integral_constant;
   auto body = [&](auto st_c) {
@@ -290,10 +312,10 @@ __device__ __forceinline__ void qconv3(QRing &ring, const u32x4 (&xp)[KB][kSplit
     u32x4 bs[kSplit];
 #pragma unroll
     for (int pl = 0; pl < kSplit; ++pl)
-      bs[pl] = t == 1 ? xp[kb][pl] : (t == 0 ? dpp_zero4<0x114>(xp[kb][pl]) : dpp_zero4<0x104>(xp[kb][pl]));   // position p - 1 / p + 1
+      bs[pl] = t == 1 ? xp[kb][pl] : (t == 0 ? dpp_zero4<0x110 + SH>(xp[kb][pl]) : dpp_zero4<0x100 + SH>(xp[kb][pl]));   // row_shr / row_shl: position p - 1 / p + 1
     auto per_m = [&](auto mi_c) {
       constexpr int mi = decltype(mi_c)::value;
-      acc[mi] = qring_mfma<N0 + st * MT + mi>(ring, bs, acc[mi]);
+      acc[mi] = qring_mfma<N0 + st * MT + mi, ST>(ring, bs, acc[mi]);
     };
     per_m(integral_constant<int, 0>{});
     if constexpr (MT > 1) per_m(integral_constant<int, 1>{});
@@ -462,13 +484,13 @@ __device__ __forceinline__ void quad_attention_head(const f32x4 (&qa)[2], const 
   constexpr float kL2e = 1.44269504088896340736f;
   float kn[2][4], qe[2][4];
   {
-    float k8[8], m8[8], e8[8], s8[8];
+    float m8[8], e8[8], s8[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) k8[i] = ka[i >> 2][i & 3];
-    pos_max8(k8, m8);
+    for (int i = 0; i < 8; ++i) m8[i] = ka[i >> 2][i & 3];
+    pos_max8(m8);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float d = k8[i] - m8[i];
+      const float d = ka[i >> 2][i & 3] - m8[i];
       e8[i] = L2E ? __builtin_amdgcn_exp2f(d) : __builtin_amdgcn_exp2f(d * kL2e);
     }
     pos_sum8(e8, s8);

@@ -90,8 +90,8 @@ struct Geo {
   static constexpr int kMiscHb = kMiscOld + NC;
   static constexpr int kMiscHs = kMiscHb + (NC == 64 ? 8 * 16 : 0);
   static constexpr int kMiscQ = kMiscHs + (NC == 64 ? 16 : 0);    // quad engine hand-shake words (quad_narrow.h): 8 + 4 x 64 ints
-  static constexpr int kMiscQTab = kMiscQ + (NC == 64 ? 16 + 4 * 64 : 0);   // [2 x 292] byte offsets of the quad engine's weight stream
-  static constexpr int kLdsFloats = kMiscQTab + (NC == 64 ? 2 * 292 : 0);
+  static constexpr int kMiscQTab = kMiscQ + (NC == 64 ? 16 + 4 * 64 : 0);   // [2 x 380] byte offsets of the quad engines' weight streams (292 / 336 / 380 fragments)
+  static constexpr int kLdsFloats = kMiscQTab + (NC == 64 ? 2 * 380 : 0);
 };
 static_assert(Geo<64>::kLdsFloats * 4 <= 160 * 1024, "LDS budget (1 WG/CU)");
 static_assert(Geo<32>::kLdsFloats * 4 * 2 <= 160 * 1024, "LDS budget (2 WG/CU)");
@@ -2610,6 +2610,7 @@ __device__ __forceinline__ void attention_pair(const Ctx &c, float *qkv, float *
 
 
 #include "quad_narrow.h"
+#include "quad16_narrow.h"
 
 // ---------------------------------------------------------- the network ----
 // Step-segment hand-off between workgroups (a tile whose steps are split over a chain of slots).
@@ -2691,6 +2692,16 @@ __host__ __device__ __forceinline__ bool quad_levels(const gldm_r1d_desc &d) {
          d.dims[3] == 128 && d.lv[0].out_wq > 0 && d.lv[1].out_wq > 0 && d.lv[1].qkvn_wq > 0 && d.lv[1].down_wq > 0 &&
          d.lv[2].out_wq > 0 && d.lv[2].qkvn_wq > 0 && d.lv[2].down_wq > 0 && d.rb[2].c1_wq > 0 && d.rb[2].c2_wq > 0 &&
          d.rb[3].c1_wq > 0 && d.rb[3].c2_wq > 0 && d.rb[4].c1_wq > 0 && d.rb[4].c2_wq > 0 && d.rb[5].c1_wq > 0 && d.rb[5].c2_wq > 0;
+}
+// The same for the 16-position nets (quad16_narrow.h): levels of 16, 32 and 64 channels in front of a 128-channel one.  The
+// scale / shift rows come from the per-cloud table (pose decoder: ss_table_rows) or the 64-wide embedding (the launcher
+// checks that one of the two holds).
+__host__ __device__ __forceinline__ bool quad16_levels(const gldm_r1d_desc &d) {
+  return d.seq_len == 16 && d.groups == 4 && d.n_levels >= 3 && d.dims[0] == 16 && d.dims[1] == 32 && d.dims[2] == 64 && d.dims[3] == 128 &&
+         d.lv[0].out_wq > 0 && d.lv[0].qkvn_wq > 0 && d.lv[0].down_wq > 0 && d.lv[1].out_wq > 0 && d.lv[1].qkvn_wq > 0 &&
+         d.lv[1].down_wq > 0 && d.lv[2].out_wq > 0 && d.lv[2].qkvn_wq > 0 && d.lv[2].down_wq > 0 && d.rb[0].c1_wq > 0 &&
+         d.rb[0].c2_wq > 0 && d.rb[1].c1_wq > 0 && d.rb[1].c2_wq > 0 && d.rb[2].c1_wq > 0 && d.rb[2].c2_wq > 0 && d.rb[3].c1_wq > 0 &&
+         d.rb[3].c2_wq > 0 && d.rb[4].c1_wq > 0 && d.rb[4].c2_wq > 0 && d.rb[5].c1_wq > 0 && d.rb[5].c2_wq > 0;
 }
 // conv flags (int 7): taps | alias << 8 | GroupNorm epilogue mode << 9 | (scale/shift table offset / 4) << 12
 constexpr int kFlagAlias = 1 << 8;
@@ -2837,7 +2848,7 @@ __host__ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *
          3 | (1 << 9) | (NC == 64 ? kFlagFused : 0) | ((toff >> 2) << kFlagTabShift), rb.n1_w, rb.n1_b, rb.ss_w, rb.ss_b);
     emit(OP_CONV, NC == 64 ? rb.c2_w3 : rb.c2_w, rb.c2_b, H, X, C, C, 3 | (2 << 9), rb.n2_w, rb.n2_b, -1, 0);  // X += act(GN(conv(H)))
   };
-  const bool quad = NC == 64 && use_quad && quad_levels(d);
+  const bool quad = NC == 64 && use_quad && (quad_levels(d) || quad16_levels(d));
   if (quad) emit(OP_QUAD);
   // constant indices only: a dynamically indexed kernel argument is copied to scratch memory
 #pragma unroll
@@ -2955,6 +2966,25 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const gldm_r1d_desc &d, 
           else quad_loader(c);
 #endif
           __syncthreads();
+        } else if constexpr (NC == 64 && L == 16) {
+          kernarg_desc *dkp = (kernarg_desc *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() +
+                                               offsetof(RunArgs, d));
+          if (c.ss_lane) {   // pose decoder: scale / shift rows from the per-cloud table (wave uniform: the launch has one or not)
+            if (c.wave < 4) {
+              // the wave's sample's rows: Ctx::ss_lane of a lane whose sample (lane & 3) it is
+              const unsigned long long pv = (unsigned long long)c.ss_lane;
+              const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pv, c.wave);
+              const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), c.wave);
+              quad16_narrow_levels<1>(c, dkp, (const float *)(((unsigned long long)hi << 32) | lo));
+            } else {
+              quad_loader<QStream16<1>>(c);
+            }
+          } else {
+            if (c.wave < 4) quad16_narrow_levels<4>(c, dkp, nullptr);
+            else quad_loader<QStream16<4>>(c);
+          }
+          __syncthreads();
+          zero_plane_pads16(c.lds, c.tid);   // the ring's slots lie over the H plane rows (conv2 of the next ResnetBlock reads them behind a barrier)
         }
         break;
       case OP_RES4:
@@ -3085,9 +3115,17 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
 
   for (int i = c.tid; i < GG::kLdsFloats; i += GG::kThreads) lds[i] = 0.f;  // dead columns must stay finite
   __syncthreads();
+  // the wave-local narrow levels are in use when the step program (built by the launcher) starts with their op
+  const bool quad16 = PM && L == 16 && a.pm_nops > 0 && a.pm_tape[0] == OP_QUAD;
   if constexpr (PM && L == 4) {
-    static_assert(2 * kQNEnd == 2 * 292, "kMiscQTab size");
+    static_assert(2 * kQNEnd <= GG::kLdsFloats - GG::kMiscQTab, "kMiscQTab size");
     if (quad_levels(d)) quad_build_table(d, reinterpret_cast<int *>(lds + GG::kMiscQTab), c.tid, GG::kThreads);
+  }
+  if constexpr (PM && L == 16) {
+    if (quad16) {   // the scale / shift rows from the per-cloud table, or the Linear in the chain (its fragments in the stream)
+      if (a.ss_tab) quad16_build_table<1>(d, reinterpret_cast<int *>(lds + GG::kMiscQTab), c.tid, GG::kThreads);
+      else quad16_build_table<4>(d, reinterpret_cast<int *>(lds + GG::kMiscQTab), c.tid, GG::kThreads);
+    }
   }
   int *tape = reinterpret_cast<int *>(lds + GG::kMiscTape);
   ChainHdr *hdr = reinterpret_cast<ChainHdr *>(a.ws);
@@ -3247,8 +3285,8 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       for (int r = 0; r < R; ++r) g += silu(te + ce[r * E]);
       G[s * E + e] = g;
     }
-    if constexpr (PM && L == 4) {   // quad engine hand-shake words (quad_narrow.h): every step starts from zero
-      if (tid_o < 16 + 4 * 64) reinterpret_cast<int *>(lds + GG::kMiscQ)[tid_o] = 0;
+    if constexpr (PM) {   // quad engine hand-shake words (quad_narrow.h): every step starts from zero
+      if ((L == 4 || quad16) && tid_o < 16 + 4 * 64) reinterpret_cast<int *>(lds + GG::kMiscQ)[tid_o] = 0;
     }
     // ---- init conv (k = 7, one input channel); the barrier below also publishes G
     const int C0 = d.dims[0];
@@ -3276,7 +3314,8 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
       X[PM ? pswz(ch, n) : swz<NC>(ch, n)] = acc;
     }
     __syncthreads();
-    if constexpr (PM && L == 16) {   // the first ResnetBlock reads the planes of the init conv's 16 rows
+    if constexpr (PM && L == 16) if (!quad16) {   // the first ResnetBlock reads the planes of the init conv's 16 rows (the
+                                                  // wave-local chain reads the f32 rows and restores the zero entries itself)
       zero_plane_pads16(lds, c.tid);   // the previous step's (or tile's) 256-channel output rows lie over some of them
       {   // ... and over channels 16 .. 31 of H-plane block 0, which the 16-channel level multiplies with zero weights
         lds_u4 *hb = (lds_u4 *)(lds + PG<16>::kH);
@@ -3682,6 +3721,8 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
 #ifdef GLDM_DEBUG_KNOBS
     if (getenv("GLDM_R1D_NOQUAD")) use_quad = false;   // A/B: the narrow levels as position-major phases
 #endif
+    // 16-position nets: the wave-local levels take their scale / shift rows from the per-cloud table or a 64-wide embedding
+    if (pm16 && !(a_in.ss_tab != nullptr || a_in.d.emb_dim == 64)) use_quad = false;
     a.pm_nops = build_tape<64>(a_in.d, a.pm_tape, use_quad);
     const WsLayout wl = ws_layout(&a_in.d, a_in.n_samples);
     if (wl.park_off >= 0) a.park = reinterpret_cast<float *>(reinterpret_cast<char *>(a_in.ws) + wl.park_off);
@@ -3709,7 +3750,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
   if (stamp) {
     static long long host[kMaxOps + 2];
     static const char *names[] = {"", "CONV", "RES4", "LN", "ATT", "QKVLN", "OUTLN", "QKVAT", "QUAD"};
-    const bool quad = pm4 && a.pm_nops > 0 && a.pm_tape[0] == OP_QUAD;
+    const bool quad = (pm4 || pm16) && a.pm_nops > 0 && a.pm_tape[0] == OP_QUAD;
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(host, dstamps, sizeof(host), hipMemcpyDeviceToHost);
     // the tape is rebuilt on the host only to label the stamps
@@ -3724,7 +3765,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
       if (C == 4 && a.d.seq_len == 4) line(2, C, C, 3);
       else { line(1, C, C, 3); line(1, C, C, 3); }
     };
-    if (quad) line(8, 4, 128, 3);
+    if (quad) line(8, dims[0], 128, 3);
     for (int lv = quad ? 3 : 0; lv < a.d.n_levels; ++lv) {
       const int C = dims[lv];
       resblock(C); resblock(C);
@@ -3742,7 +3783,9 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
     if (quad) {
       static long long qs[4][16];
       (void)hipMemcpyFromSymbol(qs, HIP_SYMBOL(g_q_stamp), sizeof(qs));
-      static const char *qn[] = {"pads", "rb4", "rb4", "att4", "down4", "rb32", "rb32", "att32", "down32", "rb64", "rb64", "att64", "down64"};
+      static const char *qn4[] = {"pads", "rb4", "rb4", "att4", "down4", "rb32", "rb32", "att32", "down32", "rb64", "rb64", "att64", "down64"};
+      static const char *qn16[] = {"pads", "rb16", "rb16", "att16", "down16", "rb32", "rb32", "att32", "down32", "rb64", "rb64", "att64", "down64"};
+      const char **qn = pm16 ? qn16 : qn4;
       for (int q = 0; q < 4; ++q) {
         printf("quad %d:", q);
         for (int i = 1; i <= 12; ++i) printf(" %s %lld", qn[i], qs[q][i] - qs[q][i - 1]);

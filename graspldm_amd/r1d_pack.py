@@ -192,6 +192,9 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
             if seq_len == 4 and c in (32, 64):   # the quad engine's copies (csrc/quad_narrow.h)
                 rb.c1_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(w1)))
                 rb.c2_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(w2)))
+            elif seq_len == 16 and c in (16, 32, 64):   # csrc/quad16_narrow.h (16 channels: one zero-padded block per tap)
+                rb.c1_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(pad_cin32(w1, c, 3))))
+                rb.c2_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(pad_cin32(w2, c, 3))))
         rb.c1_w = buf.add(mfma_a_fragments(conv_as_gemm(weight_standardize(sd[q + "block1.proj.weight"]))))
         rb.c1_b = buf.add(sd[q + "block1.proj.bias"])
         rb.n1_w = buf.add(sd[q + "block1.norm.weight"])
@@ -247,6 +250,12 @@ def pack_resnet1d(sd, p, groups, seq_len, cond_rows=3, num_steps=None, decoder=N
                 wq[:2 * hid] *= 1.4426950408889634
                 lv.qkvn_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(wq.float())))
                 lv.down_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(conv_as_gemm(sd[q + "3.weight"]))))
+        if seq_len == 16 and c in (16, 32, 64):   # csrc/quad16_narrow.h: the same three copies, K padded per tap / to 32
+            lv.out_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(sd[q + "2.fn.fn.to_out.0.weight"][:, :, 0])))
+            wq = wn.double().clone()
+            wq[:2 * hid] *= 1.4426950408889634
+            lv.qkvn_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(pad_cin32(wq.float(), c, 1))))
+            lv.down_wq = buf.add(mfma_a_fragments_f16x2(quad_perm32(pad_cin32(conv_as_gemm(sd[q + "3.weight"]), c, 3))))
         lv.down_b = buf.add(sd[q + "3.bias"])
     resblock(p + "final_res_block.", dims[-1], slot)
     fw = sd[p + "final_conv.weight"]
