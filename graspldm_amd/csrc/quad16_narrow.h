@@ -148,6 +148,9 @@ __device__ __forceinline__ void quad16_resblock(const Ctx &c, QRing &ring, const
   constexpr int C = 16 * MT, CPG = C / 4;
   const int kq = c.lane >> 4;
   const float *w = c.w;
+  // Parameter loads are placed where their latency is covered and not earlier (this chain's 64-channel level with everything
+  // requested up front, as quad_narrow.h does, spilled nine registers): block1's behind the scale / shift part, in flight under
+  // conv1; block2's behind block1's epilogue, in flight under conv2.
   f32x4 sc[MT], sh[MT], g1[MT], be1[MT], b1[MT];
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
@@ -155,26 +158,21 @@ __device__ __forceinline__ void quad16_resblock(const Ctx &c, QRing &ring, const
     const float *sb = SSF == 1 ? sst : w + rb.ss_b;
     sc[mi] = *reinterpret_cast<const f32x4 *>(sb + row0);
     sh[mi] = *reinterpret_cast<const f32x4 *>(sb + C + row0);
-    b1[mi] = *reinterpret_cast<const f32x4 *>(w + rb.c1_b + row0);
-    g1[mi] = *reinterpret_cast<const f32x4 *>(w + rb.n1_w + row0);
-    be1[mi] = *reinterpret_cast<const f32x4 *>(w + rb.n1_b + row0);
   }
   {
     // SSF = 4: B operand of k-step (kb, j) = embedding sum 16 kb + 4 j + g of the wave's sample, the same in every column
-    float gb[SSF == 4 ? 16 : 1];
-    if constexpr (SSF == 4) {
-      const lds_f *Gs = (const lds_f *)(c.lds + GG::kMiscG) + smp * 64;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) gb[i] = Gs[4 * i + kq];
-    }
+    const lds_f *Gs = (const lds_f *)(c.lds + GG::kMiscG) + smp * 64 + kq;
     auto ss_f = [&](auto i_c) {   // stream slot N0 + i
       constexpr int i = decltype(i_c)::value, mi = i / SSF, kb = i % SSF;
       if constexpr (SSF == 4) {
         const u32x4 a_sc = ring.s[(N0 + i) % kQR][0], a_sh = ring.s[(N0 + i) % kQR][1];
+        float gb[4];   // read per slot (four ds_read_b32 with immediate offsets): sixteen values kept across the block were spilled
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gb[j] = Gs[16 * kb + 4 * j];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          sc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a_sc[j]), gb[4 * kb + j], sc[mi], 0, 0, 0);
-          sh[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a_sh[j]), gb[4 * kb + j], sh[mi], 0, 0, 0);
+          sc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a_sc[j]), gb[j], sc[mi], 0, 0, 0);
+          sh[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a_sh[j]), gb[j], sh[mi], 0, 0, 0);
         }
       }
       if constexpr (N0 + i >= 1) qring_load<N0 + i - 1 + kQR, ST>(ring);
@@ -189,19 +187,18 @@ __device__ __forceinline__ void quad16_resblock(const Ctx &c, QRing &ring, const
     if constexpr (MT > 2) { ss_m(integral_constant<int, 2>{}); ss_m(integral_constant<int, 3>{}); }
   }
   __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int row0 = 16 * mi + 4 * kq;
+    b1[mi] = *reinterpret_cast<const f32x4 *>(w + rb.c1_b + row0);
+    g1[mi] = *reinterpret_cast<const f32x4 *>(w + rb.n1_w + row0);
+    be1[mi] = *reinterpret_cast<const f32x4 *>(w + rb.n1_b + row0);
+  }
   // ---- conv1
   f32x4 acc[MT];
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
   qconv3<N0 + SSF * MT, MT, KB, 1, ST>(ring, xp, acc);
-  f32x4 b2[MT], g2[MT], be2[MT];
-#pragma unroll
-  for (int mi = 0; mi < MT; ++mi) {
-    const int row0 = 16 * mi + 4 * kq;
-    b2[mi] = *reinterpret_cast<const f32x4 *>(w + rb.c2_b + row0);
-    g2[mi] = *reinterpret_cast<const f32x4 *>(w + rb.n2_w + row0);
-    be2[mi] = *reinterpret_cast<const f32x4 *>(w + rb.n2_b + row0);
-  }
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -234,6 +231,15 @@ __device__ __forceinline__ void quad16_resblock(const Ctx &c, QRing &ring, const
     }
   }
   q16_split<MT, KB>(acc, hp);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 b2[MT], g2[MT], be2[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int row0 = 16 * mi + 4 * kq;
+    b2[mi] = *reinterpret_cast<const f32x4 *>(w + rb.c2_b + row0);
+    g2[mi] = *reinterpret_cast<const f32x4 *>(w + rb.n2_w + row0);
+    be2[mi] = *reinterpret_cast<const f32x4 *>(w + rb.n2_b + row0);
+  }
   // ---- conv2 on H / hs
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -178,7 +178,11 @@ typedef struct gldm_r1d_level {
 /* Quad column order (ABI 9; r1d_pack.quad_perm32): the wave-local engine of the narrow levels (csrc/quad_narrow.h) feeds
  * a GEMM's B operand straight from the accumulator layout of the previous one -- lane (column, g) holds rows 4 g + r of
  * m-tiles 2 kb and 2 kb + 1 -- so k-slot 8 g + j of a 32-channel block kb stands for channel 32 kb + 16 (j >> 2) + 4 g +
- * (j & 3), and the weights' columns are stored in that order: W_q[:, 32 kb + 8 g + j] = W[:, 32 kb + 16 (j >> 2) + 4 g + (j & 3)]. */
+ * (j & 3), and the weights' columns are stored in that order: W_q[:, 32 kb + 8 g + j] = W[:, 32 kb + 16 (j >> 2) + 4 g + (j & 3)].
+ * 16-position nets (round 6, csrc/quad16_narrow.h: the 16 / 32 / 64-channel levels in front of a 128-channel one; one wave =
+ * one sample's 16 positions): the same copies, taken from the weights with every tap's channels padded to whole 32-channel
+ * blocks first (a 16-channel level is one block whose k-slots j >= 4 are zero): quad_perm32(pad_cin32(W, C, taps)).  Packers
+ * that leave them 0 get the barrier-separated phases of the 64-column engine instead: same results, ~20 % slower. */
 
 /* Split-f16 weight fragments (layout since ABI 5, two f16 planes since ABI 9; graspldm_amd/r1d_pack.py:
  * mfma_a_fragments_f16x2).  Every f32 weight is written as hi + lo, two f16 numbers (hi = f16(w), lo = f16(w - hi):

@@ -89,3 +89,29 @@ def test_dpp_hazard_scan_flags_a_close_write(tmp_path):
     assert r.returncode == 1 and "1 VALU-write" in r.stdout, r.stdout
     r = subprocess.run([sys.executable, scan, str(good), "my_kernel"], capture_output=True, text=True)
     assert r.returncode == 0 and "2 DPP instructions, 0 VALU-write" in r.stdout, r.stdout
+
+
+def test_hazard_scan_flags_a_read_of_a_fresh_matrix_result(tmp_path):
+    """Second check of tools/isa/dpp_hazard_scan.py (round 6): a VALU instruction that reads a matrix instruction's result
+    closer than the compiler ever leaves them -- only an asm statement taking accumulators straight out of the matrix pipe can
+    do that (csrc/quad_narrow.h: pos_max8 did, 3 wait states behind a v_mfma_f32_16x16x4_f32) -- is reported; the same read
+    behind enough other instructions, or of a register overwritten in between, is not."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scan = os.path.join(root, "tools", "isa", "dpp_hazard_scan.py")
+    mfma = "\tv_mfma_f32_16x16x4_f32 v[60:63], v5, v69, 0\n"
+    filler = "\tv_mov_b32_e32 v9, v1\n"
+    read = "\tv_max_f32_dpp v3, v60, v60 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+    head, tail = "0000000000001000 <my_kernel>:\n", "\ts_endpgm\n"
+    bad = tmp_path / "bad.s"
+    bad.write_text(head + mfma + 3 * filler + read + tail)
+    far = tmp_path / "far.s"
+    far.write_text(head + mfma + 3 * filler + "\ts_nop 7\n" + read + tail)
+    over = tmp_path / "over.s"
+    over.write_text(head + mfma + "\tv_mov_b32_e32 v60, v1\n" + 2 * filler + read + tail)
+    r = subprocess.run([sys.executable, scan, str(bad), "my_kernel"], capture_output=True, text=True)
+    assert r.returncode == 1 and "1 VALU reads of a matrix" in r.stdout, r.stdout
+    for f in (far, over):
+        r = subprocess.run([sys.executable, scan, str(f), "my_kernel"], capture_output=True, text=True)
+        assert r.returncode == 0 and "0 VALU reads of a matrix" in r.stdout, (f, r.stdout)

@@ -319,3 +319,31 @@ def test_f32_only_switch_changes_what_is_packed_and_chosen(fpc_state_dict):
         assert not voxel.split_conv_supported(3, 48, 24)      # round 6: the 3-channel conv runs its f32 form too (K padded)
         assert voxel.conv_supported(48, 24)
     assert numerics.split_enabled()
+
+
+def test_sixteen_position_nets_carry_the_wave_local_copies(fpc_state_dict):
+    """csrc/quad16_narrow.h reads the 16 / 32 / 64-channel levels of a 16-position net through quad-ordered split copies with K
+    padded to whole 32-channel blocks (r1d_pack: quad_perm32(pad_cin32(...))): present for the pose decoder's three narrow
+    levels, absent at 128 channels, sized as the kernel's fragment list expects, and the padded half of a 16-channel level's
+    K is zero in the stored fragments."""
+    import torch
+    from graspldm_amd.r1d_pack import pack_resnet1d, quad_perm32, pad_cin32, mfma_a_fragments_f16x2
+    sd = fpc_state_dict
+    p = "vae_model.decoder."
+    pk = pack_resnet1d(sd, p + "net.", groups=4, seq_len=16, decoder=dict(
+        in_w=sd[p + "in_layer.weight"], in_b=sd[p + "in_layer.bias"], tmrp_w=sd[p + "tmrp.weight"],
+        tmrp_b=sd[p + "tmrp.bias"], cls_w=sd[p + "class_logits.weight"], cls_b=sd[p + "class_logits.bias"]))
+    d, w = pk["desc"], pk["weights"]
+    assert [d.dims[i] for i in range(5)] == [16, 32, 64, 128, 256]
+    for i in range(6):
+        assert d.rb[i].c1_wq > 0 and d.rb[i].c2_wq > 0
+    for i in range(3):
+        assert d.lv[i].qkvn_wq > 0 and d.lv[i].out_wq > 0 and d.lv[i].down_wq > 0
+    assert d.rb[6].c1_wq == 0 and d.lv[3].qkvn_wq == 0
+    # a 16 -> 16 conv: one m-tile x 3 taps x one padded block = 3 fragments of 512 floats; slot 8 g + j of a block holds
+    # channel 16 (j >> 2) + 4 g + (j & 3): j >= 4 are the zero-padded channels 16 .. 31
+    frag = w[d.rb[0].c1_wq:d.rb[0].c1_wq + 3 * 512].view(torch.float16).reshape(3, 2, 64, 8)   # (fragment, plane, lane, j)
+    assert float(frag[:, :, :, 4:].abs().max()) == 0.0 and float(frag[:, 0, :, :4].abs().max()) > 0.0
+    x = torch.arange(2 * 96, dtype=torch.float32).reshape(2, 96)
+    assert torch.equal(quad_perm32(x)[:, 8 * 1 + 5], x[:, 16 * 1 + 4 * 1 + 1])      # block 0, g = 1, j = 5
+    assert mfma_a_fragments_f16x2(quad_perm32(pad_cin32(torch.ones(16, 48), 16, 3))).numel() == 3 * 512

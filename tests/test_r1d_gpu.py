@@ -256,6 +256,29 @@ def test_decoder_more_tiles_than_slots(engines):
     assert torch.equal(tm[:64], tm3) and torch.equal(lg[:64], lg3)
 
 
+def test_repeated_launches_are_bitwise_equal(engines):
+    """The same launch three times: every bit equal.  The wave-local chains read accumulators inside hand-written DPP blocks;
+    one of them (quad_narrow.h: pos_max8, until round 6) took them straight out of the matrix pipe, closer than the hazard
+    allows -- a stale maximum now and then, which a softmax turns into last-bit noise that no tolerance test sees.  Both
+    engines, tiles in several rounds per workgroup and a partly filled last tile."""
+    from graspldm_amd.r1d import SCHED_DDIM
+    den, dec = engines
+    g = torch.Generator().manual_seed(77)
+    n = _slots() * 16 + 16 * 40 + 5       # whole rounds, left-over tiles cut along the step axis, a short last tile
+    x = torch.randn(n, 1, 4, generator=g).cuda()
+    cemb = den.cond_embed(torch.randn(n, 3, 64, generator=g).cuda())
+    ts, coef = _ddim_tables(100)
+    ts, coef = ts[-12:].contiguous().cuda(), coef[-12:].contiguous().cuda()
+    outs = [den.denoise(x, cemb, 1, timesteps=ts, sched_kind=SCHED_DDIM, coef=coef).clone() for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    m = _slots() * 4 * 2 + 7
+    zh = torch.randn(m, 4, generator=g).cuda()
+    dcemb = dec.cond_embed(torch.randn(m, 3, 64, generator=g).cuda())
+    runs = [tuple(t.clone() for t in dec.decode(zh, dcemb, 1)) for _ in range(3)]
+    for r in runs[1:]:
+        assert torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1])
+
+
 def test_decoder_shared_conditioning_rows(engines):
     """The decoder reads its ResnetBlocks' scale/shift rows from a per-cloud table (ss_table_kernel).  With 3 grasps
     per cloud every other 2-sample tile straddles two clouds: must equal, bit for bit, the same batch with the
