@@ -2026,61 +2026,11 @@ __device__ __forceinline__ void qkv_att_pm(const Ctx &c, int w_off, int s_off, c
 }
 
 
-// ---- attention block of the 16-position 64-column engine (LL = 16: column = 4 * position + sample) ---------------------
-// PreNorm LayerNorm folded into the to_qkv conv exactly as in qkv_att_pm; a sample's 16 x 16 attention matrix does not
-// fit the lanes, so q | k | v go to LDS as a [384][64] f32 block (over both plane regions: the conv's plane reads end at
-// the barrier in front of the stores) and attention16_pm works from there.  Wave w takes rows 48 w .. 48 w + 47.
-template <int KB32>   // ceil(C / 32): a 16-channel level is one zero-padded block
-__device__ __forceinline__ void qkv_ln16_pm(const Ctx &c, int w_off, int s_off, const float *src, int C, float *dst) {
-  constexpr int NC = 64, MT = 3, NT = 4;
-  using GG = Geo<NC>;
-  const float *wp = c.w + w_off, *srow = c.w + s_off;
-  const int mt0 = 3 * c.wave;
-  const int col = c.lane & 15, kq = c.lane >> 4;
-  f32x4 sv[MT];
-#pragma unroll
-  for (int mi = 0; mi < MT; ++mi) sv[mi] = *reinterpret_cast<const f32x4 *>(srow + 16 * (mt0 + mi) + 4 * kq);
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float inv_c = __builtin_amdgcn_rcpf((float)C);  // C: a power of two -> exact
-  if (C == 16) {
-    auto stats = [&]() { column_stats8<2>(c, src, inv_c); };
-    gemm1_pl<1, MT, NT, decltype(stats), 1, 16>(c, wp, mt0, 0, c.lds + PG<16>::kX, acc, stats);
-  } else {
-    auto stats = [&]() { column_stats8<4 * KB32>(c, src, inv_c); };
-    gemm1_pl<KB32, MT, NT, decltype(stats), 1, 16>(c, wp, mt0, 0, c.lds + PG<16>::kX, acc, stats);
-  }
-  __syncthreads();  // every column's (mean, rstd) is in LDS, every wave is past its plane reads
-  const lds_f *mean3 = (const lds_f *)(c.lds + GG::kMiscRed1), *rstd3 = (const lds_f *)(c.lds + GG::kMiscRed2);
-  lds_f *d3 = (lds_f *)dst;
-#pragma unroll
-  for (int ni = 0; ni < NT; ++ni) {
-    const float rstd = rstd3[16 * ni + col];
-    const float mr = mean3[16 * ni + col] * rstd;
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const int row0 = 16 * (mt0 + mi) + 4 * kq, cf = 16 * ni + col;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d3[pswz(row0 + r, cf)] = acc[mi][ni][r] * rstd - mr * sv[mi][r];
-    }
-  }
-  __syncthreads();
-}
-
-// LinearAttention core (resnets.py:223-235) at n = 16 positions, four heads, four samples per tile.  Both softmaxes are
-// normalised in place first -- keys over a sample's 16 positions (four lanes per (row, sample), one per tile; the lanes of
-// a wave walk the tile's four positions in rotated order so that its four rows hit different banks), queries over the 32
-// channels of their head, scaled by dim_head^-0.5 (four lanes per (head, column)) -- then a wave takes two (head,
-// sample) pairs: A = Kn^T Qn (16 x 16, K = 32) and out = V A (32 x 16, K = 16) as 16 f32 MFMAs each, A's accumulator
-// registers being the B operand of the second product as they stand (k-step r = key positions {4 kq + r}).  The output
-// leaves as split planes over the q rows (the H-plane region) once every wave is done reading; the zero entries either side
-// of every plane row, overwritten by the q | k | v block, are restored for the k = 3 convs that follow.
+// ---- attention block of the 16-position 64-column engine: qkv_att16_pm (behind quad16_narrow.h, whose core it shares).
+// (Rounds 4-5: qkv_ln16_pm + attention16_pm, q | k | v through LDS as a [384][64] f32 block over both plane regions.)
 // The four zero entries either side of every plane row (8 blocks x 3 planes x 4 g rows x 8 entries) of the 16-position
-// engine.  Two things overwrite them with f32 data: the q | k | v block of an attention phase and the f32 rows of the
-// 256-channel level's output (rows 128 .. 255 of X lie over the first H-plane blocks): restored behind each.
+// engine.  Two things overwrite them: the f32 rows of the 256-channel level's output (rows 128 .. 255 of X lie over the
+// first H-plane blocks) and the weight ring of the wave-local narrow levels (quad16_narrow.h): restored behind each.
 __device__ __forceinline__ void zero_plane_pads16(float *lds, int t) {
   using G = PG<16>;
   lds_u4 *pl = (lds_u4 *)(lds + G::kH);
@@ -2089,127 +2039,6 @@ __device__ __forceinline__ void zero_plane_pads16(float *lds, int t) {
     const int rowi = i >> 3, e8 = i & 7;
     pl[rowi * G::kCols + (e8 < 4 ? e8 : 64 + e8)] = z4;
   }
-}
-
-__device__ __forceinline__ void attention16_pm(const Ctx &c, float *qkv, int C) {
-  using G = PG<16>;
-  lds_f *q3 = (lds_f *)qkv;
-  const int t = c.tid;
-  // Addresses are formed once per phase: a row's swizzle (pswz: the column's bits 4-5 XOR bits 3-4 of the row) is constant
-  // over the 8 rows of an octet and over rows 32 apart, so everything below is a lane base plus immediates.
-  {   // keys: row = 128 + 32 rd + 4 wave + rs, rd = 0..3; swizzle = (wave >> 1) & 3 whatever rd
-    const int rs = c.lane >> 4, T = (c.lane >> 2) & 3, s = c.lane & 3;
-    const int base = (kHidden + 4 * c.wave + rs) * 64 + ((16 * T) ^ (((c.wave >> 1) & 3) << 4)) + s;
-    int off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) off[j] = base + ((4 * j + 4 * rs) & 12);   // rotated walk of the tile's positions
-#pragma unroll
-    for (int rd = 0; rd < 4; ++rd) {
-      float k[4], km = -3.0e38f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        k[j] = q3[off[j] + 2048 * rd];
-        km = fmaxf(km, k[j]);
-      }
-      km = dpp_max<0x124>(km);   // the other three tiles: row_ror 4, 8
-      km = dpp_max<0x128>(km);
-      float ks = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        k[j] = fast_exp(k[j] - km);
-        ks += k[j];
-      }
-      ks += dpp_mov<0x124>(ks);
-      ks += dpp_mov<0x128>(ks);
-      const float inv = __builtin_amdgcn_rcpf(ks);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) q3[off[j] + 2048 * rd] = k[j] * inv;
-    }
-  }
-  {   // queries: item = 128 rd + (t >> 2): head 2 rd + (t >> 8), column (t >> 2) & 63, channel quarter t & 3
-    const int qt = t & 3, col = (t >> 2) & 63;
-    const int base = ((t >> 8) * kDimHead + 8 * qt) * 64 + (col ^ (qt << 4));
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-      float q[8], qm = -3.0e38f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        q[j] = q3[base + 64 * j + 4096 * rd];
-        qm = fmaxf(qm, q[j]);
-      }
-      qm = dpp_max<0xB1>(qm);
-      qm = dpp_max<0x4E>(qm);  // the four channel quarters of a column: one quad
-      float qs = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        q[j] = fast_exp(q[j] - qm);
-        qs += q[j];
-      }
-      qs += dpp_mov<0xB1>(qs);
-      qs += dpp_mov<0x4E>(qs);
-      const float sc = 0.17677669529663687f * __builtin_amdgcn_rcpf(qs);  // dim_head ** -0.5 / sum
-#pragma unroll
-      for (int j = 0; j < 8; ++j) q3[base + 64 * j + 4096 * rd] = q[j] * sc;
-    }
-  }
-  __syncthreads();
-  const int m = c.lane & 15, kq = c.lane >> 4;
-  const int h = c.wave >> 1;   // the wave's two (head, sample) pairs: head h, samples 2 (wave & 1) + e
-  f32x4 o[2][2];
-  {
-    const int qrow = (h * kDimHead + kq) * 64, krow = qrow + kHidden * 64;
-    const int vrow = (2 * kHidden + h * kDimHead + m) * 64;
-    const int vx0 = 16 * (kq ^ (m >> 3)), vx1 = 16 * (kq ^ (2 + (m >> 3)));   // rows m and 16 + m: swizzled tile of key position 4 kq + r
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int cm = 4 * m + 2 * (c.wave & 1) + e;
-      int cx[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) cx[x] = cm ^ (x << 4);
-      f32x4 am = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {  // channel d = 4 j + kq: rows 4 j + kq of the head, swizzle (j >> 1) & 3
-        const float ka = q3[krow + 256 * j + cx[(j >> 1) & 3]];   // Kn^T[key position m][d]
-        const float qb = q3[qrow + 256 * j + cx[(j >> 1) & 3]];   // Qn[d][query position m]
-        am = __builtin_amdgcn_mfma_f32_16x16x4f32(ka, qb, am, 0, 0, 0);
-      }
-      // am: lane (query position m, kq), register r = A[key position 4 kq + r][m]
-      o[e][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      o[e][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int sv = 2 * (c.wave & 1) + e;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {  // k-step r: key positions 4 kq + r
-        const float v0 = q3[vrow + vx0 + 4 * r + sv];
-        const float v1 = q3[vrow + 16 * 64 + vx1 + 4 * r + sv];
-        o[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, am[r], o[e][0], 0, 0, 0);
-        o[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, am[r], o[e][1], 0, 0, 0);
-      }
-    }
-  }
-  __syncthreads();  // all reads of q, k, v are done
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int pair = 2 * c.wave + e, h = pair >> 2, s = pair & 3;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)   // o[e][u][r]: channel 16 u + 4 kq + r of head h, query position m
-      store_planes4<16>(c.lds + G::kH, kDimHead * h + 16 * u + 4 * kq, 4 * m + s, o[e][u][0], o[e][u][1], o[e][u][2], o[e][u][3]);
-  }
-  // the zero entries of every plane row of both regions
-  {
-    zero_plane_pads16(c.lds, t);
-    const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
-    // A 16-channel level reads its planes as ONE 32-channel block whose upper half has zero weights -- but 0 x the bit
-    // patterns the q | k | v block left there can be 0 x NaN: channels 16 .. 31 (g = 2, 3) of block 0 of the X planes are
-    // cleared (the H region's hold this phase's attention output, finite, and later finite H values)
-    if (C == 16) {
-      lds_u4 *xb = (lds_u4 *)(c.lds + G::kX);
-      for (int j = t; j < 3 * 2 * 64; j += 512) {
-        const int plane = j / 128, gg = 2 + ((j >> 6) & 1), col = j & 63;
-        xb[(plane * 4 + gg) * G::kCols + G::kOff + col] = z4;
-      }
-    }
-  }
-  __syncthreads();
 }
 
 // A whole ResnetBlock of the position-major engine as ONE op: conv1 (GroupNorm, scale/shift, SiLU -> H), barrier, conv2
@@ -2862,11 +2691,7 @@ __host__ __device__ __forceinline__ int build_tape(const gldm_r1d_desc &d, int *
       // position-major engine (C <= 128 at attention levels): X rows [0, 128) | q,k,v of the four heads: 384 rows, o in
       // place of q.  The PreNorm LayerNorm is folded into the qkv conv (C = 4: computed in the lanes of the qkv phase).
       int Oa = O;
-      if (NC == 64 && d.seq_len == 16) {   // 16 positions: q | k | v through LDS (over the plane regions), output as planes
-        emit(OP_QKVLN, v.qkvn_w3, v.qkvn_s, X, 128 * NC, C);
-        emit(OP_ATT, 128 * NC, C);
-        Oa = kPlaneH;
-      } else if (NC == 64) {   // PreNorm + to_qkv + attention core of the four heads: one op, the output as planes (kPlaneH)
+      if (NC == 64) {   // PreNorm + to_qkv + attention core of the four heads: one op, the output as planes (kPlaneH)
         emit(OP_QKVATT, C == 4 ? v.qkvn_w : v.qkvn_w3, v.qkvn_s, X, C);
         Oa = kPlaneH;
       } else {
@@ -2912,6 +2737,111 @@ __device__ __forceinline__ void read_op(const int *tape, kernarg_int *ktape, int
     for (int i = 0; i < kOpInts; ++i) o[i] = __builtin_amdgcn_readfirstlane(o[i]);
   }
 }
+
+// ---- PreNorm + to_qkv + attention core of the 16-position 64-column engine as ONE op (round 6) ---------------------------
+// Until round 6 this was two ops: qkv_ln16_pm wrote q | k | v as a [384][64] f32 block over both plane regions and
+// attention16_pm worked from there (three barriers, 96 KiB through ds_write_b32 and back, the plane rows' zero entries
+// restored behind it): 25 k of a 236 k-cycle pass at 128 channels.  The wave-local chain of the narrow levels
+// (quad16_narrow.h) keeps a (head, sample) pair's q, k and v on the accumulators; the same holds here once the GEMM is dealt
+// by PAIRS instead of by rows: wave w = head w >> 1, samples 2 (w & 1) and 2 (w & 1) + 1; an n-tile is one SAMPLE's 16 positions
+// (columns 4 p + s of the engine's layout, p = lane & 15: the B fragment reads stride over the plane row), its six m-tiles the
+// head's q, k and v rows (to_qkv's own order: m-tiles 2 h + half, + 8, + 16), v with the MFMA operands swapped so that it
+// arrives transposed (quad16_attention_head).  LayerNorm folded into the conv as before (W' = W diag(g), s = W' 1: rstd
+// (W' x - mean s), the column statistics taken by column_stats8 under the first fragment loads and applied behind ONE barrier);
+// q and k leave multiplied by log2(e) for the core's 2^x.  The output goes to the H planes (head h = 32-channel block h) for
+// out_ln_pm, as before.  Nothing overwrites a plane region any more.
+// Same MFMA count as the row split (144 per wave at 128 channels); a wave now draws six m-tiles' fragments for two n-tiles
+// instead of three for four (the head's pair of waves share them in L1).
+template <int KB32>   // ceil(C / 32): a 16-channel level is one zero-padded block
+__device__ __forceinline__ void qkv_att16_pm(const Ctx &c, int w_off, int s_off, const float *src, int C) {
+  using GG = Geo<64>;
+  using PGx = PG<16>;
+  const float *wp = c.w + w_off, *srow = c.w + s_off;
+  const int h = c.wave >> 1, s0 = 2 * (c.wave & 1);
+  const int p = c.lane & 15, g = c.lane >> 4;
+  const WStream wv(wp, c.lane);
+  // m-tile of accumulator i = 2 part + half: rows 128 part + 32 h + 16 half ..
+  auto mtile = [&](int i) { return 8 * (i >> 1) + 2 * h + (i & 1); };
+  const lds_u4 *pl3 = (const lds_u4 *)(c.lds + PGx::kX) + g * PGx::kCols + PGx::kOff + 4 * p + s0;
+  // One set of fragment registers: m-tile i's are refilled with the next block's behind the matrix instructions of m-tile
+  // i + 1 (a load into registers the pipe is still reading waits for it; double buffered, 96 registers of fragments beside 48
+  // accumulators, the op spilled 46).
+  u32x4 a[6][kSplit], bs[2][kSplit];
+  f32x4 acc[6][2];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) acc[i][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_a = [&](int i, int kb) {
+    const int sb = (mtile(i) * KB32 + kb) * kFragBytes;
+#pragma unroll
+    for (int pl = 0; pl < kSplit; ++pl) a[i][pl] = wv.raw_at(sb, pl * 1024);
+  };
+#pragma unroll
+  for (int i = 0; i < 6; ++i) load_a(i, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const float inv_c = __builtin_amdgcn_rcpf((float)C);  // C: a power of two -> exact
+    if (C == 16) column_stats8<2>(c, src, inv_c);
+    else column_stats8<4 * KB32>(c, src, inv_c);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kb = 0; kb < KB32; ++kb) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int pl = 0; pl < kSplit; ++pl) bs[e][pl] = pl3[(kb * kSplit + pl) * PGx::kPlaneU4 + e];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (i < 4) acc[i][e] = mfma_split(a[i], bs[e], acc[i][e]);
+        else acc[i][e] = mfma_split(bs[e], a[i], acc[i][e]);   // v^T: rows = positions, columns = v rows
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kb + 1 < KB32 && i >= 1) load_a(i - 1, kb + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kb + 1 < KB32) load_a(5, kb + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  f32x4 sv[4];   // s of the q and k rows 4 g + r of the wave's m-tiles; of the v rows: one per lane (row lane & 15)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sv[i] = *reinterpret_cast<const f32x4 *>(srow + 16 * mtile(i) + 4 * g);
+  const float svv[2] = {srow[16 * mtile(4) + p], srow[16 * mtile(5) + p]};
+  __syncthreads();  // every column's (mean, rstd) is in LDS
+  const lds_f *mean3 = (const lds_f *)(c.lds + GG::kMiscRed1), *rstd3 = (const lds_f *)(c.lds + GG::kMiscRed2);
+  constexpr float kL2e = 1.44269504088896340736f;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int sm = s0 + e;
+    {   // q, k: the lane's column is position p of the sample
+      const float rstd = rstd3[4 * p + sm];
+      const float mr = mean3[4 * p + sm] * rstd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][e][r] = (acc[i][e][r] * rstd - mr * sv[i][r]) * kL2e;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // v^T: register r is position 4 g + r
+      const float rstd = rstd3[4 * (4 * g + r) + sm];
+      const float mr = mean3[4 * (4 * g + r) + sm] * rstd;
+      acc[4][e][r] = acc[4][e][r] * rstd - mr * svv[0];
+      acc[5][e][r] = acc[5][e][r] * rstd - mr * svv[1];
+    }
+    const f32x4 qa[2] = {acc[0][e], acc[1][e]}, ka[2] = {acc[2][e], acc[3][e]}, vt[2] = {acc[4][e], acc[5][e]};
+    f32x4 o[2];
+    quad16_attention_head(qa, ka, vt, o);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)   // o[u][r]: channel 16 u + 4 g + r of head h at position p of sample sm
+      store_planes4<16>(c.lds + PGx::kH, kDimHead * h + 16 * u + 4 * g, 4 * p + sm, o[u][0], o[u][1], o[u][2], o[u][3]);
+  }
+  __syncthreads();
+}
+
 
 template <int NC, int L>
 __device__ __forceinline__ void run_tape(const Ctx &c0, const gldm_r1d_desc &d, const int *tape, kernarg_int *ktape, int n_ops, int E, long long *stamps) {
@@ -2994,19 +2924,16 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const gldm_r1d_desc &d, 
         }
         if (o[11]) __syncthreads();
         break;
-      case OP_QKVLN:
-        if constexpr (NC == 64 && L == 16) {
-          if (o[5] == 128) qkv_ln16_pm<4>(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4]);
-          else if (o[5] == 64) qkv_ln16_pm<2>(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4]);
-          else qkv_ln16_pm<1>(c, o[1], o[2], c.lds + o[3], o[5], c.lds + o[4]);
-        }
-        break;
       case OP_QKVATT:
         if constexpr (NC == 64 && L == 4) {
           if (o[4] == 128) qkv_att_pm<4>(c, o[1], o[2], c.lds + o[3], o[4]);
           else if (o[4] == 64) qkv_att_pm<2>(c, o[1], o[2], c.lds + o[3], o[4]);
           else if (o[4] == 32) qkv_att_pm<1>(c, o[1], o[2], c.lds + o[3], o[4]);
           else qkv_att_pm<0>(c, o[1], o[2], c.lds + o[3], o[4]);
+        } else if constexpr (NC == 64 && L == 16) {
+          if (o[4] == 128) qkv_att16_pm<4>(c, o[1], o[2], c.lds + o[3], o[4]);
+          else if (o[4] == 64) qkv_att16_pm<2>(c, o[1], o[2], c.lds + o[3], o[4]);
+          else qkv_att16_pm<1>(c, o[1], o[2], c.lds + o[3], o[4]);
         }
         break;
       case OP_OUTLN:
@@ -3018,7 +2945,6 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const gldm_r1d_desc &d, 
         break;
       default:
         if constexpr (NC != 64) attention_pair<NC, L>(c, c.lds + o[1], c.lds + o[2]);
-        else if constexpr (L == 16) attention16_pm(c, c.lds + o[1], o[2]);
         break;
     }
   }
@@ -3769,8 +3695,7 @@ int launch_r1d(const RunArgs &a_in, hipStream_t s) {
     for (int lv = quad ? 3 : 0; lv < a.d.n_levels; ++lv) {
       const int C = dims[lv];
       resblock(C); resblock(C);
-      if (pm16) { line(5, C, 384, 1); line(4, C, 128, 0); }
-      else if (pm) line(7, C, 384, 1);
+      if (pm) line(7, C, 384, 1);
       else { line(3, C, C, 0); line(1, C, 192, 1); line(4, C, 64, 0); line(1, C, 192, 1); line(4, C, 64, 0); }
       if (pm && (C == 4 || C == 16 || C == 32 || C == 64 || C == 128)) line(6, 128, C, 1);
       else { line(1, 128, C, 1); line(3, C, C, 0); }
