@@ -1497,6 +1497,14 @@ static int conv3d_k3_f16x2_impl(const float *x, const float *in_coef, const floa
   // halves pay a z halo and the weight stream twice.  Kept as an instantiable option, not used.  Round 6, with three f16
   // products instead of six bf16 ones: A/B of the whole encoder on one box 4.69 / 4.72 ms (full brick) against 4.63 / 4.84
   // (halves) -- inside the run-to-run spread, still not used.)
+  // Round 6, two more forms of the 24^3 conv measured on one box against this one (whole shipped encoder, 256 clouds, A/B by an
+  // environment switch of the diagnostic build; phase stamps of a mid-grid workgroup: taps 31 k of a brick's 70 k cycles,
+  // store phases 2.4-5.2 k and barrier waits 2.9-3.8 k per 16-channel block, epilogue 5.4 k):
+  //  * block cb + 1 split and stored INSIDE block cb's tap loop, one staging round behind every second tap pair (the other
+  //    plane set is free there): the store phases shrank to 0.3-1.1 k, the taps grew 10.4 -> 12.2 k and the barrier waits
+  //    3.5 -> 6-7 k -- 4.49-4.50 ms against 4.48: nothing.  The staging VALU work does not hide under the other wave's MFMAs;
+  //  * <3, 24, 24, 4>: four waves x six n-tiles (half the weight-fragment deliveries per MFMA), two workgroups per CU, no
+  //    staging prefetch across the tap loop (64 registers): 18-24 spilled registers, 4.58 against 4.63 ms: 1 %, not kept.
   if (cout == 48 && r == 24) return launch_conv_pl<3, 24, 24, 8>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
   if (cout == 96 && r == 12) return launch_conv_pl<6, 12, 12, 4>(x, w_split, bias, b, cin, cout, y, partial, in_coef, out_cl, s);
   // PVCNN2's power-of-two shapes (round 5; f32-MFMA kernels before): <MT, R, ZB, WAVES>
