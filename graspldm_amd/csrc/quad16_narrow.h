@@ -19,9 +19,11 @@
 //     the q and k accumulators as its operands as they stand (lane index = position on both sides); v is produced
 //     TRANSPOSED -- v^T = xn^T Wv^T, i.e. the to_qkv MFMAs of the v rows with the operands swapped (the normalised column
 //     fragment as A, the weight fragment as B) -- so that its accumulators are the A operand of out = V A, A's the B operand.
-//   * scale / shift of a ResnetBlock: rows of the per-cloud table (pose decoder, Ctx::ss_lane: SSF = 1) or the
-//     [2 C x 64] Linear on the f32 matrix pipe against the sample's 64 embedding sums, its f32 fragments through the ring
-//     (time-conditioned nets, the `ppc` denoiser: SSF = 4 fragments per m-tile, 32 matrix instructions each).
+//   * scale / shift of a ResnetBlock: rows of a table -- the per-cloud one of the pose decoder (Ctx::ss_lane), or, for the
+//     time-conditioned nets (the `ppc` denoiser: the rows change with the step), 448 rows per sample that ALL EIGHT waves
+//     compute in front of the chain (quad16_ss_rows: the six [2 C x 64] Linears as 28 m-tiles of 16 f32 MFMAs, dealt over the
+//     waves, into LDS behind the ring).  Inside the chain the same Linears cost one wave per sample 448 dependent f32 matrix
+//     instructions, 11.6 k cycles a step (the SSF = 4 stream below: built first, kept as an option, not instantiated).
 // Weights: the same LDS ring and loader waves as quad_narrow.h over this chain's fragment list (QStream16<SSF>: 336 / 380
 // fragments).
 #ifndef GLDM_QUAD16_NARROW_H_
@@ -450,6 +452,51 @@ __device__ __forceinline__ void quad16_attention(const Ctx &c, QRing &ring, cons
     for (int r = 0; r < 4; ++r) xr[mi][r] += (oacc[mi][r] - m2) * rs2 * gv[r];
   }
   q16_split<MT, KB>(xr, xp);
+}
+
+// The scale / shift rows of the six narrow ResnetBlocks for the tile's four samples, by all eight waves: LDS rows
+// [sample][448] in the table's order (block i at 0, 32, 64, 128, 192, 320: [C] scale then [C] shift), = ss_b + ss_w G[sample]
+// (ss_w: f32 fragments [m-tile][k-block 4][lane][4], r1d_pack.mfma_a_fragments; G: the 64 embedding sums, Geo::kMiscG).
+// Columns of the MFMA = samples (column & 3); columns 0 .. 3 are stored.  The caller puts a barrier behind it.
+constexpr int kQ16SsRows = 448;
+constexpr int kQ16SsLds = PG<16>::kX + 4 * PG<16>::kBlockFloats + 16 * 512;   // behind the ring's last slot: 2048 floats to the arena's end
+static_assert(kQ16SsLds + 4 * kQ16SsRows <= Geo<64>::kArena, "scale / shift rows behind the ring");
+__device__ __forceinline__ void quad16_ss_rows(const Ctx &c, kernarg_desc *dk) {
+  using GG = Geo<64>;
+  const int col = c.lane & 15, kq = c.lane >> 4;
+  const lds_f *Gs = (const lds_f *)(c.lds + GG::kMiscG) + (col & 3) * 64 + kq;
+  lds_f *rows = (lds_f *)(c.lds + kQ16SsLds) + (col & 3) * kQ16SsRows;
+  const int ssw[6] = {dk->rb[0].ss_w, dk->rb[1].ss_w, dk->rb[2].ss_w, dk->rb[3].ss_w, dk->rb[4].ss_w, dk->rb[5].ss_w};
+  const int ssb[6] = {dk->rb[0].ss_b, dk->rb[1].ss_b, dk->rb[2].ss_b, dk->rb[3].ss_b, dk->rb[4].ss_b, dk->rb[5].ss_b};
+  float gb[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) gb[i] = Gs[4 * i];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = c.wave + 8 * k;   // m-tile 0 .. 27 of the six blocks' 2 + 2 + 4 + 4 + 8 + 8 (wave uniform)
+    if (t < 28) {
+      // block, its first m-tile and table offset: constant indices only (kernel argument)
+      int w_off = ssw[0], b_off = ssb[0], mt = t, tab = 0;
+      if (t >= 2) { w_off = ssw[1]; b_off = ssb[1]; mt = t - 2; tab = 32; }
+      if (t >= 4) { w_off = ssw[2]; b_off = ssb[2]; mt = t - 4; tab = 64; }
+      if (t >= 8) { w_off = ssw[3]; b_off = ssb[3]; mt = t - 8; tab = 128; }
+      if (t >= 12) { w_off = ssw[4]; b_off = ssb[4]; mt = t - 12; tab = 192; }
+      if (t >= 20) { w_off = ssw[5]; b_off = ssb[5]; mt = t - 20; tab = 320; }
+      const WStream wv(c.w + w_off, c.lane);
+      f32x4 a[4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) a[kb] = wv[(size_t)(mt * 4 + kb) * 64];
+      f32x4 acc = *reinterpret_cast<const f32x4 *>(c.w + b_off + 16 * mt + 4 * kq);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb][j], gb[4 * kb + j], acc, 0, 0, 0);
+      if (col < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rows[tab + 16 * mt + 4 * kq + r] = acc[r];
+      }
+    }
+  }
 }
 
 // The chain.  Entry: X rows 0 .. 15 (f32, column = 4 * position + sample) hold the init conv's output, G the embedding

@@ -2899,20 +2899,20 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const gldm_r1d_desc &d, 
         } else if constexpr (NC == 64 && L == 16) {
           kernarg_desc *dkp = (kernarg_desc *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() +
                                                offsetof(RunArgs, d));
-          if (c.ss_lane) {   // pose decoder: scale / shift rows from the per-cloud table (wave uniform: the launch has one or not)
-            if (c.wave < 4) {
-              // the wave's sample's rows: Ctx::ss_lane of a lane whose sample (lane & 3) it is
-              const unsigned long long pv = (unsigned long long)c.ss_lane;
-              const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pv, c.wave);
-              const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), c.wave);
-              quad16_narrow_levels<1>(c, dkp, (const float *)(((unsigned long long)hi << 32) | lo));
-            } else {
-              quad_loader<QStream16<1>>(c);
-            }
-          } else {
-            if (c.wave < 4) quad16_narrow_levels<4>(c, dkp, nullptr);
-            else quad_loader<QStream16<4>>(c);
+          const float *sstab;   // the wave's sample's scale / shift rows of the six narrow ResnetBlocks
+          if (c.ss_lane) {   // pose decoder: the per-cloud table (wave uniform: the launch has one or not); Ctx::ss_lane of a
+                             // lane whose sample (lane & 3) is the wave's
+            const unsigned long long pv = (unsigned long long)c.ss_lane;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pv, c.wave & 3);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), c.wave & 3);
+            sstab = (const float *)(((unsigned long long)hi << 32) | lo);
+          } else {   // time-conditioned net: the step's rows by all eight waves first, into LDS behind the ring
+            quad16_ss_rows(c, dkp);
+            __syncthreads();
+            sstab = c.lds + kQ16SsLds + (c.wave & 3) * kQ16SsRows;
           }
+          if (c.wave < 4) quad16_narrow_levels<1>(c, dkp, sstab);
+          else quad_loader<QStream16<1>>(c);
           __syncthreads();
           zero_plane_pads16(c.lds, c.tid);   // the ring's slots lie over the H plane rows (conv2 of the next ResnetBlock reads them behind a barrier)
         }
@@ -3048,10 +3048,7 @@ __global__ __launch_bounds__(Geo<NC>::kThreads, 2) void r1d_kernel(const RunArgs
     if (quad_levels(d)) quad_build_table(d, reinterpret_cast<int *>(lds + GG::kMiscQTab), c.tid, GG::kThreads);
   }
   if constexpr (PM && L == 16) {
-    if (quad16) {   // the scale / shift rows from the per-cloud table, or the Linear in the chain (its fragments in the stream)
-      if (a.ss_tab) quad16_build_table<1>(d, reinterpret_cast<int *>(lds + GG::kMiscQTab), c.tid, GG::kThreads);
-      else quad16_build_table<4>(d, reinterpret_cast<int *>(lds + GG::kMiscQTab), c.tid, GG::kThreads);
-    }
+    if (quad16) quad16_build_table<1>(d, reinterpret_cast<int *>(lds + GG::kMiscQTab), c.tid, GG::kThreads);
   }
   int *tape = reinterpret_cast<int *>(lds + GG::kMiscTape);
   ChainHdr *hdr = reinterpret_cast<ChainHdr *>(a.ws);
