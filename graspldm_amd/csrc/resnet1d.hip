@@ -1744,10 +1744,11 @@ __device__ __forceinline__ void resblock4_pm(const Ctx &c, const int (&o)[kOpInt
 // accumulators.  Replaces a conv phase that stored y plus a LayerNorm phase that read it back (3 barriers).
 // NPW = partner waves of the LayerNorm merge, FULL = every row of the m-tile is a channel (C >= 16): compile-time, so that
 // the per-value code has no wave-uniform branches (each value used to be its own chain of basic blocks)
-template <int NT, int NPW, bool FULL, int LL = 4>
+// FIRST: block 0's fragments of the wave's m-tile, requested by the caller ahead of the call (Frag3), or NoFirst.
+template <int NT, int NPW, bool FULL, int LL = 4, class FIRST = NoFirst>
 __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const float *bias, int mt0, int nt0,
                                             bool active, int p0, const float *src, int cin, float *xres, int C,
-                                            const float *gain) {
+                                            const float *gain, const FIRST &first = FIRST()) {
   using GG = Geo<64>;
   constexpr int NC = 64;
   const int kq = c.lane >> 4, col = c.lane & 15;
@@ -1760,7 +1761,7 @@ __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + row0);
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) acc[0][ni] = bv;
-    gemm1_pl<kHidden / 32, 1, NT, NoPre, 1, LL>(c, wp, mt0, nt0, c.lds + PG<LL>::kH, acc);  // the attention output's planes (cin = 128)
+    gemm1_pl<kHidden / 32, 1, NT, NoPre, 1, LL, FIRST>(c, wp, mt0, nt0, c.lds + PG<LL>::kH, acc, NoPre(), first);  // the attention output's planes (cin = 128)
     gv = *reinterpret_cast<const f32x4 *>(gain + row0);
     const float inv_n = __builtin_amdgcn_rcpf((float)nloc);
 #pragma unroll
@@ -1819,6 +1820,21 @@ __device__ __forceinline__ void out_ln_wave(const Ctx &c, const float *wp, const
   __syncthreads();
 }
 
+// The 128-channel level's to_out with its first weight fragments requested by the caller in front of the attention op
+// (run_tape: OP_QKVATT followed by OP_OUTLN run as one case): cold at the top of this op they cost an L2 round trip with all
+// eight waves waiting.
+__device__ __forceinline__ Frag3 out_ln_request(const Ctx &c, int w_off) {
+  const WStream wv(c.w + w_off, c.lane);
+  Frag3 f;
+#pragma unroll
+  for (int pl = 0; pl < kSplit; ++pl) f.p[pl] = wv.raw_at((c.wave * (kHidden / 32)) * kFragBytes, pl * 1024);   // m-tile = wave, block 0
+  return f;
+}
+template <int LL = 4>
+__device__ __forceinline__ void out_ln_pm128(const Ctx &c, int w_off, int b_off, const float *src, int cin, float *xres, int g_off,
+                                             const Frag3 &first) {
+  out_ln_wave<4, 8, true, LL, Frag3>(c, c.w + w_off, c.w + b_off, c.wave, 0, true, 0, src, cin, xres, 128, c.w + g_off, first);
+}
 template <int LL = 4>
 __device__ __forceinline__ void out_ln_pm(const Ctx &c, int w_off, int b_off, const float *src, int cin, float *xres,
                                           int C, int g_off) {
@@ -2925,6 +2941,21 @@ __device__ __forceinline__ void run_tape(const Ctx &c0, const gldm_r1d_desc &d, 
         if (o[11]) __syncthreads();
         break;
       case OP_QKVATT:
+        if constexpr (NC == 64) {
+          if (o[4] == 128) {   // the 128-channel level: this op and the to_out op behind it as one case (see out_ln_request)
+            int q[kOpInts];
+            read_op<KARG>(tape, ktape, op + 1, q);
+            if (q[0] == OP_OUTLN && q[6] == 128) {
+              const Frag3 first = out_ln_request(c, q[1]);
+              if constexpr (L == 4) qkv_att_pm<4>(c, o[1], o[2], c.lds + o[3], o[4]);
+              else qkv_att16_pm<4>(c, o[1], o[2], c.lds + o[3], o[4]);
+              ++op;
+              if (stamps && c0.tid == 0) stamps[op] = (long long)__builtin_readcyclecounter();
+              out_ln_pm128<L == 16 ? 16 : 4>(c, q[1], q[2], c.lds + q[3], q[5], c.lds + q[4], q[7], first);
+              break;
+            }
+          }
+        }
         if constexpr (NC == 64 && L == 4) {
           if (o[4] == 128) qkv_att_pm<4>(c, o[1], o[2], c.lds + o[3], o[4]);
           else if (o[4] == 64) qkv_att_pm<2>(c, o[1], o[2], c.lds + o[3], o[4]);
