@@ -171,3 +171,55 @@ def test_non_finite_poses_raise(fpc_state_dict):
     bad_metas["grasp_mean"] = metas["grasp_mean"] * float("inf")
     with pytest.raises(GldmError, match="not finite"):
         inf.generate_grasps(pcn, bad_metas, num_grasps=2)
+
+
+@pytest.mark.parametrize("scale", [1e3, 3e4])
+def test_resnet_engines_under_wild_conditioning(scale, fpc_state_dict):
+    """The ResnetBlocks' H = act((scale + 1) GN(conv1) + shift) is the one operand of the fused ResNet1D engines whose size the
+    DATA sets (through the conditioning embedding): with conditioning rows 1e3 .. 3e4 times their usual size the scale / shift
+    rows reach 1e5 and H leaves the f16 range, so block1 writes H / hs with a power-of-two hs per sample and block2 folds it
+    back (conv_pm3_wave, quad_narrow.h, quad16_narrow.h).  All three 64-column paths -- the shipped 4-position denoiser, the
+    pose decoder (scale / shift rows from the per-cloud table) and a 16-position time-conditioned net (the `ppc` denoiser's
+    shape: rows computed in front of the wave-local chain) -- against the f64 oracle: as close as torch's own f32 (5e-7; bar 5e-6)."""
+    from oracle import torch_ref as R
+    from graspldm_amd.r1d import R1dEngine, pack_resnet1d
+    from graspldm_amd.resnets import TimeConditionedResNet1D
+    from graspldm_amd.synthetic import load_synthetic_weights
+    sd = fpc_state_dict
+    g = torch.Generator().manual_seed(5)
+    n = 11
+    z = torch.randn(n, 3, 64, generator=g) * scale
+
+    def err(a, b):
+        return (a.cpu().double() - b).abs().max().item()
+
+    # the shipped 4-position denoiser
+    p = "diffusion_model.model."
+    den = R1dEngine(pack_resnet1d(sd, p, groups=4, seq_len=4, num_steps=1000), "cuda:0")
+    x4 = torch.randn(n, 1, 4, generator=g)
+    t4 = torch.randint(0, 1000, (n,), generator=g)
+    sub64 = {k[len(p):]: v.double() for k, v in sd.items() if k.startswith(p)}
+    exp = R.resnet1d_forward(sub64, "", x4.double(), z_cond=z.double(), time=t4)
+    got = den.denoise(x4.cuda(), den.cond_embed(z.cuda()), 1, sample_t=t4.int().cuda())
+    assert torch.isfinite(got).all() and err(got, exp) < 5e-6, err(got, exp)
+    # the pose decoder
+    pd = "vae_model.decoder."
+    dec = R1dEngine(pack_resnet1d(sd, pd + "net.", groups=4, seq_len=16, decoder=dict(
+        in_w=sd[pd + "in_layer.weight"], in_b=sd[pd + "in_layer.bias"], tmrp_w=sd[pd + "tmrp.weight"],
+        tmrp_b=sd[pd + "tmrp.bias"], cls_w=sd[pd + "class_logits.weight"], cls_b=sd[pd + "class_logits.bias"])), "cuda:0")
+    zh = torch.randn(n, 4, generator=g)
+    tm64, lg64 = R.decoder_forward({k: v.double() for k, v in sd.items()}, pd, zh.double(), z.double())
+    tm, lg = dec.decode(zh.cuda(), dec.cond_embed(z.cuda()), 1)
+    assert torch.isfinite(tm).all() and err(tm, tm64) < 5e-6 and err(lg, lg64.reshape(lg.shape)) < 5e-6, (err(tm, tm64), err(lg, lg64.reshape(lg.shape)))
+    # a 16-position time-conditioned net
+    net = TimeConditionedResNet1D(dim=16, channels=1, block_channels=(32, 64, 128, 256), input_conditioning_dims=64,
+                                  resnet_block_groups=4, dropout=0.1, is_time_conditioned=True, learned_variance=False,
+                                  learned_sinusoidal_cond=False, random_fourier_features=True)
+    load_synthetic_weights(net, seed=7)
+    sd16 = {k: v.detach().clone().double() for k, v in net.state_dict().items()}
+    net = net.cuda().eval()
+    x = torch.randn(n, 1, 16, generator=g)
+    t = torch.randint(0, 1000, (n,), generator=g)
+    exp = R.resnet1d_forward(sd16, "", x.double(), z_cond=z.double(), time=t)
+    got = net(x.cuda(), time=t.cuda(), z_cond=z.cuda())
+    assert torch.isfinite(got).all() and err(got, exp) < 5e-6, err(got, exp)
